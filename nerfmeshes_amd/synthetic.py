@@ -1,0 +1,150 @@
+"""Seeded synthetic inputs for measurement and parity.
+
+Neither the lego dataset nor any pretrained checkpoint is available offline
+(`/root/reference/.MISSING_LARGE_BLOBS`), so every benchmark / parity run uses
+
+* weights: `torch.nn.Linear`-style uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) draws
+  from a numpy PCG64 stream (stable across numpy/torch versions, unlike
+  `torch.manual_seed`), optionally with a *density gain* that scales `fc_alpha`
+  so transmittance, inverse-CDF resampling and the iso-surface are non-trivial
+  (default init gives |sigma| ~ 0.1 -> alpha ~ 0 everywhere);
+* camera poses: the reference's own orbit `pose_spherical(theta, -30, 4.0)`
+  (/root/reference/src/data/data_helpers.py:32-37, src/data/datasets.py:105-117);
+* rays: the reference's pinhole model (src/nerf/nerf_helpers.py:226-277).
+
+Pure numpy; importable without torch or a GPU.
+"""
+import numpy as np
+
+LEGO_FOCAL_800 = 1111.1111  # /root/reference/src/mesh_surface_ray.py:90
+
+
+def mlp_layer_shapes(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10,
+                     num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=True,
+                     use_viewdirs=True, **_unused):
+    """(name, out, in) for every Linear of FlexibleNeRFModel, in state_dict order
+    (/root/reference/src/nerf/models.py:34-56)."""
+    dim_xyz = 6 * num_encoding_fn_xyz + (3 if include_input_xyz else 0)
+    dim_dir = (6 * num_encoding_fn_dir + (3 if include_input_dir else 0)) if use_viewdirs else 0
+    shapes = [("layer1", hidden_size, dim_xyz)]
+    for i in range(num_layers - 1):
+        skip = i % skip_step == 0 and i > 0 and i != num_layers - 1
+        shapes.append((f"layers_xyz.{i}", hidden_size, hidden_size + (dim_xyz if skip else 0)))
+    if use_viewdirs:
+        shapes.append(("layers_dir.0", hidden_size // 2, dim_dir + hidden_size))
+        shapes.append(("fc_alpha", 1, hidden_size))
+        shapes.append(("fc_rgb", 3, hidden_size // 2))
+        shapes.append(("fc_feat", hidden_size, hidden_size))
+    else:
+        shapes.append(("fc_out", 4, hidden_size))
+    return shapes
+
+
+def make_mlp_weights(seed, density_gain=1.0, density_bias=0.0, **mlp_kwargs):
+    """dict name -> float32 ndarray, keyed like FlexibleNeRFModel.state_dict()
+    (minus the two `frequency_bands` buffers, which are derived constants)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for name, n_out, n_in in mlp_layer_shapes(**mlp_kwargs):
+        bound = 1.0 / np.sqrt(n_in)
+        out[name + ".weight"] = rng.uniform(-bound, bound, size=(n_out, n_in)).astype(np.float32)
+        out[name + ".bias"] = rng.uniform(-bound, bound, size=(n_out,)).astype(np.float32)
+    key = "fc_alpha" if mlp_kwargs.get("use_viewdirs", True) else None
+    if key is not None:
+        out[key + ".weight"] = (out[key + ".weight"] * np.float32(density_gain)).astype(np.float32)
+        out[key + ".bias"] = (out[key + ".bias"] * np.float32(density_gain) + np.float32(density_bias)).astype(np.float32)
+    else:
+        out["fc_out.weight"][3] *= np.float32(density_gain)
+        out["fc_out.bias"][3] = out["fc_out.bias"][3] * np.float32(density_gain) + np.float32(density_bias)
+    return out
+
+
+def pose_spherical(theta, phi, radius):
+    """Camera-to-world of the reference's synthetic orbit (data_helpers.py:9-37)."""
+    tr = np.eye(4, dtype=np.float32)
+    tr[2, 3] = radius
+    p = phi / 180.0 * np.pi
+    rx = np.eye(4, dtype=np.float32)
+    rx[1, 1] = rx[2, 2] = np.cos(p)
+    rx[1, 2] = -np.sin(p)
+    rx[2, 1] = -rx[1, 2]
+    t = theta / 180 * np.pi
+    ry = np.eye(4, dtype=np.float32)
+    ry[0, 0] = ry[2, 2] = np.cos(t)
+    ry[0, 2] = -np.sin(t)
+    ry[2, 0] = -ry[0, 2]
+    c2w = ry @ (rx @ tr)
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
+    return c2w.astype(np.float32)
+
+
+def orbit_poses(count, phi=-30.0, radius=4.0):
+    """datasets.py:109-117 with a configurable number of views."""
+    return np.stack([pose_spherical(a, phi, radius) for a in np.linspace(-270, 90, count, endpoint=False)], 0)
+
+
+def pseudo_targets(n, seed=42):
+    """Seeded stand-in for ground-truth pixels (PSNR bookkeeping only)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.random((n, 3), dtype=np.float32)
+
+
+# Density calibration found for make_mlp_weights(seed=2) on the 8x256 net: acc_map mean ~0.9
+# along lego-orbit rays with bounds [2, 6], and the sigma=32 iso-surface exists inside the
+# [-1.2, 1.2]^3 mesh-extraction cube (about 1 % of the volume is above it).
+SCENE_SEED, SCENE_GAIN, SCENE_BIAS = 2, 3000.0, 50.0
+
+
+def make_scene_weights(seed=SCENE_SEED, **mlp_kwargs):
+    """'W1' of SURVEY.md section 8d: seeded weights with a non-degenerate density field."""
+    return make_mlp_weights(seed, density_gain=SCENE_GAIN, density_bias=SCENE_BIAS, **mlp_kwargs)
+
+
+def hparams(model="NeRFModel", hidden_size=256, num_layers=8, skip_step=4, num_encoding_fn_xyz=10,
+            num_encoding_fn_dir=4, num_coarse=64, num_fine=128, use_fine=True, near=2.0, far=6.0,
+            white_background=False, lindisp=False, chunksize=2048, dataset_type="blender", use_ndc=False):
+    """Flat dotted-key experiment config in the layout Lightning writes to `hparams.yaml`
+    (cf. /root/reference/pretrained/*/default/version_0/hparams.yaml); every key the hot
+    path or the three scripts read is present."""
+    mlp = dict(encoding="positional", hidden_size=hidden_size, include_input_dir=True, include_input_xyz=True,
+               log_sampling_dir=True, log_sampling_xyz=True, num_encoding_fn_dir=num_encoding_fn_dir,
+               num_encoding_fn_xyz=num_encoding_fn_xyz, num_layers=num_layers, num_layers_view=-1,
+               skip_step=skip_step, use_viewdirs=True)
+    flat = {
+        "experiment.id": "synthetic", "experiment.model": model, "experiment.description": "seeded synthetic",
+        "experiment.logdir": "../logs", "experiment.meshdir": "../data/meshes", "experiment.randomseed": 42,
+        "experiment.train_iters": 250000, "experiment.validate_every": 5000, "experiment.print_every": 100,
+        "experiment.use_early_stopping": False, "experiment.early_stopping_step": 25,
+        "experiment.chamfer_loss": False, "experiment.chamfer_sampling_size": 2400,
+        "logging.use_acronyms": True, "logging.use_projection": True, "logging.projection_step_size": 5000,
+        "dataset.type": dataset_type, "dataset.basedir": "../data/nerf_synthetic/lego",
+        "dataset.reduced_resolution": 1, "dataset.testskip": 1, "dataset.use_ndc": use_ndc,
+        "dataset.near": near, "dataset.far": far, "dataset.empty": 0.0, "dataset.num_workers": 0,
+        "dataset.llff_downsample_factor": 8, "dataset.llff_hold_step": 8,
+        "dataset.white_background": white_background,
+        "dataset.caching.use_caching": False, "dataset.caching.override_caching": False,
+        "dataset.caching.cache_dir": "../cache/synthetic", "dataset.caching.num_variations": 4,
+        "dataset.caching.sample_all": True,
+        "models.coarse_type": "FlexibleNeRFModel", "models.fine_type": "FlexibleNeRFModel",
+        "models.use_fine": use_fine,
+        "optimizer.type": "Adam", "optimizer.lr": 5.0e-3,
+        "scheduler.type": "DefaultScheduler", "scheduler.options.gamma": 0.1,
+        "scheduler.options.step_size": 450000,
+        "nerf.use_viewdirs": True, "nerf.encode_position_fn": "positional_encoding",
+        "nerf.encode_direction_fn": "positional_encoding",
+    }
+    for part in ("coarse", "fine"):
+        for k, v in mlp.items():
+            flat[f"models.{part}.{k}"] = v
+    for mode, noise in (("train", 0.2), ("validation", 0.0)):
+        flat.update({f"nerf.{mode}.chunksize": chunksize, f"nerf.{mode}.perturb": False,
+                     f"nerf.{mode}.num_coarse": num_coarse, f"nerf.{mode}.num_fine": num_fine,
+                     f"nerf.{mode}.radiance_field_noise_std": noise, f"nerf.{mode}.lindisp": lindisp})
+    flat["nerf.train.num_random_rays"] = 2048
+    flat["nerf.validation.num_samples"] = 1
+    if model == "BuFFModel":
+        flat.update({"tree.eps": 1.0e-4, "tree.max_depth": 4, "tree.max_voxel_count": 1536,
+                     "tree.step_size_integration_offset": 0, "tree.step_size_tree": 6000,
+                     "tree.subdivision_inner_count": 2, "tree.subdivision_outer_count": 12,
+                     "tree.use_random_sampling": False})
+    return flat

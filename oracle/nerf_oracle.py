@@ -1,0 +1,325 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the NeRF ray-batch path.
+
+A functional, stateless restatement -- in torch *CPU* fp32 ops, issued in the
+same order as the reference so that it is bit-identical to it on the same torch
+build -- of the reference hot path:
+
+  R0  get_ray_bundle / ndc_rays          /root/reference/src/nerf/nerf_helpers.py:226-307
+  R1  RaySampleInterval.forward          /root/reference/src/nerf/modules.py:157-186
+  R2  intervals_to_ray_points            /root/reference/src/models/model_helpers.py:32-35
+  R3a PositionalEncoding.forward         /root/reference/src/nerf/modules.py:26-34
+  R3b FlexibleNeRFModel.forward          /root/reference/src/nerf/models.py:60-80
+  R4  VolumeRenderer.forward             /root/reference/src/nerf/modules.py:67-121
+      cumprod_exclusive                  /root/reference/src/nerf/nerf_helpers.py:199-223
+  R5  SamplePDF.forward / sample_pdf     /root/reference/src/nerf/modules.py:197-248
+  R6  NeRFModel.forward / query          /root/reference/src/models/model_nerf.py:37-86
+  R7  BaseModel.sample_points            /root/reference/src/models/model_base.py:65-73
+  R8  eval_nerf loss/PSNR bookkeeping    /root/reference/src/eval_nerf.py:50-105
+  R11 extract_radiance / iso level       /root/reference/src/mesh_nerf.py:27-92
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may
+import this module, and only as the checker / timed CPU baseline.  The product
+(`nerfmeshes_amd`) never imports it and has no CPU fallback.
+
+Parity pin: the reference has no tests or golden vectors of its own
+(SURVEY.md F2).  This oracle is pinned instead against outputs of the
+unmodified reference executed in the build container
+(`tests/golden/make_golden.py` -> `tests/golden/*.npz`, checked by
+`tests/test_oracle_golden.py`) -- bit-exact there, and within 1e-5 on hosts
+whose BLAS picks a different summation order.
+
+Weights are passed as a plain dict keyed exactly like the reference
+`FlexibleNeRFModel.state_dict()` (`layer1.weight`, `layers_xyz.3.bias`, ...).
+"""
+from dataclasses import dataclass
+import math
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class MLPSpec:
+    """Hyper-parameters of FlexibleNeRFModel (models.py:5-19)."""
+    num_layers: int = 8
+    hidden_size: int = 256
+    skip_step: int = 4
+    num_encoding_fn_xyz: int = 10
+    num_encoding_fn_dir: int = 4
+    include_input_xyz: bool = True
+    include_input_dir: bool = True
+    log_sampling_xyz: bool = True
+    log_sampling_dir: bool = True
+    use_viewdirs: bool = True
+
+    @property
+    def dim_xyz(self):
+        return 6 * self.num_encoding_fn_xyz + (3 if self.include_input_xyz else 0)
+
+    @property
+    def dim_dir(self):
+        if not self.use_viewdirs:
+            return 0
+        return 6 * self.num_encoding_fn_dir + (3 if self.include_input_dir else 0)
+
+    def is_skip(self, i):
+        # models.py:37,63 -- layer i of layers_xyz consumes cat(hidden, xyz_enc)
+        return i % self.skip_step == 0 and i > 0 and i != self.num_layers - 1
+
+
+@dataclass(frozen=True)
+class RenderSpec:
+    """The subset of cfg.nerf.{train,validation} + cfg.dataset the path reads."""
+    num_coarse: int = 64
+    num_fine: int = 128
+    lindisp: bool = False
+    perturb: bool = False          # only the deterministic branch is restated
+    white_background: bool = False
+    attenuation_threshold: float = 1e-5   # model_base.py:32
+    noise_std: float = 0.0
+    training: bool = False
+
+
+def _t(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(torch.float32).cpu()
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+
+
+def frequency_bands(n, log_sampling=True):
+    """modules.py:16-23"""
+    if log_sampling:
+        return 2.0 ** torch.linspace(0.0, n - 1, n)
+    return torch.linspace(2.0 ** 0.0, 2.0 ** (n - 1), n)
+
+
+def positional_encoding(x, n_freq, include_input=True, log_sampling=True):
+    """R3a.  Coordinate-major layout: [x | sin(x_c * f_k) for c, k | cos(...)]."""
+    bands = frequency_bands(n_freq, log_sampling)
+    shape = list(x.shape)
+    scaled = (bands * x[..., None].expand(*shape, n_freq)).reshape(*shape[:-1], -1)
+    parts = ([x] if include_input else []) + [torch.sin(scaled), torch.cos(scaled)]
+    return torch.cat(parts, dim=-1)
+
+
+def mlp_forward(w, spec: MLPSpec, points, directions=None):
+    """R3b.  (N,3),(N,3) -> (N,4) = [sigmoid rgb | raw sigma]."""
+    lin = torch.nn.functional.linear
+    w = {k: _t(v) for k, v in w.items()}
+    points = _t(points)
+    enc = positional_encoding(points, spec.num_encoding_fn_xyz, spec.include_input_xyz, spec.log_sampling_xyz)
+    h = lin(enc, w["layer1.weight"], w["layer1.bias"])          # no activation (models.py:62)
+    for i in range(spec.num_layers - 1):
+        if spec.is_skip(i):
+            h = torch.cat((h, enc), dim=-1)                      # hidden first (models.py:65)
+        h = torch.relu(lin(h, w[f"layers_xyz.{i}.weight"], w[f"layers_xyz.{i}.bias"]))
+    if not spec.use_viewdirs:
+        out = lin(h, w["fc_out.weight"], w["fc_out.bias"])
+        out[..., :3] = torch.sigmoid(out[..., :3])
+        return out
+    view = positional_encoding(_t(directions), spec.num_encoding_fn_dir, spec.include_input_dir,
+                               spec.log_sampling_dir)
+    feat = torch.relu(lin(h, w["fc_feat.weight"], w["fc_feat.bias"]))
+    sigma = lin(h, w["fc_alpha.weight"], w["fc_alpha.bias"])
+    v = torch.cat((feat, view), dim=-1)                          # feat first (models.py:72)
+    v = torch.relu(lin(v, w["layers_dir.0.weight"], w["layers_dir.0.bias"]))
+    rgb = torch.sigmoid(lin(v, w["fc_rgb.weight"], w["fc_rgb.bias"]))
+    return torch.cat((rgb, sigma), dim=-1)
+
+
+def coarse_intervals(near, far, count, ray_count, lindisp=False):
+    """R1 (deterministic branch).  near/far: python floats, 0-dim or (R,) tensors."""
+    u = torch.linspace(0.0, 1.0, count)[None, :]
+    near = torch.as_tensor(near, dtype=torch.float32)
+    far = torch.as_tensor(far, dtype=torch.float32)
+    per_ray = near.dim() > 0 and near.shape[0] == ray_count
+    if per_ray:
+        near, far = near[:, None], far[:, None]
+    if not lindisp:
+        t = near * (1.0 - u) + far * u
+    else:
+        t = 1.0 / (1.0 / near * (1.0 - u) + 1.0 / far * u)
+    if not per_ray:
+        t = t.expand([ray_count, count])
+    return t
+
+
+def ray_points(t, directions, origins):
+    """R2: p = o + d * t, (R,S,3)."""
+    return origins[..., None, :] + directions[..., None, :] * t[..., :, None]
+
+
+def exclusive_cumprod(x):
+    """nerf_helpers.py:199-223"""
+    c = torch.roll(torch.cumprod(x, -1), 1, -1)
+    c[..., 0] = 1.0
+    return c
+
+
+def composite(radiance, t, directions, rs: RenderSpec):
+    """R4.  radiance (R,S,4), t (R,S), directions (R,3) -> dict of maps."""
+    big = torch.tensor([1e10])
+    dists = torch.cat((t[..., 1:] - t[..., :-1], big.expand(t[..., :1].shape)), dim=-1)
+    dists = dists * directions[..., None, :].norm(p=2, dim=-1)
+    rgb = radiance[..., :3]
+    sigma = torch.relu(radiance[..., 3] + 0.0)
+    alpha = 1.0 - torch.exp(-sigma * dists)
+    trans = exclusive_cumprod(1.0 - alpha + 1e-10)
+    mask = (trans > rs.attenuation_threshold).float()
+    weights = alpha * trans
+    rgb_map = (weights[..., None] * rgb).sum(dim=-2)
+    acc = weights.sum(dim=-1)
+    depth = (weights * t).sum(dim=-1)
+    disp = 1.0 / torch.max(1e-10 * torch.ones_like(depth), depth / acc)
+    disp[torch.isnan(disp)] = 0
+    if not rs.training:
+        depth[acc < 1.0] = 0                                     # modules.py:108-109
+    if rs.white_background:
+        rgb_map = rgb_map + (1.0 - acc[..., None])
+    return dict(rgb_map=rgb_map, depth_map=depth, weights=weights, mask_weights=mask,
+                acc_map=acc, disp_map=disp)
+
+
+def sample_pdf_intervals(t, weights, num_fine):
+    """R5, deterministic u.  t (R,Sc), weights (R,Sc) -> sorted (R, Sc+num_fine)."""
+    bins = 0.5 * (t[..., 1:] + t[..., :-1])
+    w = weights[..., 1:-1] + 1e-5
+    pdf = w / torch.sum(w, dim=-1, keepdim=True)
+    cdf = torch.cumsum(pdf, dim=-1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
+    u = torch.linspace(0.0, 1.0, steps=num_fine).expand(list(cdf.shape[:-1]) + [num_fine]).contiguous()
+    cdf = cdf.contiguous()
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo = torch.max(torch.zeros_like(idx), idx - 1)
+    hi = torch.min((cdf.shape[-1] - 1) * torch.ones_like(idx), idx)
+    both = torch.stack((lo, hi), dim=-1)
+    shape = (both.shape[0], both.shape[1], cdf.shape[-1])
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape), 2, both)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(shape), 2, both)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    frac = (u - cdf_g[..., 0]) / denom
+    new = bins_g[..., 0] + frac * (bins_g[..., 1] - bins_g[..., 0])
+    merged, _ = torch.sort(torch.cat((t, new), dim=-1), dim=-1)
+    return merged
+
+
+def render(w_coarse, w_fine, spec_c: MLPSpec, spec_f, rs: RenderSpec, origins, directions, near, far):
+    """R6: NeRFModel.forward.  Returns (coarse dict, fine dict | None); each dict also carries
+    `t` (the sample depths used) and `radiance`, which the reference does not expose but the
+    per-stage parity tests need."""
+    origins, directions = _t(origins), _t(directions)
+    R = directions.shape[0]
+    t = coarse_intervals(near, far, rs.num_coarse, R, rs.lindisp)
+    pts = ray_points(t, directions, origins)
+    dirs = directions[..., None, :].expand_as(pts)
+    rad = mlp_forward(w_coarse, spec_c, pts, dirs)
+    coarse = composite(rad, t, directions, rs)
+    coarse["t"], coarse["radiance"] = t, rad
+    fine = None
+    if w_fine is not None:
+        tf = sample_pdf_intervals(t, coarse["weights"], rs.num_fine)
+        pts = ray_points(tf, directions, origins)
+        dirs = directions[..., None, :].expand_as(pts)
+        radf = mlp_forward(w_fine, spec_f, pts, dirs)
+        fine = composite(radf, tf, directions, rs)
+        fine["t"], fine["radiance"] = tf, radf
+    return coarse, fine
+
+
+def query(*args, **kw):
+    """NeRFModel.query (model_nerf.py:80-86): finest bundle."""
+    c, f = render(*args, **kw)
+    return f if f is not None else c
+
+
+# ----------------------------------------------------------------------------- rays (R0)
+
+def pose_spherical(theta, phi, radius):
+    """data_helpers.py:8-37 (translate-z, rotate-phi about x, rotate-theta about y, axis flip)."""
+    tr = np.eye(4, dtype=np.float32)
+    tr[2, 3] = radius
+    p = phi / 180.0 * np.pi
+    rp = np.array([[1, 0, 0, 0], [0, np.cos(p), -np.sin(p), 0], [0, np.sin(p), np.cos(p), 0], [0, 0, 0, 1]],
+                  dtype=np.float32)
+    th = theta / 180.0 * np.pi
+    rt = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]],
+                  dtype=np.float32)
+    c2w = rt @ (rp @ tr)
+    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)
+    return (flip @ c2w).astype(np.float32)
+
+
+def get_ray_bundle(height, width, focal, c2w):
+    """R0: returns origin (3,), directions (H,W,3) unit length, row-major (row=j, col=i)."""
+    c2w = _t(c2w)
+    ii, jj = torch.meshgrid(torch.arange(width, dtype=torch.float32),
+                            torch.arange(height, dtype=torch.float32), indexing="ij")
+    ii, jj = ii.transpose(-1, -2), jj.transpose(-1, -2)
+    d = torch.stack([(ii - width * 0.5) / focal, -(jj - height * 0.5) / focal, -torch.ones_like(ii)], dim=-1)
+    d = d / d.norm(2, dim=-1)[..., None]
+    d = torch.sum(d[..., None, :] * c2w[:3, :3], dim=-1)
+    return c2w[:3, -1], d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """nerf_helpers.py:280-307"""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1.0 / (W / (2.0 * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1.0 / (H / (2.0 * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1.0 + 2.0 * near / rays_o[..., 2]
+    d0 = -1.0 / (W / (2.0 * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1.0 / (H / (2.0 * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2.0 * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+# ----------------------------------------------------------------------------- eval bookkeeping (R8)
+
+def view_loss(rgb, target, chunk):
+    """eval_nerf.py:56-76: fp32 tensor sum of per-chunk mse / FLOAT batch_count
+    (640000/2048 = 312.5 although 313 chunks run)."""
+    n = rgb.shape[0]
+    batch_count = n / chunk
+    loss = 0
+    for s in range(0, n, chunk):
+        loss += torch.nn.functional.mse_loss(rgb[s:s + chunk], target[s:s + chunk])
+    loss /= batch_count
+    return loss
+
+
+def mse2psnr(mse):
+    """nerf_helpers.py:17-23 (0-dim tensor in, 0-dim tensor out)."""
+    mse = torch.as_tensor(mse)
+    if mse == 0:
+        mse = torch.tensor(1e-5)
+    return -10.0 * torch.log10(mse)
+
+
+def dataset_loss(view_losses):
+    """eval_nerf.py:104: mean over views of the per-view losses."""
+    return torch.stack([torch.as_tensor(v) for v in view_losses]).mean()
+
+
+# ----------------------------------------------------------------------------- dense grid (R11)
+
+def grid_points(limit, res):
+    """mesh_nerf.py:37-40: linspace per axis, meshgrid ij, last axis fastest."""
+    nums = (res,) * 3 if isinstance(res, int) else tuple(res)
+    tiles = [torch.linspace(-limit, limit, n) for n in nums]
+    return torch.stack(torch.meshgrid(*tiles, indexing="ij"), -1).view(-1, 3).float()
+
+
+def extract_radiance(w, spec, limit, res, batch=65536):
+    """mesh_nerf.py:27-53: sample_points(p, p) -- the points themselves are the view dirs."""
+    pts = grid_points(limit, res)
+    out = [mlp_forward(w, spec, pts[s:s + batch], pts[s:s + batch]) for s in range(0, pts.shape[0], batch)]
+    nums = (res,) * 3 if isinstance(res, int) else tuple(res)
+    return torch.cat(out, 0).view(*nums, 4).contiguous().numpy()
+
+
+def iso_level(density, requested):
+    """mesh_nerf.py:56-65 on a numpy fp32 volume."""
+    lo, hi, sd = density.min(), density.max(), density.std()
+    return min(max(requested, lo + sd), hi - sd)

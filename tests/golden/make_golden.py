@@ -1,0 +1,175 @@
+"""Generate the committed golden fixtures by running the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Each fixture stores the seeds / small inputs and the reference's outputs for one case of
+the hot path.  Weights are NOT stored: they are re-derived from
+`nerfmeshes_amd.synthetic.make_mlp_weights(seed, ...)` (numpy PCG64 stream), and the npz
+records the generator arguments.  The reference model classes are instantiated from a flat
+hparams dict exactly as `load_from_checkpoint` would do (model_base.py:18-21).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import ref_import  # noqa: E402
+from nerfmeshes_amd import synthetic as S  # noqa: E402
+
+BUNDLE_KEYS = ("rgb_map", "depth_map", "weights", "mask_weights", "acc_map", "disp_map")
+
+
+def mlp_kwargs(hp, part):
+    keys = ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz", "num_encoding_fn_dir")
+    return {k: hp[f"models.{part}.{k}"] for k in keys}
+
+
+def load_weights(model, prefix, w):
+    sd = model.state_dict()
+    for k, v in w.items():
+        assert sd[prefix + k].shape == v.shape, (k, sd[prefix + k].shape, v.shape)
+        sd[prefix + k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+
+
+def lego_rays(n, view=1, views=4, size=800, focal=S.LEGO_FOCAL_800, stride=None):
+    nerf, _ = ref_import.load()
+    pose = torch.from_numpy(S.orbit_poses(views)[view])
+    o, d = nerf.get_ray_bundle(size, size, focal, pose)
+    d = d.reshape(-1, 3)
+    idx = torch.arange(n) * (stride or (d.shape[0] // n)) + 7
+    return o[None].contiguous(), d[idx].contiguous(), idx
+
+
+def bundle_to_np(prefix, b, out):
+    for k in BUNDLE_KEYS:
+        out[prefix + k] = getattr(b, k).numpy()
+
+
+def case_render(name, hp, seed_c, seed_f, gain, bias, n_rays, near, far, per_ray_origins=False, train_mode=False):
+    nerf, models = ref_import.load()
+    m = models.NeRFModel(hp)
+    m.eval()
+    wc = S.make_mlp_weights(seed_c, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "coarse"))
+    load_weights(m, "model_coarse.", wc)
+    if hp["models.use_fine"]:
+        wf = S.make_mlp_weights(seed_f, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+        load_weights(m, "model_fine.", wf)
+    o, d, idx = lego_rays(n_rays)
+    if per_ray_origins:
+        g = torch.Generator().manual_seed(5)
+        o = o + 0.05 * torch.randn(n_rays, 3, generator=g)
+        d = d * (1.0 + 0.3 * torch.rand(n_rays, 1, generator=g))   # non-unit directions (dists *= |d|)
+    bounds = torch.tensor([near, far], dtype=torch.float32)
+    with torch.no_grad():
+        coarse, fine = m.forward((o, d, bounds))
+    out = dict(origins=o.numpy(), directions=d.numpy(), bounds=bounds.numpy(),
+               seed_coarse=seed_c, seed_fine=seed_f, gain=gain, bias=bias,
+               hparams_keys=np.array(list(hp.keys())), hparams_vals=np.array([repr(v) for v in hp.values()]))
+    bundle_to_np("coarse.", coarse, out)
+    if fine is not None:
+        bundle_to_np("fine.", fine, out)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "rays", n_rays, "acc", float((fine or coarse).acc_map.mean()))
+
+
+def case_mlp(name, hp, seed, gain, bias, n):
+    """R3/R7: sample_points(points, dirs) on scattered points, incl. large coordinates."""
+    nerf, models = ref_import.load()
+    m = models.NeRFModel(hp).eval()
+    w = S.make_mlp_weights(seed, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+    load_weights(m, "model_fine.", w)
+    g = torch.Generator().manual_seed(11)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([6.0, 1.2, 3.0])
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    dirs[n // 2:] = pts[n // 2:]        # mesh_nerf.py:45 passes the points themselves as directions
+    with torch.no_grad():
+        out = m.sample_points(pts, dirs)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), points=pts.numpy(), directions=dirs.numpy(),
+                        radiance=out.numpy(), seed=seed, gain=gain, bias=bias)
+    print(name, out.shape)
+
+
+def case_grid(name, hp, seed, gain, bias, res, limit):
+    """R11: extract_radiance + extract_iso_level through the reference's own mesh_nerf functions."""
+    nerf, models = ref_import.load()
+    sys.path.insert(0, ref_import.REF_SRC)
+    import mesh_nerf
+    sys.path.remove(ref_import.REF_SRC)
+    m = models.NeRFModel(hp).eval()
+    w = S.make_mlp_weights(seed, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+    load_weights(m, "model_fine.", w)
+    args = type("A", (), dict(limit=limit, batch_size=1024, iso_level=32.0, res=res))()
+    import io, contextlib
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        rad = mesh_nerf.extract_radiance(m, args, "cpu", res)
+        iso = mesh_nerf.extract_iso_level(rad[..., 3], args)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), radiance=rad, iso=np.float32(iso), seed=seed,
+                        gain=gain, bias=bias, res=res, limit=limit)
+    print(name, rad.shape, "iso", iso)
+
+
+def case_rays(name):
+    """R0: get_ray_bundle and ndc_rays."""
+    nerf, _ = ref_import.load()
+    out = {}
+    for i, (h, w, f) in enumerate(((24, 32, 40.0), (16, 16, 22.2222))):
+        pose = torch.from_numpy(S.orbit_poses(5)[i + 1])
+        o, d = nerf.get_ray_bundle(h, w, f, pose)
+        out[f"pose{i}"], out[f"hwf{i}"] = pose.numpy(), np.array([h, w, f], dtype=np.float64)
+        out[f"origin{i}"], out[f"dirs{i}"] = o.numpy(), d.numpy()
+        ro = o.expand(h, w, 3) * 0.3
+        no, nd = nerf.ndc_rays(h, w, f, 1.0, ro, d)
+        out[f"ndc_o{i}"], out[f"ndc_d{i}"] = no.numpy(), nd.numpy()
+    # the 800x800 lego view: store a strided subset of directions
+    o, d, idx = lego_rays(4096)
+    out["lego_idx"], out["lego_dirs"], out["lego_origin"] = idx.numpy(), d.numpy(), o.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name)
+
+
+def case_eval_loss(name):
+    """R8: the per-view loss normalisation quirk of eval_nerf.py:56-76 (float batch_count)."""
+    nerf, _ = ref_import.load()
+    g = torch.Generator().manual_seed(3)
+    rgb, tgt = torch.rand(5000, 3, generator=g), torch.rand(5000, 3, generator=g)
+    chunk = 2048
+    batch_count = rgb.shape[0] / chunk
+    loss = 0.0
+    for (a, b) in nerf.batchify(rgb, tgt, batch_size=chunk, device="cpu", progress=False):
+        loss += torch.nn.functional.mse_loss(a, b)
+    loss /= batch_count
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=rgb.numpy(), target=tgt.numpy(), chunk=chunk,
+                        loss=loss.numpy(), psnr=nerf.mse2psnr(loss).numpy())
+    print(name, float(loss))
+
+
+def main():
+    lego = S.hparams()
+    case_render("render_lego_scene", lego, S.SCENE_SEED, S.SCENE_SEED, S.SCENE_GAIN, S.SCENE_BIAS, 96, 2.0, 6.0)
+    case_render("render_lego_default_init", lego, 1, 2, 1.0, 0.0, 32, 2.0, 6.0)
+    case_render("render_lego_perray_white_lindisp",
+                S.hparams(white_background=True, lindisp=True), 3, 4, 2500.0, 40.0, 48, 2.0, 6.0,
+                per_ray_origins=True)
+    case_render("render_tiny", S.hparams(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6, num_coarse=32,
+                                         num_fine=0, use_fine=False), 5, 5, 100.0, 0.0, 128, 2.0, 6.0)
+    case_render("render_fern_8x128", S.hparams(hidden_size=128, num_coarse=64, num_fine=64, near=0.0, far=1.2),
+                6, 7, 3000.0, 100.0, 64, 0.0, 1.2)
+    case_mlp("mlp_8x256_points", lego, S.SCENE_SEED, S.SCENE_GAIN, S.SCENE_BIAS, 512)
+    case_grid("grid_8x256_res20", lego, S.SCENE_SEED, S.SCENE_GAIN, S.SCENE_BIAS, 20, 1.2)
+    case_rays("rays")
+    case_eval_loss("eval_loss")
+
+
+if __name__ == "__main__":
+    main()
