@@ -1,0 +1,148 @@
+/*
+ * nerfmeshes_hip.h -- C ABI of the MI355X (gfx950) hot path of qway/nerfmeshes.
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own:
+ * its boundary is the Python class surface (models.NeRFModel.forward/query/sample_points,
+ * nerf.* helpers, mesh_nerf.extract_*).  This header is the C-ABI that sits *under* re-implemented
+ * Python classes of the same names (package `nerfmeshes_amd`); every entry point cites the
+ * reference code (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; nm_last_error() gives the message
+ *    (thread-local).  Nothing here ever falls back to a CPU path.
+ *  - `d_` pointers are DEVICE pointers (HBM) owned by the caller; `h_` pointers are HOST pointers.
+ *    The library allocates nothing on the hot calls; it owns only the packed weights in an
+ *    nm_mlp handle.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous.
+ *  - all floating point is IEEE fp32 (the reference never casts, train_nerf.py:38-41); index
+ *    outputs are int32 (marching cubes faces) or int64 (BuFF voxel ids) as in the reference.
+ */
+#ifndef NERFMESHES_HIP_H
+#define NERFMESHES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_ABI_VERSION 1
+
+const char* nm_last_error(void);
+int nm_abi_version(void);
+/* Number of visible HIP devices (<=0: none / error). */
+int nm_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * FlexibleNeRFModel  (src/nerf/models.py:4-80; PositionalEncoding src/nerf/modules.py:8-37)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nm_mlp_desc {
+    int32_t num_layers;           /* models.py:7   */
+    int32_t hidden_size;          /* models.py:8   */
+    int32_t skip_step;            /* models.py:9   */
+    int32_t num_encoding_fn_xyz;  /* models.py:10  */
+    int32_t num_encoding_fn_dir;  /* models.py:11  */
+    int32_t include_input_xyz;    /* models.py:12  */
+    int32_t include_input_dir;    /* models.py:13  */
+    int32_t use_viewdirs;         /* models.py:16 -- only 1 is implemented (all shipped configs) */
+} nm_mlp_desc;
+
+/* Host pointers to the tensors of FlexibleNeRFModel.state_dict(), torch.nn.Linear layout
+ * (out_features, in_features) row-major fp32.  layers_xyz_* have num_layers-1 entries. */
+typedef struct nm_mlp_weights {
+    const float* layer1_w;            const float* layer1_b;
+    const float* const* layers_xyz_w; const float* const* layers_xyz_b;
+    const float* layers_dir0_w;       const float* layers_dir0_b;
+    const float* fc_alpha_w;          const float* fc_alpha_b;
+    const float* fc_rgb_w;            const float* fc_rgb_b;
+    const float* fc_feat_w;           const float* fc_feat_b;
+    const float* freq_xyz;            /* encode_xyz.frequency_bands (num_encoding_fn_xyz) */
+    const float* freq_dir;            /* encode_dir.frequency_bands (num_encoding_fn_dir) */
+} nm_mlp_weights;
+
+typedef struct nm_mlp nm_mlp;
+
+/* Packs the weights into the MFMA operand stream and uploads them to `device`.
+ * Unsupported (hidden_size, num_encoding_fn_*) combinations fail with a message. */
+int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
+void nm_mlp_destroy(nm_mlp* mlp);
+/* FLOP of one sample through the net (weights-only count). */
+int64_t nm_mlp_flops_per_sample(const nm_mlp* mlp, int density_only);
+
+/* BaseModel.sample_points / FlexibleNeRFModel.forward  (src/models/model_base.py:65-73,
+ * src/nerf/models.py:60-80): d_points (n,3), d_dirs (n,3) -> d_radiance (n,4) = [sigmoid rgb, raw sigma]. */
+int nm_mlp_sample_points(nm_mlp* mlp, const float* d_points, const float* d_dirs, int64_t n,
+                         float* d_radiance, void* stream);
+
+/* intervals_to_ray_points + model(...) of NeRFModel.forward  (src/models/model_helpers.py:32-35,
+ * src/models/model_nerf.py:55-61,67-75): p = o + d * t (two roundings, as torch), view dir = d.
+ * d_origins is (1,3) when origins_per_ray == 0, else (rays,3); d_dirs (rays,3); d_t (rays,samples);
+ * d_radiance (rays,samples,4). */
+int nm_mlp_eval_rays(nm_mlp* mlp, const float* d_origins, int origins_per_ray, const float* d_dirs,
+                     const float* d_t, int64_t rays, int32_t samples, float* d_radiance, void* stream);
+
+/* extract_radiance  (src/mesh_nerf.py:37-51): grid point (i,j,k) = (ax0[i], ax1[j], ax2[k]), flattened
+ * with k fastest; the point itself is passed as view direction (mesh_nerf.py:45).  Evaluates points
+ * [first, first+count) of the flattened grid.  If density_only != 0 writes raw sigma (count,) --
+ * the colour branch is skipped -- else writes (count,4). */
+int nm_mlp_grid_query(nm_mlp* mlp, const float* d_ax0, const float* d_ax1, const float* d_ax2,
+                      int32_t n0, int32_t n1, int32_t n2, int64_t first, int64_t count,
+                      int32_t density_only, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray-batch primitives
+ * ------------------------------------------------------------------------------------------ */
+
+/* get_ray_bundle  (src/nerf/nerf_helpers.py:226-277): h_c2w = 12 floats (rows of [:3,:4]);
+ * writes unit directions for pixels [first, first+count) of the row-major (H,W) image into
+ * d_dirs (count,3), and the origin c2w[:3,3] into h_origin[3]. */
+int nm_ray_bundle(const float* h_c2w, int32_t height, int32_t width, float focal, int64_t first,
+                  int64_t count, float* d_dirs, float* h_origin, void* stream);
+
+/* RaySampleInterval.forward, deterministic branch  (src/nerf/modules.py:157-186):
+ * t[r][k] = near*(1-u[k]) + far*u[k]   (or the lindisp form).  d_u = linspace(0,1,samples) as the
+ * module buffer holds it; d_near/d_far are (1,) when bounds_per_ray == 0 else (rays,). */
+int nm_coarse_intervals(const float* d_u, const float* d_near, const float* d_far, int bounds_per_ray,
+                        int lindisp, int64_t rays, int32_t samples, float* d_t, void* stream);
+
+/* VolumeRenderer.forward + cumprod_exclusive  (src/nerf/modules.py:67-121,
+ * src/nerf/nerf_helpers.py:199-223), noise = 0.  Any output pointer may be NULL.
+ * d_radiance (rays,samples,4), d_t (rays,samples), d_dirs (rays,3). */
+typedef struct nm_bundle_out {
+    float* d_rgb_map;      /* (rays,3)       */
+    float* d_depth_map;    /* (rays,)        */
+    float* d_weights;      /* (rays,samples) */
+    float* d_mask_weights; /* (rays,samples) */
+    float* d_acc_map;      /* (rays,)        */
+    float* d_disp_map;     /* (rays,)        */
+} nm_bundle_out;
+int nm_composite(const float* d_radiance, const float* d_t, const float* d_dirs, int64_t rays,
+                 int32_t samples, float attenuation_threshold, int white_background, int training,
+                 const nm_bundle_out* out, void* stream);
+
+/* SamplePDF.forward / sample_pdf, deterministic u  (src/nerf/modules.py:197-248):
+ * d_t (rays,coarse), d_weights (rays,coarse), d_u = linspace(0,1,fine) -> d_t_out (rays,coarse+fine) sorted. */
+int nm_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int64_t rays,
+                  int32_t coarse, int32_t fine, float* d_t_out, void* stream);
+
+/* NeRFModel.forward  (src/models/model_nerf.py:37-78): the whole coarse -> resample -> fine chain in
+ * one call, all intermediates in caller-provided workspace (nm_render_workspace_bytes).  `fine`
+ * (and fine_out) may be NULL (models.use_fine False). */
+typedef struct nm_render_cfg {
+    int32_t num_coarse, num_fine;      /* cfg.nerf.train.num_coarse / num_fine (model_nerf.py:30-31) */
+    int32_t lindisp;                   /* cfg.nerf.{train,validation}.lindisp */
+    int32_t white_background;          /* cfg.dataset.white_background (model_base.py:31) */
+    int32_t training;                  /* module.training: toggles depth_map[acc<1]=0 (modules.py:108) */
+    float attenuation_threshold;       /* 1e-5 (model_base.py:32) */
+} nm_render_cfg;
+int64_t nm_render_workspace_bytes(int64_t rays, int32_t num_coarse, int32_t num_fine);
+int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const float* d_origins,
+                   int origins_per_ray, const float* d_dirs, const float* d_near, const float* d_far,
+                   int bounds_per_ray, const float* d_u_coarse, const float* d_u_fine, int64_t rays,
+                   void* d_workspace, const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFMESHES_HIP_H */

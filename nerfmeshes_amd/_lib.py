@@ -1,0 +1,103 @@
+"""ctypes binding of libnerfmeshes_hip.so (the C ABI declared in include/nerfmeshes_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or a symbol cannot be bound,
+importing the hot path raises.  `load()` only dlopens the library (works without a GPU -- used by
+the CPU test that checks every declared symbol is exported); compute calls need a MI355X.
+"""
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnerfmeshes_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_void_p = C.c_void_p
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz",
+                                         "num_encoding_fn_dir", "include_input_xyz", "include_input_dir",
+                                         "use_viewdirs")]
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("layer1_w", c_void_p), ("layer1_b", c_void_p),
+                ("layers_xyz_w", C.POINTER(c_void_p)), ("layers_xyz_b", C.POINTER(c_void_p)),
+                ("layers_dir0_w", c_void_p), ("layers_dir0_b", c_void_p),
+                ("fc_alpha_w", c_void_p), ("fc_alpha_b", c_void_p),
+                ("fc_rgb_w", c_void_p), ("fc_rgb_b", c_void_p),
+                ("fc_feat_w", c_void_p), ("fc_feat_b", c_void_p),
+                ("freq_xyz", c_void_p), ("freq_dir", c_void_p)]
+
+
+class BundleOut(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("d_rgb_map", "d_depth_map", "d_weights", "d_mask_weights", "d_acc_map",
+                                        "d_disp_map")]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("num_coarse", C.c_int32), ("num_fine", C.c_int32), ("lindisp", C.c_int32),
+                ("white_background", C.c_int32), ("training", C.c_int32), ("attenuation_threshold", C.c_float)]
+
+
+# name -> (restype, argtypes); the single source the symbol-export test iterates over.
+SIGNATURES = {
+    "nm_last_error": (C.c_char_p, []),
+    "nm_abi_version": (C.c_int, []),
+    "nm_device_count": (C.c_int, []),
+    "nm_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpWeights), C.c_int, C.POINTER(c_void_p)]),
+    "nm_mlp_destroy": (None, [c_void_p]),
+    "nm_mlp_flops_per_sample": (C.c_int64, [c_void_p, C.c_int]),
+    "nm_mlp_sample_points": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p]),
+    "nm_mlp_eval_rays": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p,
+                                   c_void_p]),
+    "nm_mlp_grid_query": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int64, C.c_int64, C.c_int32, c_void_p, c_void_p]),
+    "nm_ray_bundle": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_float, C.c_int64, C.c_int64, c_void_p,
+                                c_float_p, c_void_p]),
+    "nm_coarse_intervals": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int32,
+                                      c_void_p, c_void_p]),
+    "nm_composite": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int, C.c_int,
+                               C.POINTER(BundleOut), c_void_p]),
+    "nm_sample_pdf": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p]),
+    "nm_render_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "nm_render_rays": (C.c_int, [c_void_p, c_void_p, C.POINTER(RenderCfg), c_void_p, C.c_int, c_void_p, c_void_p,
+                                 c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, c_void_p, C.POINTER(BundleOut),
+                                 C.POINTER(BundleOut), c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every declared symbol; raises HipLibraryError loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m nerfmeshes_amd.build` "
+            "(there is no CPU fallback for the nerfmeshes hot path)")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.nm_abi_version() != 1:
+        raise HipLibraryError("ABI version mismatch between _lib.py and libnerfmeshes_hip.so")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().nm_last_error()
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,354 @@
+// Fused FlexibleNeRFModel forward for gfx950 (MI355X): positional encoding -> trunk -> sigma /
+// feature -> view branch -> rgb in ONE kernel, fp32 MFMA (v_mfma_f32_16x16x4_f32), activations
+// never leave registers, weights streamed L2 -> LDS with global_load_lds (direct-to-LDS DMA).
+//
+// Replaces (reference file:line under /root/reference/src):
+//   nerf/modules.py:26-34      PositionalEncoding.forward      (expand, mul, view, sin, cos, cat)
+//   nerf/models.py:60-80       FlexibleNeRFModel.forward       (12x addmm, 9x relu, 3x cat, sigmoid)
+//   models/model_helpers.py:32-35 intervals_to_ray_points      (RAYS mode prologue)
+//   mesh_nerf.py:37-40         grid point generation           (GRID mode prologue)
+//
+// Dataflow.  The network is evaluated transposed: out^T[feature][sample] = W[feature][k] * act^T[k][sample].
+// One wave owns 16 samples (the 16 MFMA columns).  For v_mfma_f32_16x16x4_f32
+//   A (weights): lane l holds W[row = l&15][k = l>>4]           (one VGPR)
+//   B (activ.) : lane l holds act[k = l>>4][sample = l&15]      (one VGPR)
+//   D          : lane l, reg r holds out[row = 4*(l>>4)+r][sample = l&15]
+// so D of tile nt, register r is exactly the B operand of the NEXT layer's k-step s = 4*nt + r, in
+// which lane group g = l>>4 supplies input feature k = 16*nt + 4*g + r.  The host packer
+// (mlp_pack.cpp) permutes the weight columns accordingly, which is why bias+ReLU'd accumulators
+// feed the next layer's MFMAs directly: no LDS round trip, no transposes, no HBM traffic for
+// activations.  Weights (2.4 MB / model, L2-resident) are the only streamed operand:
+// every workgroup pulls the same linear "A-operand stream" through a 2-deep LDS ring in 8-k-step
+// chunks; each lane reads its operands for 4 consecutive output tiles with one conflict-free
+// ds_read_b128.
+//
+// Roofline: MFMA (fp32 matrix peak 157.3 TFLOP/s).  593 408 MAC per sample for the 8x256 net; the
+// kernel issues 9 280 MFMAs (1 024 MAC each) per 16-sample tile = 99.9 % useful work.
+#include "nm_internal.h"
+
+namespace nm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int H_, int FX_, int FD_>
+struct Net {
+    static constexpr int H = H_, FX = FX_, FD = FD_;
+    static constexpr int NT = H / 16;                // 16-row output tiles of a hidden layer
+    static constexpr int KH = H / 4;                 // k-steps across a hidden activation
+    static constexpr int EX = (3 * FX + 1) / 2 + 1;  // k-steps across the xyz encoding
+    static constexpr int ED = (3 * FD + 1) / 2 + 1;  // k-steps across the dir encoding
+    static constexpr int NTD = H / 32;               // tiles of the H/2-wide view layer
+    static constexpr int KD = H / 8;                 // k-steps across the view layer output
+    static constexpr int STEP = NT * 256;            // bytes of A operands per k-step (hidden out)
+    static constexpr int STEPD = NTD * 256;
+    static constexpr int LDSBUF = KC * STEP;         // one ring slot
+    static constexpr int L1_FIRST = (EX < KC ? EX : KC) * STEP;
+    static constexpr int DIR_FIRST = KC * STEPD;     // KH + ED >= KC always
+};
+
+// ---- weight stream: HBM/L2 -> LDS DMA, 1 KiB per wave-instruction, LDS image == stream image ------
+template <int NW>
+__device__ __forceinline__ void stream_to_lds(const char* src, char* dst, int bytes, int wave, int lane) {
+    const int units = (bytes + 1023) >> 10;
+    for (int u = wave; u < units; u += NW) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)u * 1024 + lane * 16),
+            (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, 0, 0);
+    }
+}
+
+// One GEMM "stage": acc[NT tiles] += W_stage * B, B = KS1 registers of b1 followed by KS2 of b2.
+// On entry chunk 0 of the stage is resident in ring slot `par`; on exit the chunk described by
+// (tail_src, tail_bytes) -- the first chunk of whatever runs next -- is resident in slot `par`.
+template <int NT, int KS1, int KS2, int NW, int LDSBUF>
+__device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[KS1],
+                                           const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
+                                           const char* tail_src, int tail_bytes, char* lds, int& par,
+                                           int wave, int lane) {
+    constexpr int KS = KS1 + KS2;
+    constexpr int NCH = (KS + KC - 1) / KC;
+    constexpr int VW = NT >= 4 ? 4 : NT;  // A operands fetched per LDS read
+    constexpr int NB = NT / VW;
+    constexpr int STEP_BYTES = NT * 256;
+    static_assert(NT % VW == 0 && (VW == 4 || VW == 2), "tile count");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int steps = (KS - c * KC) < KC ? (KS - c * KC) : KC;
+        char* next_slot = lds + (par ^ 1) * LDSBUF;
+        if (c + 1 < NCH) {
+            const int nsteps = (KS - (c + 1) * KC) < KC ? (KS - (c + 1) * KC) : KC;
+            stream_to_lds<NW>(gw + (c + 1) * KC * STEP_BYTES, next_slot, nsteps * STEP_BYTES, wave, lane);
+        } else {
+            stream_to_lds<NW>(tail_src, next_slot, tail_bytes, wave, lane);
+        }
+        const char* buf = lds + par * LDSBUF + lane * (VW * 4);
+#pragma unroll
+        for (int ks = 0; ks < steps; ++ks) {
+            const int s = c * KC + ks;
+            const float b = s < KS1 ? b1[s < KS1 ? s : 0] : b2[s >= KS1 ? s - KS1 : 0];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if constexpr (VW == 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(buf + (ks * NB + blk) * (64 * 16));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[blk * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b, acc[blk * 4 + q], 0, 0, 0);
+                } else {
+                    const f32x2 a = *reinterpret_cast<const f32x2*>(buf + (ks * NB + blk) * (64 * 8));
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[blk * 2 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b, acc[blk * 2 + q], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)) and releases slot `par` for the next fill
+        par ^= 1;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x4 (&acc)[NT], const float* bias, int g) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(bias + 16 * nt + 4 * g);
+}
+
+template <int NT, bool RELU>
+__device__ __forceinline__ void acc_to_operand(const f32x4 (&acc)[NT], float (&op)[4 * NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[4 * nt + r] = RELU ? fmaxf(acc[nt][r], 0.0f) : acc[nt][r];
+}
+
+// Positional encoding, laid out as MFMA B operands.  k-step s < STEPS-1 carries two encoding
+// arguments a0 = 2s, a1 = 2s+1 (a = coord * F + freq, the reference's coordinate-major order):
+// lane group 0: sin(a0)  1: cos(a0)  2: sin(a1)  3: cos(a1).  The last step carries (x, y, z, 0).
+template <int F, int STEPS>
+__device__ __forceinline__ void encode(float (&enc)[STEPS], const float (&x)[3], const float* bands, int g) {
+    const bool hi = (g >> 1) != 0;
+    const bool want_cos = (g & 1) != 0;
+#pragma unroll
+    for (int s = 0; s < STEPS - 1; ++s) {
+        const int a0 = 2 * s, a1 = 2 * s + 1;
+        const float x0 = x[a0 / F] * bands[a0 % F];
+        const float x1 = (a1 < 3 * F) ? x[(a1 < 3 * F ? a1 : 0) / F] * bands[(a1 < 3 * F ? a1 : 0) % F] : 0.0f;
+        float sv, cv;
+        sincosf(hi ? x1 : x0, &sv, &cv);
+        enc[s] = want_cos ? cv : sv;
+    }
+    enc[STEPS - 1] = g == 0 ? x[0] : (g == 1 ? x[1] : (g == 2 ? x[2] : 0.0f));
+}
+
+__device__ __forceinline__ float group_sum(float v) {  // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int H, int FX, int FD, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const int num_layers,
+                                                      const int density_only) {
+    using N = Net<H, FX, FD>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+
+    const int64_t wg_iters = (args.n + NW * 16 - 1) / (NW * 16);
+    int par = 0;
+    const char* gw = args.wstream;
+    if ((int64_t)blockIdx.x < wg_iters) stream_to_lds<NW>(gw, lds, N::L1_FIRST, wave, lane);
+
+    for (int64_t it = blockIdx.x; it < wg_iters; it += gridDim.x) {
+        const bool has_next = it + gridDim.x < wg_iters;
+        const int64_t sample = (it * NW + wave) * 16 + col;
+        const bool valid = sample < args.n;
+        const int64_t sidx = valid ? sample : args.n - 1;
+
+        // ---- prologue: fetch the sample, build both encodings in registers
+        float p[3], d[3];
+        if (args.mode == MODE_POINTS) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { p[i] = args.a[3 * sidx + i]; d[i] = args.b[3 * sidx + i]; }
+        } else if (args.mode == MODE_RAYS) {
+            const int64_t ray = sidx / args.samples;
+            const float t = args.c[sidx];
+            const float* o = args.a + (args.origins_per_ray ? 3 * ray : 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                d[i] = args.b[3 * ray + i];
+                const float dt = d[i] * t;   // -ffp-contract=off: two roundings, as torch (model_helpers.py:33)
+                p[i] = o[i] + dt;
+            }
+        } else {
+            const int64_t flat = args.first + sidx;
+            const int64_t plane = (int64_t)args.n1 * args.n2;
+            const int64_t i0 = flat / plane;
+            const int64_t rem = flat - i0 * plane;
+            const int i1 = (int)(rem / args.n2), i2 = (int)(rem - (int64_t)i1 * args.n2);
+            p[0] = args.a[i0]; p[1] = args.b[i1]; p[2] = args.c[i2];
+            d[0] = p[0]; d[1] = p[1]; d[2] = p[2];   // mesh_nerf.py:45: sample_points(samples, samples)
+        }
+        float encx[N::EX], encd[N::ED];
+        encode<FX, N::EX>(encx, p, args.bands_xyz, g);
+        encode<FD, N::ED>(encd, d, args.bands_dir, g);
+        const float dummy[1] = {0.0f};
+
+        f32x4 acc[N::NT];
+        float in[N::KH];
+        __syncthreads();  // first chunk of layer1 resident (its DMA was issued one tile earlier)
+
+        // ---- layer1: xyz_enc -> H, no activation (models.py:62)
+        load_bias<N::NT>(acc, args.bias, g);
+        gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF, lds, par,
+                                                    wave, lane);
+        gw += N::EX * N::STEP;
+        acc_to_operand<N::NT, false>(acc, in);
+
+        // ---- layers_xyz[0 .. L-2], then fc_feat as iteration L-1 (models.py:63-70)
+        float sigma = 0.0f;
+        bool done = false;
+#pragma unroll 1
+        for (int i = 0; i < num_layers && !done; ++i) {
+            const bool is_feat = i == num_layers - 1;
+            if (is_feat) {
+                // fc_alpha on the pre-feature activation (models.py:71): 1-row GEMV on the VALU
+                float part = 0.0f;
+                const float* wa = args.walpha + g * N::KH;
+#pragma unroll
+                for (int s = 0; s < N::KH; s += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + s);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) part = fmaf(in[s + q], w4[q], part);
+                }
+                sigma = group_sum(part) + args.balpha;
+            }
+            const bool skip = !is_feat && ((args.skip_mask >> i) & 1u);
+            const bool last_density = density_only && i == num_layers - 2;
+            load_bias<N::NT>(acc, args.bias + H * (1 + i), g);
+            {
+                const char* tsrc = gw + N::KH * N::STEP;
+                int tbytes = N::LDSBUF;
+                if (skip) tbytes = N::L1_FIRST;               // the skip layer's encoding columns follow
+                else if (is_feat) tbytes = N::DIR_FIRST;      // view layer follows
+                else if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
+                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                gw += N::KH * N::STEP;
+            }
+            if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
+                const char* tsrc = gw + N::EX * N::STEP;
+                int tbytes = N::LDSBUF;
+                if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
+                gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                gw += N::EX * N::STEP;
+            }
+            acc_to_operand<N::NT, true>(acc, in);
+            done = last_density;
+        }
+
+        if (density_only) {
+            // the iteration that would compute sigma was skipped: do it here on the trunk output
+            float part = 0.0f;
+            const float* wa = args.walpha + g * N::KH;
+#pragma unroll
+            for (int s = 0; s < N::KH; s += 4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part = fmaf(in[s + q], w4[q], part);
+            }
+            sigma = group_sum(part) + args.balpha;
+            if (valid && g == 0) args.out[sample] = sigma;
+            gw = args.wstream;
+            continue;
+        }
+
+        // ---- layers_dir[0]: cat(feat, dir_enc) -> H/2, relu (models.py:72-74)
+        f32x4 accd[N::NTD];
+        float v[N::KD];
+        load_bias<N::NTD>(accd, args.bias + H * (1 + num_layers), g);
+        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF>(accd, in, encd, gw, args.wstream,
+                                                         has_next ? N::L1_FIRST : 0, lds, par, wave, lane);
+        gw = args.wstream;
+        acc_to_operand<N::NTD, true>(accd, v);
+
+        // ---- fc_rgb + sigmoid (models.py:75), 3-row GEMV on the VALU
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float part = 0.0f;
+            const float* wr = args.wrgb + (ch * 4 + g) * N::KD;
+#pragma unroll
+            for (int s = 0; s < N::KD; s += 4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part = fmaf(v[s + q], w4[q], part);
+            }
+            const float x = group_sum(part) + args.brgb[ch];
+            rgb[ch] = 1.0f / (1.0f + expf(-x));
+        }
+        if (valid && g == 0) {
+            f32x4 o4 = {rgb[0], rgb[1], rgb[2], sigma};
+            *reinterpret_cast<f32x4*>(args.out + 4 * sample) = o4;
+        }
+    }
+}
+
+// ---- host side: plan table + launcher ------------------------------------------------------
+struct MlpPlan {
+    int H, FX, FD, NW;
+    int lds_bytes;
+    void (*kernel)(const MlpArgs, const int, const int);
+};
+
+template <int H, int FX, int FD, int NW>
+static MlpPlan make_plan() {
+    return MlpPlan{H, FX, FD, NW, 2 * Net<H, FX, FD>::LDSBUF, &mlp_kernel<H, FX, FD, NW>};
+}
+
+static const MlpPlan g_plans[] = {
+    make_plan<256, 10, 4, 8>(),
+    make_plan<128, 10, 4, 8>(),
+    make_plan<64, 10, 4, 8>(),
+    make_plan<256, 6, 4, 8>(),
+    make_plan<128, 6, 4, 8>(),
+    make_plan<64, 6, 4, 8>(),
+};
+
+const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
+    for (const MlpPlan& p : g_plans)
+        if (p.H == H && p.FX == FX && p.FD == FD) return &p;
+    return nullptr;
+}
+
+int mlp_plan_info(const MlpPlan* p, int* nw) {
+    *nw = p->NW;
+    return 0;
+}
+
+int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream) {
+    const MlpPlan* p = m->plan;
+    if (args.n <= 0) return 0;
+    static bool attr_done[sizeof(g_plans) / sizeof(g_plans[0])] = {};
+    const int idx = (int)(p - g_plans);
+    if (!attr_done[idx]) {
+        NM_HIP_CHECK(hipFuncSetAttribute((const void*)p->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         p->lds_bytes));
+        attr_done[idx] = true;
+    }
+    const int64_t wg_iters = (args.n + p->NW * 16 - 1) / (p->NW * 16);
+    const int64_t resident = (int64_t)m->num_cus * 1;
+    // persistent-style launch: a few workgroups per CU queue so the tail is balanced.
+    int64_t grid = wg_iters < resident * 4 ? wg_iters : resident * 4;
+    // keep the per-workgroup iteration count even across the grid where possible
+    if (wg_iters > grid) {
+        const int64_t rounds = (wg_iters + grid - 1) / grid;
+        grid = (wg_iters + rounds - 1) / rounds;
+    }
+    hipLaunchKernelGGL(p->kernel, dim3((unsigned)grid), dim3(p->NW * 64), p->lds_bytes, stream, args,
+                       (int)m->desc.num_layers, density_only);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace nm

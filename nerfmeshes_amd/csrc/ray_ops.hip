@@ -1,0 +1,370 @@
+// Per-ray primitives of the NeRF render path for gfx950: one 64-lane wavefront per ray, the
+// sample axis (<= 256) lives in the wave, scans and reductions are wavefront shuffles.
+//
+// Replaces (reference file:line under /root/reference/src):
+//   nerf/nerf_helpers.py:226-277  get_ray_bundle
+//   nerf/modules.py:157-186       RaySampleInterval.forward (deterministic branch)
+//   nerf/modules.py:67-121        VolumeRenderer.forward    (+ nerf_helpers.py:199-223 cumprod_exclusive)
+//   nerf/modules.py:197-248       SamplePDF.forward / sample_pdf (deterministic u)
+//
+// All of these are HBM-bound streaming kernels (a few bytes in, a few bytes out per sample) and are
+// < 1 % of the time of the path; they are written for exact agreement with the torch CPU
+// semantics: torch.cumprod/cumsum accumulate in fp64 and round every output to fp32, torch.norm
+// is an fma chain, a*b+c is two roundings (this file is compiled with -ffp-contract=off).
+#include "nm_internal.h"
+
+namespace nm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta);
+    hi = __shfl_up(hi, delta);
+    return __hiloint2double(hi, lo);
+}
+
+// exclusive multiplicative / additive scan across the 64 lanes, fp64
+template <bool MUL>
+__device__ __forceinline__ double wave_exclusive_scan(double v, int lane) {
+    double incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = shfl_up_f64(incl, off);
+        if (lane >= off) incl = MUL ? incl * o : incl + o;
+    }
+    const double prev = shfl_up_f64(incl, 1);
+    return lane == 0 ? (MUL ? 1.0 : 0.0) : prev;
+}
+
+__device__ __forceinline__ float torch_norm3(float x, float y, float z) {
+    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));  // matches at::norm(p=2) on CPU bit for bit
+}
+
+// ---- R0: pinhole rays -----------------------------------------------------------------------
+struct Pose { float r[9]; };
+
+__global__ void ray_bundle_kernel(Pose pose, int height, int width, float focal, int64_t first, int64_t count,
+                                  float* __restrict__ dirs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t pix = first + i;
+    const int row = (int)(pix / width), colx = (int)(pix - (int64_t)row * width);
+    const float x = ((float)colx - (float)(width * 0.5)) / focal;
+    const float y = -((float)row - (float)(height * 0.5)) / focal;
+    const float z = -1.0f;
+    const float n = torch_norm3(x, y, z);
+    const float dx = x / n, dy = y / n, dz = z / n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dirs[3 * i + a] = (dx * pose.r[3 * a] + dy * pose.r[3 * a + 1]) + dz * pose.r[3 * a + 2];
+}
+
+// ---- R1: coarse depth samples -----------------------------------------------------------------
+__global__ void coarse_intervals_kernel(const float* __restrict__ u, const float* __restrict__ near_,
+                                        const float* __restrict__ far_, int per_ray, int lindisp, int64_t rays,
+                                        int samples, float* __restrict__ t) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rays * samples) return;
+    const int64_t ray = i / samples;
+    const int k = (int)(i - ray * samples);
+    const float nr = near_[per_ray ? ray : 0], fr = far_[per_ray ? ray : 0];
+    const float uk = u[k], om = 1.0f - uk;
+    float v;
+    if (!lindisp) {
+        v = nr * om + fr * uk;
+    } else {
+        const float a = (1.0f / nr) * om, b = (1.0f / fr) * uk;
+        v = 1.0f / (a + b);
+    }
+    t[i] = v;
+}
+
+// ---- R4: alpha compositing ----------------------------------------------------------------------
+// One wave per ray; lane owns PER consecutive samples.
+template <int PER>
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ radiance,
+                                                        const float* __restrict__ t, const float* __restrict__ dirs,
+                                                        int64_t rays, int samples, float thr, int white_bg,
+                                                        int training, nm_bundle_out out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= rays) return;
+    const float norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    const float* tr = t + ray * samples;
+    const f32x4* rr = reinterpret_cast<const f32x4*>(radiance) + ray * samples;
+
+    float alpha[PER], tt[PER];
+    f32x4 rad[PER];
+    double local = 1.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int s = lane * PER + q;
+        alpha[q] = 0.0f; tt[q] = 0.0f; rad[q] = f32x4{0, 0, 0, 0};
+        if (s < samples) {
+            tt[q] = tr[s];
+            rad[q] = rr[s];
+            float dist = (s + 1 < samples) ? (tr[s + 1] - tt[q]) : 1e10f;
+            dist = dist * norm;
+            const float sig = fmaxf(rad[q][3] + 0.0f, 0.0f);
+            alpha[q] = 1.0f - expf(-sig * dist);
+            local *= (double)((1.0f - alpha[q]) + 1e-10f);
+        }
+    }
+    double run = wave_exclusive_scan<true>(local, lane);  // product of everything before this lane
+    float r = 0, g = 0, b = 0, acc = 0, depth = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int s = lane * PER + q;
+        if (s < samples) {
+            const float T = (float)run;           // fp64 running product rounded per element, as torch.cumprod
+            const float w = alpha[q] * T;
+            if (out.d_weights) out.d_weights[ray * samples + s] = w;
+            if (out.d_mask_weights) out.d_mask_weights[ray * samples + s] = T > thr ? 1.0f : 0.0f;
+            r += w * rad[q][0]; g += w * rad[q][1]; b += w * rad[q][2];
+            acc += w;
+            depth += w * tt[q];
+            run *= (double)((1.0f - alpha[q]) + 1e-10f);
+        }
+    }
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); acc = wave_sum(acc); depth = wave_sum(depth);
+    if (lane == 0) {
+        float disp = 1.0f / fmaxf(1e-10f, depth / acc);
+        if (disp != disp || (depth / acc) != (depth / acc)) disp = 0.0f;  // NaN -> 0 (modules.py:107)
+        if (!training && acc < 1.0f) depth = 0.0f;                        // modules.py:108-109
+        if (white_bg) { const float bg = 1.0f - acc; r += bg; g += bg; b += bg; }
+        if (out.d_rgb_map) { out.d_rgb_map[3 * ray] = r; out.d_rgb_map[3 * ray + 1] = g; out.d_rgb_map[3 * ray + 2] = b; }
+        if (out.d_depth_map) out.d_depth_map[ray] = depth;
+        if (out.d_acc_map) out.d_acc_map[ray] = acc;
+        if (out.d_disp_map) out.d_disp_map[ray] = disp;
+    }
+}
+
+// ---- R5: inverse-CDF resampling + merge -------------------------------------------------------------
+constexpr int PDF_MAX_COARSE = 256;
+constexpr int PDF_MAX_TOTAL = 512;
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ t, const float* __restrict__ weights,
+                                                         const float* __restrict__ u, int64_t rays, int coarse,
+                                                         int fine, float* __restrict__ t_out) {
+    __shared__ float s_cdf[4][PDF_MAX_COARSE];
+    __shared__ float s_bins[4][PDF_MAX_COARSE];
+    __shared__ float s_all[4][PDF_MAX_TOTAL];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= rays) return;  // wave-uniform; no block-level barriers below
+    float* cdf = s_cdf[wv];
+    float* bins = s_bins[wv];
+    float* all = s_all[wv];
+    const float* tr = t + ray * coarse;
+    const float* wr = weights + ray * coarse;
+    const int nb = coarse - 1;   // bins / cdf entries
+    const int np = coarse - 2;   // pdf entries (weights[1:-1])
+
+    // bins, pdf numerators, their sum
+    float psum = 0.0f;
+    for (int i = lane; i < coarse; i += 64) {
+        const float ti = tr[i];
+        all[i] = ti;
+        if (i < nb) bins[i] = 0.5f * (tr[i + 1] + ti);
+        if (i < np) psum += wr[i + 1] + 1e-5f;
+    }
+    psum = wave_sum(psum);
+    // cdf = [0, cumsum(pdf)]: fp64 accumulation rounded per element (torch.cumsum on CPU)
+    double carry = 0.0;
+    for (int base = 0; base < np; base += 64) {
+        const int i = base + lane;
+        const double pdf = i < np ? (double)((wr[i + 1] + 1e-5f) / psum) : 0.0;
+        double incl = pdf;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = shfl_up_f64(incl, off);
+            if (lane >= off) incl += o;
+        }
+        incl += carry;
+        if (i < np) cdf[i + 1] = (float)incl;
+        int lo = __double2loint(incl), hi = __double2hiint(incl);
+        carry = __hiloint2double(__shfl(hi, 63), __shfl(lo, 63));
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // invert: idx = searchsorted(cdf, u, right=True)
+    for (int j = lane; j < fine; j += 64) {
+        const float uj = u[j];
+        int lo = 0, hi = nb;             // first index with cdf[idx] > uj
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < nb - 1 ? lo : nb - 1;
+        const float cb = cdf[below], ca = cdf[above];
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float frac = (uj - cb) / denom;
+        const float bb = bins[below], ba = bins[above];
+        all[coarse + j] = bb + frac * (ba - bb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // sort(cat(t, samples)): rank sort (any order of inputs, ties by index) -- 192 elements per ray
+    const int total = coarse + fine;
+    float* dst = t_out + ray * total;
+    for (int e = lane; e < total; e += 64) {
+        const float v = all[e];
+        int rank = 0;
+        for (int k = 0; k < total; ++k) {
+            const float o = all[k];
+            rank += (o < v || (o == v && k < e)) ? 1 : 0;
+        }
+        dst[rank] = v;
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+int launch_ray_bundle(const float* c2w, int height, int width, float focal, int64_t first, int64_t count, float* d_dirs,
+                      hipStream_t stream) {
+    if (count <= 0) return 0;
+    Pose p;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) p.r[3 * a + b] = c2w[4 * a + b];
+    hipLaunchKernelGGL(ray_bundle_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, p, height, width,
+                       focal, first, count, d_dirs);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_coarse_intervals(const float* d_u, const float* d_near, const float* d_far, int per_ray, int lindisp,
+                            int64_t rays, int samples, float* d_t, hipStream_t stream) {
+    const int64_t n = rays * samples;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(coarse_intervals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_u, d_near,
+                       d_far, per_ray, lindisp, rays, samples, d_t);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_composite(const float* d_radiance, const float* d_t, const float* d_dirs, int64_t rays, int samples, float thr,
+                     int white_bg, int training, const nm_bundle_out& out, hipStream_t stream) {
+    if (rays <= 0) return 0;
+    NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
+    const dim3 grid((unsigned)((rays + 3) / 4)), block(256);
+    const int per = (samples + 63) / 64;
+#define NM_COMPOSITE(P)                                                                                      \
+    hipLaunchKernelGGL(composite_kernel<P>, grid, block, 0, stream, d_radiance, d_t, d_dirs, rays, samples, thr, \
+                       white_bg, training, out)
+    switch (per) {
+        case 1: NM_COMPOSITE(1); break;
+        case 2: NM_COMPOSITE(2); break;
+        case 3: NM_COMPOSITE(3); break;
+        case 4: NM_COMPOSITE(4); break;
+        default: NM_COMPOSITE(8); break;
+    }
+#undef NM_COMPOSITE
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int coarse, int fine,
+                      float* d_t_out, hipStream_t stream) {
+    if (rays <= 0) return 0;
+    NM_REQUIRE(coarse >= 3 && coarse <= PDF_MAX_COARSE, "sample_pdf: num_coarse must be in [3, 256]");
+    NM_REQUIRE(fine >= 1 && coarse + fine <= PDF_MAX_TOTAL, "sample_pdf: num_coarse + num_fine must be <= 512");
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, stream, d_t, d_weights, d_u,
+                       rays, coarse, fine, d_t_out);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace nm
+
+using namespace nm;
+
+extern "C" {
+
+int nm_ray_bundle(const float* h_c2w, int32_t height, int32_t width, float focal, int64_t first, int64_t count,
+                  float* d_dirs, float* h_origin, void* stream) {
+    NM_REQUIRE(h_c2w && d_dirs && height > 0 && width > 0, "bad argument");
+    NM_REQUIRE(first >= 0 && count >= 0 && first + count <= (int64_t)height * width, "pixel range");
+    if (h_origin)
+        for (int a = 0; a < 3; ++a) h_origin[a] = h_c2w[4 * a + 3];
+    return launch_ray_bundle(h_c2w, height, width, focal, first, count, d_dirs, static_cast<hipStream_t>(stream));
+}
+
+int nm_coarse_intervals(const float* d_u, const float* d_near, const float* d_far, int bounds_per_ray, int lindisp,
+                        int64_t rays, int32_t samples, float* d_t, void* stream) {
+    NM_REQUIRE(d_u && d_near && d_far && d_t && samples > 0 && rays >= 0, "bad argument");
+    return launch_coarse_intervals(d_u, d_near, d_far, bounds_per_ray, lindisp, rays, samples, d_t,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int nm_composite(const float* d_radiance, const float* d_t, const float* d_dirs, int64_t rays, int32_t samples,
+                 float attenuation_threshold, int white_background, int training, const nm_bundle_out* out,
+                 void* stream) {
+    NM_REQUIRE(d_radiance && d_t && d_dirs && out && rays >= 0, "bad argument");
+    return launch_composite(d_radiance, d_t, d_dirs, rays, samples, attenuation_threshold, white_background, training,
+                            *out, static_cast<hipStream_t>(stream));
+}
+
+int nm_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int32_t coarse,
+                  int32_t fine, float* d_t_out, void* stream) {
+    NM_REQUIRE(d_t && d_weights && d_u && d_t_out && rays >= 0, "bad argument");
+    return launch_sample_pdf(d_t, d_weights, d_u, rays, coarse, fine, d_t_out, static_cast<hipStream_t>(stream));
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+int64_t nm_render_workspace_bytes(int64_t rays, int32_t num_coarse, int32_t num_fine) {
+    const size_t sc = (size_t)num_coarse, sf = (size_t)(num_coarse + (num_fine > 0 ? num_fine : 0));
+    size_t b = 0;
+    b += align256(rays * sc * 4);        // t coarse
+    b += align256(rays * sc * 16);       // radiance coarse
+    b += align256(rays * sc * 4);        // weights coarse (when the caller does not ask for them)
+    if (num_fine > 0) {
+        b += align256(rays * sf * 4);    // t fine
+        b += align256(rays * sf * 16);   // radiance fine
+    }
+    return (int64_t)b;
+}
+
+int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const float* d_origins, int origins_per_ray,
+                   const float* d_dirs, const float* d_near, const float* d_far, int bounds_per_ray,
+                   const float* d_u_coarse, const float* d_u_fine, int64_t rays, void* d_workspace,
+                   const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out, void* stream_) {
+    NM_REQUIRE(coarse && cfg && d_origins && d_dirs && d_near && d_far && d_u_coarse && d_workspace && coarse_out,
+               "bad argument");
+    NM_REQUIRE(!fine || (d_u_fine && fine_out && cfg->num_fine > 0), "fine network needs u_fine / fine_out / num_fine");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (rays <= 0) return 0;
+    const int sc = cfg->num_coarse, sf = cfg->num_coarse + cfg->num_fine;
+    char* ws = static_cast<char*>(d_workspace);
+    float* t_c = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sc * 4);
+    float* rad_c = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sc * 16);
+    float* w_c = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sc * 4);
+    int rc;
+    // RaySampleInterval -> intervals_to_ray_points -> model_coarse -> volume_renderer (model_nerf.py:52-62)
+    if ((rc = launch_coarse_intervals(d_u_coarse, d_near, d_far, bounds_per_ray, cfg->lindisp, rays, sc, t_c, stream))) return rc;
+    if ((rc = nm_mlp_eval_rays(coarse, d_origins, origins_per_ray, d_dirs, t_c, rays, sc, rad_c, stream))) return rc;
+    nm_bundle_out co = *coarse_out;
+    if (!co.d_weights) co.d_weights = w_c;
+    if ((rc = launch_composite(rad_c, t_c, d_dirs, rays, sc, cfg->attenuation_threshold, cfg->white_background,
+                               cfg->training, co, stream))) return rc;
+    if (!fine) return 0;
+    // sample_pdf -> intervals_to_ray_points -> model_fine -> volume_renderer (model_nerf.py:65-76)
+    float* t_f = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sf * 4);
+    float* rad_f = reinterpret_cast<float*>(ws);
+    if ((rc = launch_sample_pdf(t_c, co.d_weights, d_u_fine, rays, sc, cfg->num_fine, t_f, stream))) return rc;
+    if ((rc = nm_mlp_eval_rays(fine, d_origins, origins_per_ray, d_dirs, t_f, rays, sf, rad_f, stream))) return rc;
+    return launch_composite(rad_f, t_f, d_dirs, rays, sf, cfg->attenuation_threshold, cfg->white_background,
+                            cfg->training, *fine_out, stream);
+}
+
+}  // extern "C"

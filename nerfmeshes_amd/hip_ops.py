@@ -1,0 +1,209 @@
+"""Tensor-level host wrappers over the C ABI (torch is plumbing: device memory + streams).
+
+Every function takes/returns torch CUDA(HIP) fp32 tensors, launches on torch's current stream and
+raises if the HIP library is unavailable or an input is on the CPU -- no silent fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BundleOut, MlpDesc, MlpWeights, RenderCfg, check
+
+BUNDLE_FIELDS = ("rgb_map", "depth_map", "weights", "mask_weights", "acc_map", "disp_map")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev32(t, device=None, name="tensor"):
+    """contiguous fp32 tensor on the GPU; host tensors are accepted only where the reference
+    hands over host data (ray bounds: eval_nerf.py:65, mesh_nerf.py:179)."""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.float32)
+    if device is not None and t.device != device:
+        t = t.to(device)
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(f"{name} must live in GPU memory (got {t.device}); there is no CPU path")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class HipMLP:
+    """Device-resident packed copy of one FlexibleNeRFModel (handle of nm_mlp_create)."""
+
+    def __init__(self, state, desc, device):
+        """state: dict name -> array-like in torch.nn.Linear layout, keyed like
+        FlexibleNeRFModel.state_dict(); desc: dict of constructor hyper-parameters."""
+        lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HipLibraryError("HipMLP needs a GPU device")
+        L = int(desc["num_layers"])
+        host = {}
+
+        def arr(key):
+            v = state[key]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            host[key] = np.ascontiguousarray(a, dtype=np.float32)
+            return C.c_void_p(host[key].ctypes.data)
+
+        fx, fd = int(desc["num_encoding_fn_xyz"]), int(desc["num_encoding_fn_dir"])
+        for key, n, log in (("encode_xyz.frequency_bands", fx, desc.get("log_sampling_xyz", True)),
+                            ("encode_dir.frequency_bands", fd, desc.get("log_sampling_dir", True))):
+            if key not in state:
+                state = dict(state)
+                state[key] = (2.0 ** torch.linspace(0.0, n - 1, n)) if log else torch.linspace(1.0, 2.0 ** (n - 1), n)
+        d = MlpDesc(L, int(desc["hidden_size"]), int(desc["skip_step"]), fx, fd,
+                    int(bool(desc.get("include_input_xyz", True))), int(bool(desc.get("include_input_dir", True))),
+                    int(bool(desc.get("use_viewdirs", True))))
+        if not d.use_viewdirs:
+            raise _lib.HipLibraryError("use_viewdirs=False networks are not implemented on the HIP path")
+        xs_w = (C.c_void_p * (L - 1))(*[arr(f"layers_xyz.{i}.weight") for i in range(L - 1)])
+        xs_b = (C.c_void_p * (L - 1))(*[arr(f"layers_xyz.{i}.bias") for i in range(L - 1)])
+        w = MlpWeights(arr("layer1.weight"), arr("layer1.bias"), xs_w, xs_b,
+                       arr("layers_dir.0.weight"), arr("layers_dir.0.bias"),
+                       arr("fc_alpha.weight"), arr("fc_alpha.bias"), arr("fc_rgb.weight"), arr("fc_rgb.bias"),
+                       arr("fc_feat.weight"), arr("fc_feat.bias"),
+                       arr("encode_xyz.frequency_bands"), arr("encode_dir.frequency_bands"))
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        check(lib.nm_mlp_create(C.byref(d), C.byref(w), idx, C.byref(self._h)), "nm_mlp_create")
+        self._lib = lib
+        self.desc = dict(desc)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.nm_mlp_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def flops_per_sample(self, density_only=False):
+        return int(self._lib.nm_mlp_flops_per_sample(self._h, int(density_only)))
+
+    def sample_points(self, points, dirs):
+        points, dirs = _dev32(points, self.device, "points"), _dev32(dirs, self.device, "dirs")
+        lead = points.shape[:-1]
+        points, dirs = points.reshape(-1, 3), dirs.expand(*lead, 3).reshape(-1, 3).contiguous()
+        out = torch.empty(points.shape[0], 4, dtype=torch.float32, device=self.device)
+        check(self._lib.nm_mlp_sample_points(self._h, _ptr(points), _ptr(dirs), points.shape[0], _ptr(out), _stream()),
+              "nm_mlp_sample_points")
+        return out.reshape(*lead, 4)
+
+    def eval_rays(self, origins, dirs, t):
+        origins, dirs, t = (_dev32(x, self.device) for x in (origins, dirs, t))
+        rays, samples = t.shape
+        per_ray = int(origins.reshape(-1, 3).shape[0] == rays and rays > 1)
+        out = torch.empty(rays, samples, 4, dtype=torch.float32, device=self.device)
+        check(self._lib.nm_mlp_eval_rays(self._h, _ptr(origins), per_ray, _ptr(dirs), _ptr(t), rays, samples,
+                                         _ptr(out), _stream()), "nm_mlp_eval_rays")
+        return out
+
+    def grid_query(self, ax0, ax1, ax2, first=0, count=None, density_only=True, out=None):
+        ax = [_dev32(a, self.device) for a in (ax0, ax1, ax2)]
+        n0, n1, n2 = (a.numel() for a in ax)
+        count = n0 * n1 * n2 - first if count is None else count
+        if out is None:
+            out = torch.empty((count,) if density_only else (count, 4), dtype=torch.float32, device=self.device)
+        check(self._lib.nm_mlp_grid_query(self._h, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), n0, n1, n2, first, count,
+                                          int(density_only), _ptr(out), _stream()), "nm_mlp_grid_query")
+        return out
+
+
+def ray_bundle(c2w, height, width, focal, first=0, count=None, device="cuda"):
+    """get_ray_bundle on the GPU: (origin (3,) on `device`, dirs (count,3))."""
+    lib = _lib.load()
+    count = height * width - first if count is None else count
+    pose = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w,
+                                           dtype=np.float32)[:3, :4])
+    dirs = torch.empty(count, 3, dtype=torch.float32, device=device)
+    origin = np.zeros(3, dtype=np.float32)
+    check(lib.nm_ray_bundle(pose.ctypes.data_as(_lib.c_float_p), height, width, float(focal), first, count,
+                            _ptr(dirs), origin.ctypes.data_as(_lib.c_float_p), _stream()), "nm_ray_bundle")
+    return torch.from_numpy(origin).to(device), dirs
+
+
+def coarse_intervals(u, near, far, rays, lindisp=False):
+    lib = _lib.load()
+    u = _dev32(u)
+    near, far = _dev32(near, u.device).reshape(-1), _dev32(far, u.device).reshape(-1)
+    per_ray = int(near.numel() == rays and rays > 1)
+    t = torch.empty(rays, u.numel(), dtype=torch.float32, device=u.device)
+    check(lib.nm_coarse_intervals(_ptr(u), _ptr(near), _ptr(far), per_ray, int(lindisp), rays, u.numel(), _ptr(t),
+                                  _stream()), "nm_coarse_intervals")
+    return t
+
+
+def _alloc_bundle(rays, samples, device, want=BUNDLE_FIELDS):
+    shapes = dict(rgb_map=(rays, 3), depth_map=(rays,), weights=(rays, samples), mask_weights=(rays, samples),
+                  acc_map=(rays,), disp_map=(rays,))
+    tensors = {k: torch.empty(shapes[k], dtype=torch.float32, device=device) for k in want}
+    out = BundleOut(*[_ptr(tensors.get(k)) for k in BUNDLE_FIELDS])
+    return tensors, out
+
+
+def composite(radiance, t, dirs, attenuation_threshold=1e-5, white_background=False, training=False):
+    lib = _lib.load()
+    radiance, t = _dev32(radiance), _dev32(t)
+    dirs = _dev32(dirs, radiance.device)
+    rays, samples = t.shape
+    tensors, out = _alloc_bundle(rays, samples, radiance.device)
+    check(lib.nm_composite(_ptr(radiance), _ptr(t), _ptr(dirs), rays, samples, float(attenuation_threshold),
+                           int(white_background), int(training), C.byref(out), _stream()), "nm_composite")
+    return tensors
+
+
+def sample_pdf(t, weights, u):
+    lib = _lib.load()
+    t, weights = _dev32(t), _dev32(weights)
+    u = _dev32(u, t.device)
+    rays, coarse = t.shape
+    out = torch.empty(rays, coarse + u.numel(), dtype=torch.float32, device=t.device)
+    check(lib.nm_sample_pdf(_ptr(t), _ptr(weights), _ptr(u), rays, coarse, u.numel(), _ptr(out), _stream()),
+          "nm_sample_pdf")
+    return out
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def render_rays(coarse, fine, origins, dirs, near, far, u_coarse, u_fine, lindisp=False, white_background=False,
+                training=False, attenuation_threshold=1e-5):
+    """NeRFModel.forward in one C call.  Returns (coarse dict, fine dict | None)."""
+    lib = _lib.load()
+    device = coarse.device
+    origins, dirs = _dev32(origins, device, "origins").reshape(-1, 3), _dev32(dirs, device, "dirs").reshape(-1, 3)
+    rays = dirs.shape[0]
+    near, far = _dev32(near, device).reshape(-1), _dev32(far, device).reshape(-1)
+    u_coarse = _dev32(u_coarse, device)
+    sc = u_coarse.numel()
+    nf = 0 if fine is None else int(u_fine.numel())
+    u_f = None if fine is None else _dev32(u_fine, device)
+    cfg = RenderCfg(sc, nf, int(lindisp), int(white_background), int(training), float(attenuation_threshold))
+    ws = _workspace(int(lib.nm_render_workspace_bytes(rays, sc, nf)), device)
+    ct, cout = _alloc_bundle(rays, sc, device)
+    ft, fout = (None, None) if fine is None else _alloc_bundle(rays, sc + nf, device)
+    per_ray_o = int(origins.shape[0] == rays and rays > 1)
+    per_ray_b = int(near.numel() == rays and rays > 1)
+    check(lib.nm_render_rays(coarse.handle, fine.handle if fine is not None else None, C.byref(cfg), _ptr(origins),
+                             per_ray_o, _ptr(dirs), _ptr(near), _ptr(far), per_ray_b, _ptr(u_coarse), _ptr(u_f),
+                             rays, _ptr(ws), C.byref(cout), C.byref(fout) if fout is not None else None, _stream()),
+          "nm_render_rays")
+    return ct, ft
