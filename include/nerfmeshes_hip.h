@@ -69,6 +69,12 @@ void nm_mlp_destroy(nm_mlp* mlp);
 /* FLOP of one sample through the net (weights-only count). */
 int64_t nm_mlp_flops_per_sample(const nm_mlp* mlp, int density_only);
 
+/* Measurement hook (no reference counterpart): while enabled, every launch of the fused MLP kernel is
+ * bracketed by hipEvents on its own stream.  nm_mlp_profile_read synchronises those events, returns
+ * the number of launches, their summed duration and summed ALGORITHMIC flops, and clears the list. */
+int nm_mlp_profile_enable(int on);
+int nm_mlp_profile_read(int64_t* launches, double* total_ms, double* total_flops);
+
 /* BaseModel.sample_points / FlexibleNeRFModel.forward  (src/models/model_base.py:65-73,
  * src/nerf/models.py:60-80): d_points (n,3), d_dirs (n,3) -> d_radiance (n,4) = [sigmoid rgb, raw sigma]. */
 int nm_mlp_sample_points(nm_mlp* mlp, const float* d_points, const float* d_dirs, int64_t n,

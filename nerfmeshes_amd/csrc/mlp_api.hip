@@ -60,6 +60,24 @@ static void pack_gemm(std::vector<float>& out, const float* W, int ld, int rows,
                 }
 }
 
+// ---- optional per-launch timing of the dominant kernel (bench.py's roofline leg) ---------------
+struct ProfRec { hipEvent_t start, stop; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+static int launch_mlp_timed(const nm_mlp* m, const MlpArgs& a, int density_only, hipStream_t stream) {
+    if (!g_prof_on || a.n <= 0) return launch_mlp(m, a, density_only, stream);
+    ProfRec r;
+    NM_HIP_CHECK(hipEventCreate(&r.start));
+    NM_HIP_CHECK(hipEventCreate(&r.stop));
+    r.flops = (double)a.n * (double)(density_only ? m->flops_density : m->flops_full);
+    NM_HIP_CHECK(hipEventRecord(r.start, stream));
+    const int rc = launch_mlp(m, a, density_only, stream);
+    NM_HIP_CHECK(hipEventRecord(r.stop, stream));
+    g_prof.push_back(r);
+    return rc;
+}
+
 static int64_t mlp_macs(const nm_mlp_desc& d, bool density_only) {
     const int64_t H = d.hidden_size, dx = 6 * d.num_encoding_fn_xyz + (d.include_input_xyz ? 3 : 0);
     const int64_t dd = 6 * d.num_encoding_fn_dir + (d.include_input_dir ? 3 : 0);
@@ -85,6 +103,27 @@ int nm_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
     return n;
+}
+
+int nm_mlp_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int nm_mlp_profile_read(int64_t* launches, double* total_ms, double* total_flops) {
+    double ms = 0, fl = 0;
+    for (ProfRec& r : g_prof) {
+        NM_HIP_CHECK(hipEventSynchronize(r.stop));
+        float t = 0;
+        NM_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
+        ms += t; fl += r.flops;
+        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+    }
+    if (launches) *launches = (int64_t)g_prof.size();
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    g_prof.clear();
+    return 0;
 }
 
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, nm_mlp** out) {
@@ -195,7 +234,7 @@ int nm_mlp_sample_points(nm_mlp* m, const float* d_points, const float* d_dirs, 
     a.mode = MODE_POINTS;
     a.a = d_points; a.b = d_dirs; a.c = nullptr;
     a.n = n; a.out = d_radiance;
-    return launch_mlp(m, a, 0, static_cast<hipStream_t>(stream));
+    return launch_mlp_timed(m, a, 0, static_cast<hipStream_t>(stream));
 }
 
 int nm_mlp_eval_rays(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
@@ -206,7 +245,7 @@ int nm_mlp_eval_rays(nm_mlp* m, const float* d_origins, int origins_per_ray, con
     a.a = d_origins; a.b = d_dirs; a.c = d_t;
     a.origins_per_ray = origins_per_ray; a.samples = samples;
     a.n = rays * samples; a.out = d_radiance;
-    return launch_mlp(m, a, 0, static_cast<hipStream_t>(stream));
+    return launch_mlp_timed(m, a, 0, static_cast<hipStream_t>(stream));
 }
 
 int nm_mlp_grid_query(nm_mlp* m, const float* d_ax0, const float* d_ax1, const float* d_ax2, int32_t n0, int32_t n1,
@@ -219,7 +258,7 @@ int nm_mlp_grid_query(nm_mlp* m, const float* d_ax0, const float* d_ax1, const f
     a.a = d_ax0; a.b = d_ax1; a.c = d_ax2;
     a.n1 = n1; a.n2 = n2; a.first = first;
     a.n = count; a.out = d_out;
-    return launch_mlp(m, a, density_only ? 1 : 0, static_cast<hipStream_t>(stream));
+    return launch_mlp_timed(m, a, density_only ? 1 : 0, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -207,3 +207,14 @@ def render_rays(coarse, fine, origins, dirs, near, far, u_coarse, u_fine, lindis
                              rays, _ptr(ws), C.byref(cout), C.byref(fout) if fout is not None else None, _stream()),
           "nm_render_rays")
     return ct, ft
+
+
+def mlp_profile_enable(on=True):
+    check(_lib.load().nm_mlp_profile_enable(int(on)), "nm_mlp_profile_enable")
+
+
+def mlp_profile_read():
+    """(launches, total kernel ms, total algorithmic flops) of the fused-MLP launches since the last read."""
+    n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+    check(_lib.load().nm_mlp_profile_read(C.byref(n), C.byref(ms), C.byref(fl)), "nm_mlp_profile_read")
+    return n.value, ms.value, fl.value
