@@ -79,6 +79,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be the HIP runtime of the process (device pointers and
+    # streams cross the boundary), so make sure it is loaded before our library resolves its DT_NEEDED.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m nerfmeshes_amd.build` "

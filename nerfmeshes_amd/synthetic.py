@@ -89,15 +89,54 @@ def pseudo_targets(n, seed=42):
     return rng.random((n, 3), dtype=np.float32)
 
 
-# Density calibration found for make_mlp_weights(seed=2) on the 8x256 net: acc_map mean ~0.9
-# along lego-orbit rays with bounds [2, 6], and the sigma=32 iso-surface exists inside the
-# [-1.2, 1.2]^3 mesh-extraction cube (about 1 % of the volume is above it).
-SCENE_SEED, SCENE_GAIN, SCENE_BIAS = 2, 3000.0, 50.0
+# ---- scenes ----------------------------------------------------------------------------------------
+# 'rough' scene (W1 of SURVEY.md 8d): default-init weights with fc_alpha scaled so that acc_map ~ 0.9 along
+# lego-orbit rays.  Its density is thresholded high-frequency noise (the 2^9 positional-encoding octave
+# enters layer1 at full strength), which makes hierarchical resampling ill-conditioned: the unmodified
+# reference differs from ITSELF by up to 3e-2 in rgb when its hidden units are permuted (a mathematically
+# neutral change of summation order; tests/test_oracle_golden.py::test_reference_self_noise).
+ROUGH_SEED, ROUGH_GAIN, ROUGH_BIAS = 2, 3000.0, 50.0
+# 'smooth' scene: the same draw, but encoding octave f enters layer1 / the skip layer with weight 0.5**f
+# (band-limited like a trained NeRF), fc_alpha rescaled so the sigma = 32 iso-surface exists both along the
+# orbit rays (acc_map mean ~0.5, half the rays saturate) and inside the [-1.2, 1.2]^3 mesh cube.  The
+# reference's self-noise on it is < 1e-5, so end-to-end parity can be measured to the 1e-4 dB bar.
+SCENE_SEED, SCENE_DECAY, SCENE_GAIN, SCENE_BIAS = 2, 0.5, 1.0e5, 50.0
+_SCENE_RAW_MEAN, _SCENE_RAW_STD = -0.0233, 0.0054   # raw fc_alpha output statistics of the band-limited draw
+
+
+def make_rough_scene_weights(seed=ROUGH_SEED, **mlp_kwargs):
+    return make_mlp_weights(seed, density_gain=ROUGH_GAIN, density_bias=ROUGH_BIAS, **mlp_kwargs)
+
+
+def band_limit(weights, decay, num_encoding_fn_xyz=10, hidden_size=256, num_layers=8, skip_step=4, **_unused):
+    """Scale the sin/cos columns of octave f by decay**f wherever the xyz encoding enters the trunk."""
+    F = num_encoding_fn_xyz
+    scale = np.ones(3 + 6 * F, dtype=np.float32)
+    for c in range(3):
+        for f in range(F):
+            scale[3 + c * F + f] = scale[3 + 3 * F + c * F + f] = np.float32(decay ** f)
+    out = {k: v.copy() for k, v in weights.items()}
+    out["layer1.weight"] = out["layer1.weight"] * scale
+    for i in range(num_layers - 1):
+        if i % skip_step == 0 and i > 0 and i != num_layers - 1:
+            out[f"layers_xyz.{i}.weight"][:, hidden_size:] *= scale
+    return out
 
 
 def make_scene_weights(seed=SCENE_SEED, **mlp_kwargs):
-    """'W1' of SURVEY.md section 8d: seeded weights with a non-degenerate density field."""
-    return make_mlp_weights(seed, density_gain=SCENE_GAIN, density_bias=SCENE_BIAS, **mlp_kwargs)
+    """Seeded weights with a smooth, non-degenerate density field (the benchmark / parity scene).
+    Calibrated for the 8x256, F=10/4 network only (the constants are hard-coded, not re-derived, so
+    that every host regenerates bit-identical weights)."""
+    shapes = mlp_layer_shapes(**mlp_kwargs)
+    if shapes != mlp_layer_shapes():
+        raise ValueError("make_scene_weights is calibrated for the default 8x256 network; use "
+                         "make_mlp_weights(seed, density_gain=..., density_bias=...) for other sizes")
+    w = band_limit(make_mlp_weights(seed, **mlp_kwargs), SCENE_DECAY, **mlp_kwargs)
+    g = np.float32(SCENE_GAIN)
+    w["fc_alpha.weight"] = w["fc_alpha.weight"] * g
+    w["fc_alpha.bias"] = ((w["fc_alpha.bias"] - np.float32(_SCENE_RAW_MEAN + _SCENE_RAW_STD)) * g
+                          + np.float32(SCENE_BIAS)).astype(np.float32)
+    return w
 
 
 def hparams(model="NeRFModel", hidden_size=256, num_layers=8, skip_step=4, num_encoding_fn_xyz=10,

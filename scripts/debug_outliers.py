@@ -1,0 +1,39 @@
+"""Find the rays where HIP and oracle renders differ most and explain why (debug aid, GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from nerfmeshes_amd import hip_ops as ops, synthetic as S
+from oracle import nerf_oracle as O
+torch.set_num_threads(32)
+kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+w = S.make_scene_weights(**kw)
+m = ops.HipMLP(w, kw, "cuda")
+o, d = ops.ray_bundle(S.orbit_poses(4)[0], 800, 800, S.LEGO_FOCAL_800)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
+idx = torch.arange(0, 640000, 19, device="cuda")[:n]
+d = d[idx].contiguous(); o = o[None]
+spec, rs = O.MLPSpec(**kw), O.RenderSpec()
+c, f = O.render(w, w, spec, spec, rs, o.cpu(), d.cpu(), 2.0, 6.0)
+uc, uf = torch.linspace(0, 1, 64).cuda(), torch.linspace(0, 1, 128).cuda()
+tc = ops.coarse_intervals(uc, torch.tensor([2.0]).cuda(), torch.tensor([6.0]).cuda(), n)
+radc = m.eval_rays(o, d, tc); cc = ops.composite(radc, tc, d)
+tf = ops.sample_pdf(tc, cc["weights"], uf)
+radf = m.eval_rays(o, d, tf); ff = ops.composite(radf, tf, d)
+err = (ff["rgb_map"].cpu() - f["rgb_map"]).abs().max(-1).values
+print("rgb err: mean %.2e median %.2e  >1e-4: %d  >1e-3: %d  >1e-2: %d of %d" % (err.mean(), err.median(), (err > 1e-4).sum(), (err > 1e-3).sum(), (err > 1e-2).sum(), n))
+print("coarse weights max err %.2e ; coarse sigma max err %.2e" % ((cc["weights"].cpu() - c["weights"]).abs().max(), (radc.cpu()[..., 3] - c["radiance"][..., 3]).abs().max()))
+for r in torch.argsort(err, descending=True)[:4].tolist():
+    dt = (tf[r].cpu() - f["t"][r]).abs()
+    pos = torch.nonzero(dt > 1e-6).flatten().tolist()
+    print(f"ray {r}: rgb err {err[r]:.3e} acc ref {f['acc_map'][r]:.6f} ours {ff['acc_map'][r]:.6f}; t differs at {pos[:10]} (max {dt.max():.3e})")
+    for p in pos[:4]:
+        print(f"    pos {p}: t ref {f['t'][r, p]:.6f} ours {tf[r, p]:.6f} | w ref {f['weights'][r, p]:.4e} ours {ff['weights'][r, p]:.4e} | sigma ref {f['radiance'][r, p, 3]:.3f} ours {radf[r, p, 3]:.3f}")
+    # where is the mass?
+    wr = f["weights"][r]; top = torch.argsort(wr, descending=True)[:3].tolist()
+    print("    ref top weights at", top, [float(wr[i]) for i in top], "ours there", [float(ff['weights'][r, i]) for i in top])
+    # re-run our fine stage on the ORACLE's t to see whether the MLP/composite agree given identical samples
+    radf2 = m.eval_rays(o, d[r:r + 1], f["t"][r:r + 1].cuda().contiguous()); f2 = ops.composite(radf2, f["t"][r:r + 1].cuda().contiguous(), d[r:r + 1])
+    print("    ours on oracle's t: rgb err %.3e ; sigma max err %.3e" % ((f2["rgb_map"].cpu() - f["rgb_map"][r]).abs().max(), (radf2.cpu()[0, :, 3] - f["radiance"][r, :, 3]).abs().max()))
+    # cdf tail of the coarse pdf
+    wc = c["weights"][r, 1:-1] + 1e-5; pdf = wc / wc.sum(); cdf = torch.cumsum(pdf, -1)
+    print("    coarse pdf min %.3e ; #bins with pdf<1.1e-5: %d ; cdf[-3:] %s" % (pdf.min(), (pdf < 1.1e-5).sum(), cdf[-3:].tolist()))

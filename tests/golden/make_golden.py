@@ -56,14 +56,21 @@ def bundle_to_np(prefix, b, out):
         out[prefix + k] = getattr(b, k).numpy()
 
 
+def gen_weights(seed, gain, bias, **kw):
+    """gain == 0 selects the calibrated smooth scene (synthetic.make_scene_weights)."""
+    if gain == 0:
+        return S.make_scene_weights(seed, **kw)
+    return S.make_mlp_weights(seed, density_gain=gain, density_bias=bias, **kw)
+
+
 def case_render(name, hp, seed_c, seed_f, gain, bias, n_rays, near, far, per_ray_origins=False, train_mode=False):
     nerf, models = ref_import.load()
     m = models.NeRFModel(hp)
     m.eval()
-    wc = S.make_mlp_weights(seed_c, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "coarse"))
+    wc = gen_weights(seed_c, gain, bias, **mlp_kwargs(hp, "coarse"))
     load_weights(m, "model_coarse.", wc)
     if hp["models.use_fine"]:
-        wf = S.make_mlp_weights(seed_f, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+        wf = gen_weights(seed_f, gain, bias, **mlp_kwargs(hp, "fine"))
         load_weights(m, "model_fine.", wf)
     o, d, idx = lego_rays(n_rays)
     if per_ray_origins:
@@ -87,7 +94,7 @@ def case_mlp(name, hp, seed, gain, bias, n):
     """R3/R7: sample_points(points, dirs) on scattered points, incl. large coordinates."""
     nerf, models = ref_import.load()
     m = models.NeRFModel(hp).eval()
-    w = S.make_mlp_weights(seed, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+    w = gen_weights(seed, gain, bias, **mlp_kwargs(hp, "fine"))
     load_weights(m, "model_fine.", w)
     g = torch.Generator().manual_seed(11)
     pts = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([6.0, 1.2, 3.0])
@@ -107,7 +114,7 @@ def case_grid(name, hp, seed, gain, bias, res, limit):
     import mesh_nerf
     sys.path.remove(ref_import.REF_SRC)
     m = models.NeRFModel(hp).eval()
-    w = S.make_mlp_weights(seed, density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+    w = gen_weights(seed, gain, bias, **mlp_kwargs(hp, "fine"))
     load_weights(m, "model_fine.", w)
     args = type("A", (), dict(limit=limit, batch_size=1024, iso_level=32.0, res=res))()
     import io, contextlib
@@ -156,7 +163,8 @@ def case_eval_loss(name):
 
 def main():
     lego = S.hparams()
-    case_render("render_lego_scene", lego, S.SCENE_SEED, S.SCENE_SEED, S.SCENE_GAIN, S.SCENE_BIAS, 96, 2.0, 6.0)
+    case_render("render_lego_scene", lego, S.SCENE_SEED, S.SCENE_SEED, 0, 0, 256, 2.0, 6.0)
+    case_render("render_lego_rough", lego, S.ROUGH_SEED, S.ROUGH_SEED, S.ROUGH_GAIN, S.ROUGH_BIAS, 96, 2.0, 6.0)
     case_render("render_lego_default_init", lego, 1, 2, 1.0, 0.0, 32, 2.0, 6.0)
     case_render("render_lego_perray_white_lindisp",
                 S.hparams(white_background=True, lindisp=True), 3, 4, 2500.0, 40.0, 48, 2.0, 6.0,
@@ -165,8 +173,8 @@ def main():
                                          num_fine=0, use_fine=False), 5, 5, 100.0, 0.0, 128, 2.0, 6.0)
     case_render("render_fern_8x128", S.hparams(hidden_size=128, num_coarse=64, num_fine=64, near=0.0, far=1.2),
                 6, 7, 3000.0, 100.0, 64, 0.0, 1.2)
-    case_mlp("mlp_8x256_points", lego, S.SCENE_SEED, S.SCENE_GAIN, S.SCENE_BIAS, 512)
-    case_grid("grid_8x256_res20", lego, S.SCENE_SEED, S.SCENE_GAIN, S.SCENE_BIAS, 20, 1.2)
+    case_mlp("mlp_8x256_points", lego, S.ROUGH_SEED, S.ROUGH_GAIN, S.ROUGH_BIAS, 512)
+    case_grid("grid_8x256_res20", lego, S.SCENE_SEED, 0, 0, 20, 1.2)
     case_rays("rays")
     case_eval_loss("eval_loss")
 

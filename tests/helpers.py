@@ -32,14 +32,20 @@ def specs_from_hparams(hp):
     return sc, sf, rs
 
 
+def gen_weights(seed, gain, bias, **kw):
+    """Mirror of tests/golden/make_golden.py::gen_weights (gain == 0 -> calibrated smooth scene)."""
+    if float(gain) == 0:
+        return S.make_scene_weights(int(seed), **kw)
+    return S.make_mlp_weights(int(seed), density_gain=float(gain), density_bias=float(bias), **kw)
+
+
 def golden_weights(g, hp):
-    gain, bias = float(g["gain"]), float(g["bias"])
-    wc = S.make_mlp_weights(int(g["seed_coarse"]), density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "coarse"))
+    wc = gen_weights(g["seed_coarse"], g["gain"], g["bias"], **mlp_kwargs(hp, "coarse"))
     wf = None
     if hp["models.use_fine"]:
-        wf = S.make_mlp_weights(int(g["seed_fine"]), density_gain=gain, density_bias=bias, **mlp_kwargs(hp, "fine"))
+        wf = gen_weights(g["seed_fine"], g["gain"], g["bias"], **mlp_kwargs(hp, "fine"))
     return wc, wf
 
 
-RENDER_CASES = ("render_lego_scene", "render_lego_default_init", "render_lego_perray_white_lindisp",
+RENDER_CASES = ("render_lego_scene", "render_lego_rough", "render_lego_default_init", "render_lego_perray_white_lindisp",
                 "render_tiny", "render_fern_8x128")

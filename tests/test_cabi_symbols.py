@@ -25,11 +25,13 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_no_cpu_fallback_in_product():
-    """The product package must not import the oracle."""
+    """The product package must not import / execute anything under oracle/."""
     pkg = os.path.join(ROOT, "nerfmeshes_amd")
+    bad = re.compile(r"^\s*(from\s+\.*oracle\b|import\s+oracle\b)|import_module\([\"']oracle|oracle/_ref|oracle\.", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), \
-                    f"{f} references the oracle"
+                code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+                code = re.sub(r'"""[\s\S]*?"""', "", code)
+                assert not bad.search(code), f"{f} references the oracle"
