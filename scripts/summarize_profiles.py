@@ -1,0 +1,96 @@
+"""Turn the rocprofv3 outputs merged back under gpurun_out/ into the small, committed summaries under
+profiles/ (kernel-trace stats + PMC counters of the dominant kernel).
+
+    python scripts/summarize_profiles.py r01
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+GO = os.path.join(ROOT, "gpurun_out")
+PR = os.path.join(ROOT, "profiles")
+KERNEL = "mlp_kernel"
+
+
+def mean(v):
+    return sum(v) / len(v) if v else 0.0
+
+
+summary = {"tag": tag, "kernel": "nm::mlp_kernel<256,10,4,8>", "notes": []}
+
+# ---- kernel-trace --stats
+stats = os.path.join(GO, f"prof_{tag}", "bench_kernel_stats.csv")
+if os.path.exists(stats):
+    shutil.copy(stats, os.path.join(PR, f"{tag}_bench_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats)))
+    summary["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")}
+                               for r in rows[:8]]
+trace = os.path.join(GO, f"prof_{tag}", "bench_kernel_trace.csv")
+if os.path.exists(trace):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if KERNEL in r["Kernel_Name"]:
+            per[int(r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    summary["mlp_launches_by_grid"] = {str(g): {"launches": len(v), "avg_ms": mean(v), "min_ms": min(v), "max_ms": max(v)}
+                                       for g, v in per.items()}
+    full = [x for g, v in per.items() if g == 524288 for x in v]
+    summary["mlp_avg_ms_full_size_launches"] = mean(full)
+log = os.path.join(GO, f"bench_{tag}_profiled.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith('{"metric"'):
+            summary["bench_line_under_profiler"] = json.loads(line)
+
+# ---- PMC passes
+pmc_dir = os.path.join(GO, f"pmc_{tag}")
+counters = collections.defaultdict(list)
+if os.path.isdir(pmc_dir):
+    for d in sorted(os.listdir(pmc_dir)):
+        f = os.path.join(pmc_dir, d, "pmc_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        keep = []
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"] and int(r["Grid_Size"]) == 524288:
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                keep.append(r)
+        with open(os.path.join(PR, f"{tag}_raw", f"pmc_{d}.csv"), "w", newline="") as out:
+            wr = csv.DictWriter(out, fieldnames=["Dispatch_Id", "Kernel_Name", "Grid_Size", "VGPR_Count", "SGPR_Count",
+                                                 "LDS_Block_Size", "Scratch_Size", "Counter_Name", "Counter_Value",
+                                                 "Start_Timestamp", "End_Timestamp"], extrasaction="ignore")
+            wr.writeheader()
+            wr.writerows(keep)
+if counters:
+    c = {k: mean(v) for k, v in counters.items()}
+    n = {k: len(v) for k, v in counters.items()}
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced
+    # read stream (MI355X_MICROARCH.md, HBM) -> doubled.  WRITE_SIZE is taken as reported (it matches the
+    # algorithmic 16 B/sample output of the kernel to 6 %).
+    fetch_b = c.get("FETCH_SIZE", 0.0) * 1024 * 2
+    write_b = c.get("WRITE_SIZE", 0.0) * 1024
+    xcds, simds = 8, 1024
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0) / xcds          # the counter is summed over the 8 XCDs
+    summary["pmc"] = {
+        "launches_averaged": n, "mean": c,
+        "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
+        "hbm_bytes_per_launch": fetch_b + write_b,
+        "mfma_util": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (simds * gui) if gui else None,
+        "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"),
+        "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0),
+        "issue_stall_frac_of_wave_cycles": c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+        "wait_frac_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+    }
+    summary["notes"].append("PMC means are over the 18 full-size launches (9 coarse R x 64 + 9 fine R x 192 samples, "
+                            "R = 65536 rays) of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`, one counter group "
+                            "per rocprofv3 run (kernel-trace only, no other trace domains).")
+    json.dump({"hbm_bytes_per_launch": fetch_b + write_b, "hbm_read_bytes_per_launch": fetch_b,
+               "hbm_write_bytes_per_launch": write_b, "mfma_util": summary["pmc"]["mfma_util"],
+               "source": f"profiles/{tag}_summary.json"},
+              open(os.path.join(PR, f"{tag}_pmc_mlp_kernel.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(PR, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps({k: summary[k] for k in summary if k not in ("kernel_stats", "bench_line_under_profiler")}, indent=1)[:3000])
