@@ -1,0 +1,8 @@
+"""`nerf` package of the reference (/root/reference/src/nerf/__init__.py), same public names."""
+from .cfgnode import CfgNode
+from .tree import Node, TreeSampling
+from .nerf_helpers import (batchify, cast_to_disparity_image, cast_to_image, cast_to_pil_image, cumprod_exclusive,
+                           export_obj, get_ray_bundle, img2mse, meshgrid_xy, mse2psnr, ndc_rays)
+from .modules import OutputBundle, PositionalEncoding, RaySampleInterval, SamplePDF, VolumeRenderer
+from .models import FlexibleNeRFModel
+from . import models, modules, nerf_helpers, tree

@@ -1,0 +1,58 @@
+"""FlexibleNeRFModel with the reference's constructor, parameter names and forward signature
+(/root/reference/src/nerf/models.py:4-80); forward runs the fused gfx950 MLP kernel."""
+import torch
+
+from .. import hip_ops
+from .modules import PositionalEncoding
+
+
+class FlexibleNeRFModel(torch.nn.Module):
+    def __init__(self, num_layers=4, hidden_size=128, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4,
+                 include_input_xyz=True, include_input_dir=True, log_sampling_xyz=True, log_sampling_dir=True,
+                 use_viewdirs=True, **kwargs):
+        super().__init__()
+        self.encode_xyz = PositionalEncoding(num_encoding_fn_xyz, include_input_xyz, log_sampling_xyz)
+        self.encode_dir = PositionalEncoding(num_encoding_fn_dir, include_input_dir, log_sampling_dir)
+        self.dim_xyz = self.encode_xyz.output_size()
+        self.dim_dir = self.encode_dir.output_size() if use_viewdirs else 0
+        self.skip_step, self.num_layers, self.hidden_size, self.use_viewdirs = skip_step, num_layers, hidden_size, use_viewdirs
+        lin = torch.nn.Linear
+        self.layer1 = lin(self.dim_xyz, hidden_size)
+        self.layers_xyz = torch.nn.ModuleList(
+            lin(hidden_size + (self.dim_xyz if self._is_skip(i) else 0), hidden_size) for i in range(num_layers - 1))
+        if use_viewdirs:
+            self.layers_dir = torch.nn.ModuleList([lin(self.dim_dir + hidden_size, hidden_size // 2)])
+            self.fc_alpha = lin(hidden_size, 1)
+            self.fc_rgb = lin(hidden_size // 2, 3)
+            self.fc_feat = lin(hidden_size, hidden_size)
+        else:
+            self.fc_out = lin(hidden_size, 4)
+        self._desc = dict(num_layers=num_layers, hidden_size=hidden_size, skip_step=skip_step,
+                          num_encoding_fn_xyz=num_encoding_fn_xyz, num_encoding_fn_dir=num_encoding_fn_dir,
+                          include_input_xyz=include_input_xyz, include_input_dir=include_input_dir,
+                          log_sampling_xyz=log_sampling_xyz, log_sampling_dir=log_sampling_dir,
+                          use_viewdirs=use_viewdirs)
+        self._hip = None
+        self._hip_key = None
+
+    def _is_skip(self, i):
+        return i % self.skip_step == 0 and i > 0 and i != self.num_layers - 1
+
+    def hip(self):
+        """Packed device copy of the current parameters (rebuilt when they change or move)."""
+        params = list(self.parameters()) + list(self.buffers())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise hip_ops._lib.HipLibraryError(
+                "FlexibleNeRFModel lives on %s: move it to the MI355X (.to('cuda')); there is no CPU path" % dev)
+        key = (dev, tuple((p.data_ptr(), p._version) for p in params))
+        if self._hip is None or key != self._hip_key:
+            self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev)
+            self._hip_key = key
+        return self._hip
+
+    def forward(self, ray_points, ray_directions=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("the HIP path implements inference; call under torch.no_grad() / .eval() "
+                                      "(training backward is a later scope row)")
+        return self.hip().sample_points(ray_points, ray_directions if ray_directions is not None else ray_points)

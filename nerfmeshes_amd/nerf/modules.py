@@ -1,0 +1,89 @@
+"""Render primitives with the reference's class names and signatures
+(/root/reference/src/nerf/modules.py:8-248), dispatching to the gfx950 kernels through the C ABI.
+
+Every forward requires GPU tensors and `torch.no_grad()`-style use: there is no CPU or eager fallback
+(training-time noise / stratified jitter / random u are reference rows (f)-2 and raise)."""
+from dataclasses import dataclass
+
+import torch
+
+from .. import hip_ops
+
+
+@dataclass
+class OutputBundle:
+    rgb_map: torch.Tensor = None
+    depth_map: torch.Tensor = None
+    weights: torch.Tensor = None
+    mask_weights: torch.Tensor = None
+    acc_map: torch.Tensor = None
+    disp_map: torch.Tensor = None
+
+
+class PositionalEncoding(torch.nn.Module):
+    """Holds `frequency_bands` (state_dict compatibility, modules.py:16-24).  The encoding itself is
+    computed inside the fused MLP kernel and never materialised; calling this module on its own is not
+    part of the accelerated path."""
+
+    def __init__(self, num_encoding_functions=6, include_input=True, log_sampling=True):
+        super().__init__()
+        self.num_encoding_functions = num_encoding_functions
+        self.include_input = include_input
+        n = num_encoding_functions
+        bands = 2.0 ** torch.linspace(0.0, n - 1, n) if log_sampling else torch.linspace(1.0, 2.0 ** (n - 1), n)
+        self.register_buffer("frequency_bands", bands)
+
+    def output_size(self):
+        return 6 * self.num_encoding_functions + (3 if self.include_input else 0)
+
+    def forward(self, x):
+        raise NotImplementedError("PositionalEncoding is fused into the HIP MLP kernel (FlexibleNeRFModel.forward)")
+
+
+class VolumeRenderer(torch.nn.Module):
+    """modules.py:50-121 -> nm_composite."""
+
+    def __init__(self, train_radiance_field_noise_std=0.0, val_radiance_field_noise_std=0.0, white_background=False,
+                 attenuation_threshold=1e-3):
+        super().__init__()
+        self.train_radiance_field_noise_std = train_radiance_field_noise_std
+        self.val_radiance_field_noise_std = val_radiance_field_noise_std
+        self.attenuation_threshold = attenuation_threshold
+        self.white_background = white_background
+        self.register_buffer("one_e_10", torch.tensor([1e10]))
+
+    def forward(self, radiance_field, depth_values, ray_directions):
+        noise = self.train_radiance_field_noise_std if self.training else self.val_radiance_field_noise_std
+        if noise > 0.0:
+            raise NotImplementedError("radiance-field noise (training) is not implemented on the HIP path")
+        out = hip_ops.composite(radiance_field, depth_values, ray_directions, self.attenuation_threshold,
+                                self.white_background, self.training)
+        return OutputBundle(**out)
+
+
+class RaySampleInterval(torch.nn.Module):
+    """modules.py:148-186 -> nm_coarse_intervals."""
+
+    def __init__(self, count):
+        super().__init__()
+        self.count = count
+        self.register_buffer("point_intervals", torch.linspace(0.0, 1.0, count)[None, :], persistent=False)
+
+    def forward(self, cfg, ray_count, near, far):
+        if cfg.perturb:
+            raise NotImplementedError("stratified jitter (perturb) is not implemented on the HIP path")
+        return hip_ops.coarse_intervals(self.point_intervals.reshape(-1), near, far, ray_count, bool(cfg.lindisp))
+
+
+class SamplePDF(torch.nn.Module):
+    """modules.py:189-248 -> nm_sample_pdf."""
+
+    def __init__(self, num_samples):
+        super().__init__()
+        self.num_samples = num_samples
+        self.register_buffer("u", torch.linspace(0.0, 1.0, steps=num_samples))
+
+    def forward(self, point_interval, weights, perturb):
+        if perturb != 0.0:
+            raise NotImplementedError("random u (perturb) is not implemented on the HIP path")
+        return hip_ops.sample_pdf(point_interval, weights, self.u)

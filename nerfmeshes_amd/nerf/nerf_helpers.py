@@ -1,0 +1,113 @@
+"""Helper functions the three scripts import by name (mirror of /root/reference/src/nerf/nerf_helpers.py)."""
+import math
+
+import numpy as np
+import torch
+
+from .. import hip_ops
+
+
+def img2mse(img_src, img_tgt):
+    return torch.nn.functional.mse_loss(img_src, img_tgt)
+
+
+def mse2psnr(mse):
+    """nerf_helpers.py:17-23: PSNR = -10 log10(mse), MAX = 1."""
+    mse = torch.as_tensor(mse)
+    if mse == 0:
+        mse = torch.full_like(mse, 1e-5, dtype=torch.float32)
+    return -10.0 * torch.log10(mse)
+
+
+def batchify(*data, batch_size=1024, device="cpu", progress=True):
+    """nerf_helpers.py:114-139: yield aligned slices of every tensor, moved to `device`."""
+    size = data[0].shape[0]
+    assert all(s is None or s.shape[0] == size for s in data), "Sizes of tensors must match for dimension 0."
+
+    def gen():
+        for start in range(0, size, batch_size):
+            yield [s[start:start + batch_size].to(device) if s is not None else s for s in data]
+
+    if not progress:
+        return gen()
+    try:
+        from tqdm import tqdm
+        return tqdm(gen(), total=(size - 1) // batch_size + 1)
+    except ImportError:
+        return gen()
+
+
+def meshgrid_xy(tensor1, tensor2):
+    ii, jj = torch.meshgrid(tensor1, tensor2, indexing="ij")
+    return ii.transpose(-1, -2), jj.transpose(-1, -2)
+
+
+def cumprod_exclusive(tensor):
+    """nerf_helpers.py:199-223 (kept for API compatibility; the render path does the scan in-kernel)."""
+    c = torch.roll(torch.cumprod(tensor, -1), 1, -1)
+    c[..., 0] = 1.0
+    return c
+
+
+def get_ray_bundle(height, width, focal_length, tform_cam2world):
+    """nerf_helpers.py:226-277 on the GPU: (origin (3,), directions (H, W, 3))."""
+    dev = tform_cam2world.device if isinstance(tform_cam2world, torch.Tensor) and tform_cam2world.is_cuda else "cuda"
+    origin, dirs = hip_ops.ray_bundle(tform_cam2world, int(height), int(width), float(focal_length), device=dev)
+    return origin, dirs.reshape(int(height), int(width), 3)
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """nerf_helpers.py:280-307 (elementwise torch ops on whatever device the rays live on; per-image
+    preprocessing, not part of the per-chunk hot loop)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    sx, sy = -1.0 / (W / (2.0 * focal)), -1.0 / (H / (2.0 * focal))
+    o = torch.stack([sx * rays_o[..., 0] / rays_o[..., 2], sy * rays_o[..., 1] / rays_o[..., 2],
+                     1.0 + 2.0 * near / rays_o[..., 2]], -1)
+    d = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2]),
+                     sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2]),
+                     -2.0 * near / rays_o[..., 2]], -1)
+    return o, d
+
+
+def cast_to_image(tensor):
+    """(H, W, 3) float -> (3, H, W) uint8 numpy (nerf_helpers.py:155-181 family)."""
+    img = np.array((tensor.detach().cpu().clamp(0.0, 1.0) * 255).to(torch.uint8))
+    return np.moveaxis(img, [-1], [0])
+
+
+def cast_to_pil_image(tensor):
+    return (tensor.detach().cpu().clamp(0.0, 1.0) * 255).to(torch.uint8).numpy()
+
+
+def cast_to_disparity_image(tensor, white_background=False):
+    """(H, W) -> uint8 image, min-max normalised; exact zeros become white if requested."""
+    img = (tensor - tensor.min()) / (tensor.max() - tensor.min())
+    img = (img.clamp(0.0, 1.0) * 255).byte()
+    if white_background:
+        img[img == 0] = 255
+    return img.detach().cpu().numpy()
+
+
+def export_obj(vertices, triangles, diffuse, normals, filename):
+    """nerf_helpers.py:86-111 text format: `v x y z [r g b]`, `vn x y z`, `f a//a b//b c//c` (1-based).
+    Numbers are written exactly as the reference's `"{}".format(tensor_element)` does: the shortest
+    repr of the fp32 value widened to a Python float."""
+    def rows(x):
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        return np.asarray(x)
+
+    v, c, n, t = rows(vertices), rows(diffuse), rows(normals), rows(triangles)
+    print("Writing to obj...")
+    with open(filename, "w") as fh:
+        out = []
+        for i in range(len(v)):
+            line = "v {} {} {}".format(*(float(a) for a in v[i]))
+            if len(c) > i:
+                line += " {} {} {}".format(*(float(a) for a in c[i]))
+            out.append(line)
+        out.extend("vn {} {} {}".format(*(float(a) for a in row)) for row in n)
+        out.extend("f" + "".join(" {}//{}".format(int(a) + 1, int(a) + 1) for a in row) for row in t)
+        fh.write("\n".join(out) + ("\n" if out else ""))
+    print(f"Finished writing to {filename} with {len(v)} vertices")
