@@ -148,6 +148,27 @@ int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
                    void* d_workspace, const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Marching cubes: skimage.measure.marching_cubes(volume, level) as called at src/mesh_nerf.py:79
+ * (third-party scikit-image 0.17.2, Lewiner MC33, defaults: step_size=1, gradient_direction='descent',
+ * allow_degenerate=True, no mask).  Output-identical: vertices (V,3) fp32 in (axis0,axis1,axis2) order,
+ * faces (F,3) int32 (same vertex numbering and triangle order), normals (V,3), values (V,).
+ * Two-phase because V and F are data dependent:
+ *   nm_mc_count  classifies every cube and returns V and F (synchronises the stream);
+ *   nm_mc_emit   writes the four arrays (caller-allocated from those counts).
+ * d_workspace (nm_mc_workspace_bytes) must be kept between the two calls; d_vertex_scratch
+ * (nm_mc_vertex_scratch_bytes(V)) is only used by nm_mc_emit.  V == 0 is skimage's
+ * RuntimeError('No surface found at the given iso value.'); the level-in-range ValueError is the
+ * host wrapper's check, as in skimage's Python wrapper.
+ * ------------------------------------------------------------------------------------------ */
+int64_t nm_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2);
+int64_t nm_mc_vertex_scratch_bytes(int64_t vertices);
+int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
+                int64_t* h_vertices, int64_t* h_faces, void* stream);
+int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
+               void* d_vertex_scratch, int64_t vertices, int64_t faces, float* d_verts, int32_t* d_faces,
+               float* d_normals, float* d_values, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,655 @@
+// Lewiner MC33 marching cubes for gfx950, output-identical to skimage.measure.marching_cubes(volume, level)
+// (the call at /root/reference/src/mesh_nerf.py:79: method='lewiner', step_size=1, 'descent', no mask):
+// same vertices (bit for bit), same vertex NUMBERING, same triangle order, same normals and values.
+//
+// The CPU algorithm is a sequential scan (axis0 outermost, axis2 innermost) with a per-layer vertex
+// cache; vertex ids are "order of first creation", triangle order is "cube scan order, tiling order".
+// Parallel restatement used here:
+//   1. classify   one thread per cube: corner signs -> case/config -> (face / interior tests) -> tiling row
+//                 (offset into the LUT, triangle count) and the number of vertices this cube CREATES.
+//                 An edge vertex is created by the first cube in scan order that contains the edge; every
+//                 tiling of a cube uses exactly its sign-changing edges, so ownership is a pure function of
+//                 the edge position ("no earlier cube contains it").
+//   2. scan       exclusive prefix sums of (created vertices, triangles) over cubes in scan order
+//                 (block sums -> single-block scan of the sums; the intra-block scan is redone in LDS by the
+//                 emit kernels, so no per-cube offsets are stored).
+//   3. vertices   each cube walks its tiling; every first use of an owned edge (or of the centre vertex,
+//                 edge id 12) creates vertex base+k: position (fp64 inverse-|v| interpolation rounded to
+//                 fp32, as skimage), its index goes into an edge->vertex table (one int32 volume per axis).
+//   4. faces      each cube walks its tiling again and looks the indices up; triples are reversed ('descent').
+//   5. normals    one thread per vertex: re-plays, in scan order, the <= 4 cubes sharing its edge and
+//                 accumulates their gradient contributions in fp32 in exactly skimage's order, takes the
+//                 max of the cubes' value ranges, normalises in fp64.
+// HBM-bound integer/byte work: 4 B/voxel streamed once for classification is the algorithmic traffic
+// (442 MB at 480^3); the other passes touch only the ~1 % of cubes that are active.
+#include "nm_internal.h"
+#include "mc_luts.h"
+
+namespace nm {
+
+constexpr double SK_EPS = 2.220446049250313e-16;   // skimage's "FLT_EPSILON" is np.spacing(1.0)
+constexpr int MC_BLOCK = 256;
+constexpr int MC_ITEMS = 4;                          // cubes per thread in scan-partitioned kernels
+constexpr int MC_TILE = MC_BLOCK * MC_ITEMS;
+
+struct McDims {
+    int n0, n1, n2;          // volume extents (axis0 = skimage z, axis2 = skimage x)
+    int c0, c1, c2;          // cube extents (n-1)
+    int64_t cubes;
+};
+
+__device__ __forceinline__ int lut(int i) { return MC_LUT[i]; }
+
+struct Cube {
+    double v[8];             // corner value - iso, Lewiner corner numbering
+};
+
+__device__ __forceinline__ void load_cube(const float* __restrict__ vol, const McDims& d, int z, int y, int x,
+                                          double iso, Cube& c) {
+    const int64_t s1 = d.n2, s0 = (int64_t)d.n1 * d.n2;
+    const float* p = vol + (int64_t)z * s0 + (int64_t)y * s1 + x;
+    c.v[0] = (double)p[0] - iso;           c.v[1] = (double)p[1] - iso;
+    c.v[2] = (double)p[s1 + 1] - iso;      c.v[3] = (double)p[s1] - iso;
+    c.v[4] = (double)p[s0] - iso;          c.v[5] = (double)p[s0 + 1] - iso;
+    c.v[6] = (double)p[s0 + s1 + 1] - iso; c.v[7] = (double)p[s0 + s1] - iso;
+}
+
+__device__ __forceinline__ bool test_face(const Cube& c, int face) {
+    const double* v = c.v;
+    double A, B, C, D;
+    switch (face < 0 ? -face : face) {
+        case 1: A = v[0]; B = v[4]; C = v[5]; D = v[1]; break;
+        case 2: A = v[1]; B = v[5]; C = v[6]; D = v[2]; break;
+        case 3: A = v[2]; B = v[6]; C = v[7]; D = v[3]; break;
+        case 4: A = v[3]; B = v[7]; C = v[4]; D = v[0]; break;
+        case 5: A = v[0]; B = v[3]; C = v[2]; D = v[1]; break;
+        default: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
+    }
+    const double acbd = A * C - B * D;
+    if (acbd > -SK_EPS && acbd < SK_EPS) return face >= 0;
+    return face * A * acbd >= 0;
+}
+
+// reference edge (p,q) and the three parallel edges (B, C, D) used by the interior test
+__device__ __constant__ signed char MC_INTERIOR_EDGES[12][8] = {
+    {0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7}, {3, 0, 2, 1, 6, 5, 7, 4},
+    {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2}, {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0},
+    {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
+
+__device__ bool test_interior(const Cube& c, int kase, int cfg, int subcfg, int s) {
+    const double* v = c.v;
+    double t, At = 0, Bt, Ct, Dt;
+    if (kase == 4 || kase == 10) {
+        const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+        const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+        t = -b / (2 * a + SK_EPS);
+        if (t < 0 || t > 1) return s > 0;
+        At = v[0] + (v[4] - v[0]) * t;
+        Bt = v[3] + (v[7] - v[3]) * t;
+        Ct = v[2] + (v[6] - v[2]) * t;
+        Dt = v[1] + (v[5] - v[1]) * t;
+    } else {
+        int edge;
+        if (kase == 6) edge = lut(MC_TEST6_OFF + cfg * MC_TEST6_ROW + 2);
+        else if (kase == 7) edge = lut(MC_TEST7_OFF + cfg * MC_TEST7_ROW + 4);
+        else if (kase == 12) edge = lut(MC_TEST12_OFF + cfg * MC_TEST12_ROW + 3);
+        else edge = lut(MC_TILING13_5_1_OFF + (cfg * MC_TILING13_5_1_SUB + subcfg) * MC_TILING13_5_1_ROW);
+        const signed char* e = MC_INTERIOR_EDGES[edge];
+        t = v[e[0]] / (v[e[0]] - v[e[1]] + SK_EPS);
+        Bt = v[e[2]] + (v[e[3]] - v[e[2]]) * t;
+        Ct = v[e[4]] + (v[e[5]] - v[e[4]]) * t;
+        Dt = v[e[6]] + (v[e[7]] - v[e[6]]) * t;
+    }
+    const int test = (At >= 0 ? 1 : 0) + (Bt >= 0 ? 2 : 0) + (Ct >= 0 ? 4 : 0) + (Dt >= 0 ? 8 : 0);
+    switch (test) {
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 12: return s > 0;
+        case 5: return (At * Ct - Bt * Dt < SK_EPS) ? (s > 0) : false;     // skimage returns 0 when the
+        case 10: return (At * Ct - Bt * Dt >= SK_EPS) ? (s > 0) : false;   // saddle test fails (not s < 0)
+        default: return s < 0;
+    }
+}
+
+#define MC_ROW(NAME, cfg) (MC_##NAME##_OFF + (cfg) * MC_##NAME##_ROW)
+#define MC_ROW3(NAME, cfg, sub) (MC_##NAME##_OFF + ((cfg) * MC_##NAME##_SUB + (sub)) * MC_##NAME##_ROW)
+#define MC_T1(NAME, cfg) lut(MC_##NAME##_OFF + (cfg))
+#define MC_T2(NAME, cfg, k) lut(MC_##NAME##_OFF + (cfg) * MC_##NAME##_ROW + (k))
+
+// Lewiner's process_cube: -> tiling row offset in MC_LUT and triangle count (0 = empty cube)
+__device__ void select_tiling(const Cube& c, int index, int& offset, int& nt) {
+    const int kase = lut(MC_CASES_OFF + 2 * index), cfg = lut(MC_CASES_OFF + 2 * index + 1);
+    offset = 0; nt = 0;
+    int sub = 0;
+#define MC_PICK(off, n) do { offset = (off); nt = (n); } while (0)
+    switch (kase) {
+        case 1: MC_PICK(MC_ROW(TILING1, cfg), 1); break;
+        case 2: MC_PICK(MC_ROW(TILING2, cfg), 2); break;
+        case 3:
+            if (test_face(c, MC_T1(TEST3, cfg))) MC_PICK(MC_ROW(TILING3_2, cfg), 4);
+            else MC_PICK(MC_ROW(TILING3_1, cfg), 2);
+            break;
+        case 4:
+            if (test_interior(c, kase, cfg, 0, MC_T1(TEST4, cfg))) MC_PICK(MC_ROW(TILING4_1, cfg), 2);
+            else MC_PICK(MC_ROW(TILING4_2, cfg), 6);
+            break;
+        case 5: MC_PICK(MC_ROW(TILING5, cfg), 3); break;
+        case 6:
+            if (test_face(c, MC_T2(TEST6, cfg, 0))) MC_PICK(MC_ROW(TILING6_2, cfg), 5);
+            else if (test_interior(c, kase, cfg, 0, MC_T2(TEST6, cfg, 1))) MC_PICK(MC_ROW(TILING6_1_1, cfg), 3);
+            else MC_PICK(MC_ROW(TILING6_1_2, cfg), 9);
+            break;
+        case 7:
+            if (test_face(c, MC_T2(TEST7, cfg, 0))) sub += 1;
+            if (test_face(c, MC_T2(TEST7, cfg, 1))) sub += 2;
+            if (test_face(c, MC_T2(TEST7, cfg, 2))) sub += 4;
+            switch (sub) {
+                case 0: MC_PICK(MC_ROW(TILING7_1, cfg), 3); break;
+                case 1: MC_PICK(MC_ROW3(TILING7_2, cfg, 0), 5); break;
+                case 2: MC_PICK(MC_ROW3(TILING7_2, cfg, 1), 5); break;
+                case 3: MC_PICK(MC_ROW3(TILING7_3, cfg, 0), 9); break;
+                case 4: MC_PICK(MC_ROW3(TILING7_2, cfg, 2), 5); break;
+                case 5: MC_PICK(MC_ROW3(TILING7_3, cfg, 1), 9); break;
+                case 6: MC_PICK(MC_ROW3(TILING7_3, cfg, 2), 9); break;
+                default:
+                    if (test_interior(c, kase, cfg, 0, MC_T2(TEST7, cfg, 3))) MC_PICK(MC_ROW(TILING7_4_2, cfg), 9);
+                    else MC_PICK(MC_ROW(TILING7_4_1, cfg), 5);
+            }
+            break;
+        case 8: MC_PICK(MC_ROW(TILING8, cfg), 2); break;
+        case 9: MC_PICK(MC_ROW(TILING9, cfg), 4); break;
+        case 10:
+            if (test_face(c, MC_T2(TEST10, cfg, 0))) {
+                if (test_face(c, MC_T2(TEST10, cfg, 1))) MC_PICK(MC_ROW(TILING10_1_1_, cfg), 4);
+                else MC_PICK(MC_ROW(TILING10_2, cfg), 8);
+            } else {
+                if (test_face(c, MC_T2(TEST10, cfg, 1))) MC_PICK(MC_ROW(TILING10_2_, cfg), 8);
+                else if (test_interior(c, kase, cfg, 0, MC_T2(TEST10, cfg, 2))) MC_PICK(MC_ROW(TILING10_1_1, cfg), 4);
+                else MC_PICK(MC_ROW(TILING10_1_2, cfg), 8);
+            }
+            break;
+        case 11: MC_PICK(MC_ROW(TILING11, cfg), 4); break;
+        case 12:
+            if (test_face(c, MC_T2(TEST12, cfg, 0))) {
+                if (test_face(c, MC_T2(TEST12, cfg, 1))) MC_PICK(MC_ROW(TILING12_1_1_, cfg), 4);
+                else MC_PICK(MC_ROW(TILING12_2, cfg), 8);
+            } else {
+                if (test_face(c, MC_T2(TEST12, cfg, 1))) MC_PICK(MC_ROW(TILING12_2_, cfg), 8);
+                else if (test_interior(c, kase, cfg, 0, MC_T2(TEST12, cfg, 2))) MC_PICK(MC_ROW(TILING12_1_1, cfg), 4);
+                else MC_PICK(MC_ROW(TILING12_1_2, cfg), 8);
+            }
+            break;
+        case 13: {
+            for (int k = 0; k < 6; ++k)
+                if (test_face(c, MC_T2(TEST13, cfg, k))) sub += 1 << k;
+            const int sc = lut(MC_SUBCONFIG13_OFF + sub);
+            if (sc == 0) MC_PICK(MC_ROW(TILING13_1, cfg), 4);
+            else if (sc <= 6) MC_PICK(MC_ROW3(TILING13_2, cfg, sc - 1), 6);
+            else if (sc <= 18) MC_PICK(MC_ROW3(TILING13_3, cfg, sc - 7), 10);
+            else if (sc <= 22) MC_PICK(MC_ROW3(TILING13_4, cfg, sc - 19), 12);
+            else if (sc <= 26) {
+                if (test_interior(c, kase, cfg, sc - 23, MC_T2(TEST13, cfg, 6))) MC_PICK(MC_ROW3(TILING13_5_1, cfg, sc - 23), 6);
+                else MC_PICK(MC_ROW3(TILING13_5_2, cfg, sc - 23), 10);
+            } else if (sc <= 38) MC_PICK(MC_ROW3(TILING13_3_, cfg, sc - 27), 10);
+            else if (sc <= 44) MC_PICK(MC_ROW3(TILING13_2_, cfg, sc - 39), 6);
+            else if (sc == 45) MC_PICK(MC_ROW(TILING13_1_, cfg), 4);
+            break;
+        }
+        case 14: MC_PICK(MC_ROW(TILING14, cfg), 4); break;
+        default: break;
+    }
+#undef MC_PICK
+}
+
+// ---- edge bookkeeping ------------------------------------------------------------------------------
+// corner offsets (dz,dy,dx) of the two ends of edge e, Lewiner numbering
+__device__ __constant__ signed char MC_EDGE_A[12][3] = {{0,0,0},{0,0,1},{0,1,1},{0,1,0},{1,0,0},{1,0,1},{1,1,1},{1,1,0},{0,0,0},{0,0,1},{0,1,1},{0,1,0}};
+__device__ __constant__ signed char MC_EDGE_B[12][3] = {{0,0,1},{0,1,1},{0,1,0},{0,0,0},{1,0,1},{1,1,1},{1,1,0},{1,0,0},{1,0,0},{1,0,1},{1,1,1},{1,1,0}};
+// axis of the edge (0 = x / axis2, 1 = y / axis1, 2 = z / axis0) and its lower corner offset (dz,dy,dx)
+__device__ __constant__ signed char MC_EDGE_AXIS[12] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2};
+__device__ __constant__ signed char MC_EDGE_LO[12][3] = {{0,0,0},{0,0,1},{0,1,0},{0,0,0},{1,0,0},{1,0,1},{1,1,0},{1,0,0},{0,0,0},{0,0,1},{0,1,1},{0,1,0}};
+// Lewiner corner -> skimage's "bitwise" corner index dz*4+dy*2+dx used for vv[] / vg[]
+__device__ __forceinline__ int bitwise_index(const signed char* o) { return o[0] * 4 + o[1] * 2 + o[2]; }
+
+// this cube creates the vertex on edge e iff no cube earlier in scan order contains that edge
+__device__ __forceinline__ bool owns_edge(int e, int z, int y, int x) {
+    switch (e) {
+        case 0: return y == 0 && z == 0;
+        case 2: return z == 0;
+        case 4: return y == 0;
+        case 6: return true;
+        case 3: return x == 0 && z == 0;
+        case 1: return z == 0;
+        case 7: return x == 0;
+        case 5: return true;
+        case 8: return x == 0 && y == 0;
+        case 9: return y == 0;
+        case 11: return x == 0;
+        default: return true;   // 10, and the centre vertex (12)
+    }
+}
+
+__device__ __forceinline__ int count_created(int offset, int nt, int z, int y, int x) {
+    unsigned seen = 0;
+    int n = 0;
+    for (int i = 0; i < 3 * nt; ++i) {
+        const int e = lut(offset + i);
+        if (seen & (1u << e)) continue;
+        seen |= 1u << e;
+        n += owns_edge(e, z, y, x) ? 1 : 0;
+    }
+    return n;
+}
+
+// code word per cube: [14:0] tiling offset, [18:15] triangles, [22:19] created vertices
+__device__ __forceinline__ uint32_t pack_code(int offset, int nt, int ncreated) {
+    return (uint32_t)offset | ((uint32_t)nt << 15) | ((uint32_t)ncreated << 19);
+}
+__device__ __forceinline__ int code_offset(uint32_t c) { return c & 0x7fff; }
+__device__ __forceinline__ int code_nt(uint32_t c) { return (c >> 15) & 0xf; }
+__device__ __forceinline__ int code_created(uint32_t c) { return (c >> 19) & 0xf; }
+
+__device__ __forceinline__ void cube_coords(const McDims& d, int64_t id, int& z, int& y, int& x) {
+    const int64_t plane = (int64_t)d.c1 * d.c2;
+    z = (int)(id / plane);
+    const int64_t r = id - (int64_t)z * plane;
+    y = (int)(r / d.c2);
+    x = (int)(r - (int64_t)y * d.c2);
+}
+
+// ---- pass 1: classify ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(MC_BLOCK) void mc_classify(const float* __restrict__ vol, McDims d, double iso,
+                                                        uint32_t* __restrict__ codes, uint2* __restrict__ tile_sums) {
+    __shared__ uint32_t s_v[MC_BLOCK / 64], s_t[MC_BLOCK / 64];
+    uint32_t nv = 0, ntri = 0;
+    const int64_t base = (int64_t)blockIdx.x * MC_TILE;
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        const int64_t id = base + it * MC_BLOCK + threadIdx.x;   // coalesced along x within a tile
+        if (id >= d.cubes) continue;
+        int z, y, x;
+        cube_coords(d, id, z, y, x);
+        Cube c;
+        load_cube(vol, d, z, y, x, iso, c);
+        int index = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) index |= (c.v[k] > 0.0) ? (1 << k) : 0;
+        uint32_t code = 0;
+        if (index != 0 && index != 255) {
+            int off, nt;
+            select_tiling(c, index, off, nt);
+            const int created = count_created(off, nt, z, y, x);
+            code = pack_code(off, nt, created);
+            nv += created; ntri += nt;
+        }
+        codes[id] = code;
+    }
+    // block reduction of the two counters
+    for (int o = 32; o > 0; o >>= 1) { nv += __shfl_xor(nv, o); ntri += __shfl_xor(ntri, o); }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = nv; s_t[threadIdx.x >> 6] = ntri; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+        for (int w = 0; w < MC_BLOCK / 64; ++w) { a += s_v[w]; b += s_t[w]; }
+        tile_sums[blockIdx.x] = make_uint2(a, b);
+    }
+}
+
+// ---- pass 2: exclusive scan of the per-tile sums (single block; <= ~27k tiles at 480^3) -------------
+__global__ __launch_bounds__(1024) void mc_scan_tiles(uint2* __restrict__ tile_sums, int64_t tiles,
+                                                      uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    __shared__ uint32_t carry_a, carry_b;
+    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (int64_t start = 0; start < tiles; start += 1024) {
+        const int64_t i = start + threadIdx.x;
+        const uint2 v = i < tiles ? tile_sums[i] : make_uint2(0, 0);
+        s_a[threadIdx.x] = v.x; s_b[threadIdx.x] = v.y;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+            uint32_t a = 0, b = 0;
+            if ((int)threadIdx.x >= o) { a = s_a[threadIdx.x - o]; b = s_b[threadIdx.x - o]; }
+            __syncthreads();
+            s_a[threadIdx.x] += a; s_b[threadIdx.x] += b;
+            __syncthreads();
+        }
+        if (i < tiles) tile_sums[i] = make_uint2(carry_a + s_a[threadIdx.x] - v.x, carry_b + s_b[threadIdx.x] - v.y);
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_a += s_a[1023]; carry_b += s_b[1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = carry_a; totals[1] = carry_b; }
+}
+
+// exclusive (vertex, triangle) offsets of this thread's MC_ITEMS cubes inside the tile + tile prefix.
+// Cube order inside a tile: id = base + it*MC_BLOCK + tid, so the scan runs over `it` outermost.
+__device__ __forceinline__ void tile_offsets(const uint32_t (&codes)[MC_ITEMS], uint2 tile_prefix, uint32_t (&vbase)[MC_ITEMS],
+                                             uint32_t (&tbase)[MC_ITEMS]) {
+    __shared__ uint32_t s_wv[MC_ITEMS][MC_BLOCK / 64], s_wt[MC_ITEMS][MC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc_v[MC_ITEMS], inc_t[MC_ITEMS];
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        uint32_t v = code_created(codes[it]), t = code_nt(codes[it]);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t pv = __shfl_up(v, o), pt = __shfl_up(t, o);
+            if (lane >= o) { v += pv; t += pt; }
+        }
+        inc_v[it] = v; inc_t[it] = t;
+        if (lane == 63) { s_wv[it][wave] = v; s_wt[it][wave] = t; }
+    }
+    __syncthreads();
+    uint32_t run_v = tile_prefix.x, run_t = tile_prefix.y;
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        uint32_t pre_v = run_v, pre_t = run_t;
+        for (int w = 0; w < MC_BLOCK / 64; ++w) {
+            if (w < wave) { pre_v += s_wv[it][w]; pre_t += s_wt[it][w]; }
+            run_v += s_wv[it][w]; run_t += s_wt[it][w];
+        }
+        vbase[it] = pre_v + inc_v[it] - code_created(codes[it]);
+        tbase[it] = pre_t + inc_t[it] - code_nt(codes[it]);
+    }
+}
+
+struct McOut {
+    float* verts;      // (V,3) in (axis0, axis1, axis2) order
+    int32_t* faces;    // (F,3)
+    float* normals;    // (V,3)
+    float* values;     // (V,)
+    int32_t* edge_vertex[3];   // per axis (x,y,z): vertex id of the edge whose lower corner is the voxel
+    uint32_t* vertex_home;     // per vertex: creating cube (low 28 bits: tile-local... see below) -- 2 words
+};
+
+// ---- pass 3: create vertices -------------------------------------------------------------------------------
+__global__ __launch_bounds__(MC_BLOCK) void mc_emit_vertices(const float* __restrict__ vol, McDims d, double iso,
+                                                             const uint32_t* __restrict__ codes,
+                                                             const uint2* __restrict__ tile_prefix, McOut out,
+                                                             int64_t* __restrict__ vertex_cube, int8_t* __restrict__ vertex_edge) {
+    uint32_t code[MC_ITEMS], vbase[MC_ITEMS], tbase[MC_ITEMS];
+    const int64_t base = (int64_t)blockIdx.x * MC_TILE;
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
+        code[it] = id < d.cubes ? codes[id] : 0u;
+    }
+    tile_offsets(code, tile_prefix[blockIdx.x], vbase, tbase);
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        if (code_created(code[it]) == 0) continue;
+        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
+        int z, y, x;
+        cube_coords(d, id, z, y, x);
+        Cube c;
+        load_cube(vol, d, z, y, x, iso, c);
+        const int off = code_offset(code[it]), nt = code_nt(code[it]);
+        unsigned seen = 0;
+        uint32_t next = vbase[it];
+        for (int i = 0; i < 3 * nt; ++i) {
+            const int e = lut(off + i);
+            if (seen & (1u << e)) continue;
+            seen |= 1u << e;
+            if (!owns_edge(e, z, y, x)) continue;
+            double px, py, pz;
+            if (e == 12) {
+                double fx = 0, fy = 0, fz = 0, ff = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double w = 1.0 / (SK_EPS + fabs(c.v[k]));
+                    const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
+                    fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
+                }
+                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+            } else {
+                const signed char* a = MC_EDGE_A[e];
+                const signed char* b = MC_EDGE_B[e];
+                // skimage: endpoints 1 and 2 are EDGESREL*[e][0] / [1] = our A / B
+                const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
+                const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
+                const double w1 = 1.0 / (SK_EPS + fabs(c.v[ka])), w2 = 1.0 / (SK_EPS + fabs(c.v[kb]));
+                double fx = 0, fy = 0, fz = 0, ff = 0;
+                fx += (double)a[2] * w1; fy += (double)a[1] * w1; fz += (double)a[0] * w1; ff += w1;
+                fx += (double)b[2] * w2; fy += (double)b[1] * w2; fz += (double)b[0] * w2; ff += w2;
+                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+                const signed char* lo = MC_EDGE_LO[e];
+                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
+                out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
+            }
+            // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
+            out.verts[3 * (int64_t)next] = (float)pz;
+            out.verts[3 * (int64_t)next + 1] = (float)py;
+            out.verts[3 * (int64_t)next + 2] = (float)px;
+            vertex_cube[next] = id;
+            vertex_edge[next] = (int8_t)e;
+            ++next;
+        }
+    }
+}
+
+// ---- pass 4: faces -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MC_BLOCK) void mc_emit_faces(McDims d, const uint32_t* __restrict__ codes,
+                                                          const uint2* __restrict__ tile_prefix, McOut out) {
+    uint32_t code[MC_ITEMS], vbase[MC_ITEMS], tbase[MC_ITEMS];
+    const int64_t base = (int64_t)blockIdx.x * MC_TILE;
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
+        code[it] = id < d.cubes ? codes[id] : 0u;
+    }
+    tile_offsets(code, tile_prefix[blockIdx.x], vbase, tbase);
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        const int nt = code_nt(code[it]);
+        if (nt == 0) continue;
+        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
+        int z, y, x;
+        cube_coords(d, id, z, y, x);
+        const int off = code_offset(code[it]);
+        // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
+        int centre = -1;
+        {
+            unsigned seen = 0;
+            int k = 0;
+            for (int i = 0; i < 3 * nt; ++i) {
+                const int e = lut(off + i);
+                if (seen & (1u << e)) continue;
+                seen |= 1u << e;
+                if (e == 12) { centre = (int)vbase[it] + k; break; }
+                k += owns_edge(e, z, y, x) ? 1 : 0;
+            }
+        }
+        for (int t = 0; t < nt; ++t) {
+            int idx[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = lut(off + 3 * t + j);
+                if (e == 12) { idx[j] = centre; continue; }
+                const signed char* lo = MC_EDGE_LO[e];
+                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
+                idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
+            }
+            int32_t* f = out.faces + 3 * ((int64_t)tbase[it] + t);
+            f[0] = idx[2]; f[1] = idx[1]; f[2] = idx[0];   // gradient_direction='descent' reverses each triple
+        }
+    }
+}
+
+// ---- pass 5: normals + values (one thread per vertex, replaying its cubes in scan order) ---------------------
+__device__ __forceinline__ void corner_gradients(const Cube& c, double (&g)[24]) {
+    const double* v = c.v;
+    g[0] = v[0] - v[1];  g[1] = v[0] - v[3];  g[2] = v[0] - v[4];
+    g[3] = v[0] - v[1];  g[4] = v[1] - v[2];  g[5] = v[1] - v[5];
+    g[6] = v[3] - v[2];  g[7] = v[1] - v[2];  g[8] = v[2] - v[6];
+    g[9] = v[3] - v[2];  g[10] = v[0] - v[3]; g[11] = v[3] - v[7];
+    g[12] = v[4] - v[5]; g[13] = v[4] - v[7]; g[14] = v[0] - v[4];
+    g[15] = v[4] - v[5]; g[16] = v[5] - v[6]; g[17] = v[1] - v[5];
+    g[18] = v[7] - v[6]; g[19] = v[5] - v[6]; g[20] = v[2] - v[6];
+    g[21] = v[7] - v[6]; g[22] = v[4] - v[7]; g[23] = v[3] - v[7];
+}
+
+// the cubes sharing an edge, as offsets (dz,dy,dx) from the creating... from the edge's LOWER CORNER voxel,
+// in scan order, with the edge's local id inside each: [axis][k] -> {dz, dy, dx, local edge}
+__device__ __constant__ signed char MC_SHARE[3][4][4] = {
+    {{-1, -1, 0, 6}, {-1, 0, 0, 4}, {0, -1, 0, 2}, {0, 0, 0, 0}},     // x edge
+    {{-1, 0, -1, 5}, {-1, 0, 0, 7}, {0, 0, -1, 1}, {0, 0, 0, 3}},     // y edge
+    {{0, -1, -1, 10}, {0, -1, 0, 11}, {0, 0, -1, 9}, {0, 0, 0, 8}}};  // z edge
+
+__global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restrict__ vol, McDims d, double iso,
+                                                            const uint32_t* __restrict__ codes,
+                                                            const int64_t* __restrict__ vertex_cube,
+                                                            const int8_t* __restrict__ vertex_edge, int64_t nverts,
+                                                            McOut out) {
+    const int64_t vid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vid >= nverts) return;
+    const int64_t home = vertex_cube[vid];
+    const int e_home = vertex_edge[vid];
+    int hz, hy, hx;
+    cube_coords(d, home, hz, hy, hx);
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f, value = 0.0f;
+    int ncubes = 1, axis = 0, lz = 0, ly = 0, lx = 0;
+    if (e_home != 12) {
+        axis = MC_EDGE_AXIS[e_home];
+        lz = hz + MC_EDGE_LO[e_home][0]; ly = hy + MC_EDGE_LO[e_home][1]; lx = hx + MC_EDGE_LO[e_home][2];
+        ncubes = 4;
+    }
+    for (int k = 0; k < ncubes; ++k) {
+        int z, y, x, e;
+        if (e_home == 12) { z = hz; y = hy; x = hx; e = 12; }
+        else {
+            const signed char* s = MC_SHARE[axis][k];
+            z = lz + s[0]; y = ly + s[1]; x = lx + s[2]; e = s[3];
+            if (z < 0 || y < 0 || x < 0 || z >= d.c0 || y >= d.c1 || x >= d.c2) continue;
+        }
+        const uint32_t code = codes[((int64_t)z * d.c1 + y) * d.c2 + x];
+        const int nt = code_nt(code), off = code_offset(code);
+        if (nt == 0) continue;
+        Cube c;
+        load_cube(vol, d, z, y, x, iso, c);
+        // vmax of the cube = max(v,0) - min(v,0)
+        double lo = 0.0, hi = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { hi = c.v[q] > hi ? c.v[q] : hi; lo = c.v[q] < lo ? c.v[q] : lo; }
+        const double vmax = hi - lo;
+        double g[24];
+        corner_gradients(c, g);
+        float gx = 0, gy = 0, gz = 0;   // contribution per reference
+        float s1 = 0, s2 = 0;
+        int i1 = 0, i2 = 0;
+        if (e == 12) {
+            double w[8], sx = 0, sy = 0, sz = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = 1.0 / (SK_EPS + fabs(c.v[q]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { sx += w[q] * g[3 * q]; sy += w[q] * g[3 * q + 1]; sz += w[q] * g[3 * q + 2]; }
+            (void)sx;
+            gx = (float)sz; gy = (float)sy; gz = 0.0f;   // skimage's centre gradient: (sum w*gz, sum w*gy, 0)
+        } else {
+            const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;
+            const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4;
+            i1 = bitwise_index(MC_EDGE_A[e]); i2 = bitwise_index(MC_EDGE_B[e]);
+            s1 = (float)(1.0 / (SK_EPS + fabs(c.v[ka])));   // `strength` is a C float in skimage
+            s2 = (float)(1.0 / (SK_EPS + fabs(c.v[kb])));
+        }
+        bool referenced = false;
+        for (int i = 0; i < 3 * nt; ++i) {
+            if (lut(off + i) != e) continue;
+            referenced = true;
+            if (e == 12) { nx += gx; ny += gy; nz += gz; }
+            else {
+                nx += (float)(g[3 * i1] * (double)s1); ny += (float)(g[3 * i1 + 1] * (double)s1); nz += (float)(g[3 * i1 + 2] * (double)s1);
+                nx += (float)(g[3 * i2] * (double)s2); ny += (float)(g[3 * i2 + 1] * (double)s2); nz += (float)(g[3 * i2 + 2] * (double)s2);
+            }
+        }
+        if (referenced && vmax > (double)value) value = (float)vmax;
+    }
+    const double len = sqrt((double)nx * nx + (double)ny * ny + (double)nz * nz);
+    if (len > 0.0) { nx = (float)(nx / len); ny = (float)(ny / len); nz = (float)(nz / len); }
+    out.normals[3 * vid] = nz; out.normals[3 * vid + 1] = ny; out.normals[3 * vid + 2] = nx;   // flipped columns
+    out.values[vid] = value;
+}
+
+static inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct McWorkspace {
+    uint32_t* codes; uint2* tile_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
+    int64_t tiles;
+};
+
+static McDims make_dims(int n0, int n1, int n2) {
+    McDims d{n0, n1, n2, n0 - 1, n1 - 1, n2 - 1, (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1)};
+    return d;
+}
+
+static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
+    const int64_t tiles = (d.cubes + MC_TILE - 1) / MC_TILE;
+    const size_t vox = (size_t)d.n0 * d.n1 * d.n2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
+    char* p;
+    p = take((size_t)d.cubes * 4); if (ws) ws->codes = (uint32_t*)p;
+    p = take((size_t)tiles * 8); if (ws) ws->tile_sums = (uint2*)p;
+    p = take(256); if (ws) ws->totals = (uint32_t*)p;
+    for (int a = 0; a < 3; ++a) { p = take(vox * 4); if (ws) ws->edge[a] = (int32_t*)p; }
+    if (ws) ws->tiles = tiles;
+    return off;
+}
+
+}  // namespace nm
+
+using namespace nm;
+
+extern "C" {
+
+int64_t nm_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2) {
+    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
+    return (int64_t)carve(make_dims(n0, n1, n2), nullptr, nullptr);
+}
+
+int64_t nm_mc_vertex_scratch_bytes(int64_t vertices) { return (int64_t)(al((size_t)vertices * 8) + al((size_t)vertices)); }
+
+int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
+                int64_t* h_vertices, int64_t* h_faces, void* stream_) {
+    NM_REQUIRE(d_volume && d_workspace && h_vertices && h_faces, "bad argument");
+    NM_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const McDims d = make_dims(n0, n1, n2);
+    NM_REQUIRE(d.cubes < (int64_t(1) << 40), "volume too large");
+    McWorkspace ws;
+    carve(d, static_cast<char*>(d_workspace), &ws);
+    hipLaunchKernelGGL(mc_classify, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
+                       ws.tile_sums);
+    hipLaunchKernelGGL(mc_scan_tiles, dim3(1), dim3(1024), 0, stream, ws.tile_sums, ws.tiles, ws.totals);
+    NM_HIP_CHECK(hipGetLastError());
+    uint32_t totals[2];
+    NM_HIP_CHECK(hipMemcpyAsync(totals, ws.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+    NM_HIP_CHECK(hipStreamSynchronize(stream));
+    *h_vertices = totals[0];
+    *h_faces = totals[1];
+    return 0;
+}
+
+int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
+               void* d_vertex_scratch, int64_t vertices, int64_t faces, float* d_verts, int32_t* d_faces,
+               float* d_normals, float* d_values, void* stream_) {
+    NM_REQUIRE(d_volume && d_workspace && d_vertex_scratch && d_verts && d_faces && d_normals && d_values, "bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (vertices == 0) return 0;
+    const McDims d = make_dims(n0, n1, n2);
+    McWorkspace ws;
+    carve(d, static_cast<char*>(d_workspace), &ws);
+    ws.vertex_cube = static_cast<int64_t*>(d_vertex_scratch);
+    ws.vertex_edge = reinterpret_cast<int8_t*>(static_cast<char*>(d_vertex_scratch) + al((size_t)vertices * 8));
+    McOut out;
+    out.verts = d_verts; out.faces = d_faces; out.normals = d_normals; out.values = d_values;
+    for (int a = 0; a < 3; ++a) out.edge_vertex[a] = ws.edge[a];
+    out.vertex_home = nullptr;
+    hipLaunchKernelGGL(mc_emit_vertices, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
+                       ws.tile_sums, out, ws.vertex_cube, ws.vertex_edge);
+    hipLaunchKernelGGL(mc_emit_faces, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d, ws.codes, ws.tile_sums, out);
+    hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((vertices + 255) / 256)), dim3(256), 0, stream, d_volume, d, iso,
+                       ws.codes, ws.vertex_cube, ws.vertex_edge, vertices, out);
+    NM_HIP_CHECK(hipGetLastError());
+    (void)faces;
+    return 0;
+}
+
+}  // extern "C"

@@ -236,3 +236,34 @@ def buff_intersect(voxels, origins, dirs, near, far, samples):
                                 _ptr(dirs), float(near), float(far), rays, samples, _ptr(z), _ptr(idx), _ptr(mask),
                                 _stream()), "nm_buff_intersect")
     return z, idx, mask.bool()
+
+
+def marching_cubes(volume, level):
+    """skimage.measure.marching_cubes(volume, level) on the GPU (nm_mc_count + nm_mc_emit).
+    volume: (n0,n1,n2) fp32 CUDA tensor.  Returns (verts (V,3) f32, faces (F,3) i32, normals (V,3) f32,
+    values (V,) f32) as CUDA tensors; raises ValueError / RuntimeError exactly where skimage does."""
+    lib = _lib.load()
+    if not isinstance(volume, torch.Tensor) or volume.dim() != 3:
+        raise ValueError("Input volume should be a 3D tensor.")
+    if min(volume.shape) < 2:
+        raise ValueError("Input array must be at least 2x2x2.")
+    vol = _dev32(volume, name="volume")
+    level = float(level)
+    lo, hi = (float(v) for v in torch.aminmax(vol))
+    if level < lo or level > hi:
+        raise ValueError("Surface level must be within volume data range.")
+    n0, n1, n2 = vol.shape
+    dev = vol.device
+    ws = torch.empty(int(lib.nm_mc_workspace_bytes(n0, n1, n2)), dtype=torch.uint8, device=dev)
+    nv, nf = C.c_int64(), C.c_int64()
+    check(lib.nm_mc_count(_ptr(vol), n0, n1, n2, level, _ptr(ws), C.byref(nv), C.byref(nf), _stream()), "nm_mc_count")
+    if nv.value == 0:
+        raise RuntimeError("No surface found at the given iso value.")
+    verts = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)
+    normals = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)
+    values = torch.empty(nv.value, dtype=torch.float32, device=dev)
+    faces = torch.empty(nf.value, 3, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(lib.nm_mc_vertex_scratch_bytes(nv.value)) + 256, dtype=torch.uint8, device=dev)
+    check(lib.nm_mc_emit(_ptr(vol), n0, n1, n2, level, _ptr(ws), _ptr(scratch), nv.value, nf.value, _ptr(verts),
+                         _ptr(faces), _ptr(normals), _ptr(values), _stream()), "nm_mc_emit")
+    return verts, faces, normals, values
