@@ -149,6 +149,17 @@ int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * BuFF voxel-tree sampler: TreeSampling.batch_ray_voxel_intersect, deterministic branch
+ * (src/nerf/tree.py:215-343).  d_voxels (nvox,2,3) min/max corners; d_origins (1,3) or (rays,3);
+ * d_u = linspace(0,1,samples).  Outputs: d_z (rays,samples) sorted depths, d_idx (rays,samples) int64
+ * voxel ids, d_mask (rays,) uint8 "ray crosses at least one voxel inside [near, far]".
+ * Synchronises the stream (overflow check: a ray may cross at most 512 voxels).
+ * ------------------------------------------------------------------------------------------ */
+int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                      const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
+                      int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Marching cubes: skimage.measure.marching_cubes(volume, level) as called at src/mesh_nerf.py:79
  * (third-party scikit-image 0.17.2, Lewiner MC33, defaults: step_size=1, gradient_direction='descent',
  * allow_degenerate=True, no mask).  Output-identical: vertices (V,3) fp32 in (axis0,axis1,axis2) order,

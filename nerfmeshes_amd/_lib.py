@@ -65,6 +65,8 @@ SIGNATURES = {
     "nm_render_rays": (C.c_int, [c_void_p, c_void_p, C.POINTER(RenderCfg), c_void_p, C.c_int, c_void_p, c_void_p,
                                  c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, c_void_p, C.POINTER(BundleOut),
                                  C.POINTER(BundleOut), c_void_p]),
+    "nm_buff_intersect": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
+                                    C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_mc_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "nm_mc_vertex_scratch_bytes": (C.c_int64, [C.c_int64]),
     "nm_mc_count": (C.c_int, [c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_void_p, C.POINTER(C.c_int64),

@@ -1,0 +1,191 @@
+// BuFF voxel-tree sampler for gfx950: TreeSampling.batch_ray_voxel_intersect, deterministic branch
+// (/root/reference/src/nerf/tree.py:215-343) as ONE kernel, one 64-lane wavefront per ray.
+//
+// The reference materialises dense (R, N, 3) slab-test tensors (2 x 42 MB at R = 2048, N = 1728), sorts all
+// N voxels per ray three times and gathers five times.  Here a wave streams the N axis-aligned boxes (41 KB,
+// L2 resident) through the slab test, compacts the handful of boxes the ray actually crosses into LDS with a
+// ballot, orders them by entry depth, and places the S samples:
+//   samples = linspace(0,1,S) * (total crossed length); bucket = first box whose cumulative length reaches
+//   the sample; z = t_enter(bucket) + (sample - first sample of the same bucket); final sort by z.
+// z values and the ray mask are bit-identical to the reference (same fp32 expressions, cumulative lengths
+// accumulated in fp64 and rounded per element like torch.cumsum).  Voxel ids follow a STABLE ordering of
+// ties; the reference leaves that order to torch.sort's unstable default, which makes its ids inconsistent
+// with its own z values on ~90 % of samples (tests/test_oracle_golden.py::test_buff_...).
+#include "nm_internal.h"
+
+namespace nm {
+
+constexpr int BUFF_MAX_HITS = 512;     // boxes one ray can cross (12^3 root grid: <= 34; refined trees more)
+constexpr int BUFF_MAX_SAMPLES = 512;
+
+__device__ __forceinline__ double shfl_up_d(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta); hi = __shfl_up(hi, delta);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void buff_intersect_kernel(const float* __restrict__ voxels, int nvox,
+                                                             const float* __restrict__ origins, int origins_per_ray,
+                                                             const float* __restrict__ dirs, float near_, float far_,
+                                                             const float* __restrict__ u, int64_t rays, int samples,
+                                                             float* __restrict__ z_out, int64_t* __restrict__ idx_out,
+                                                             uint8_t* __restrict__ mask_out, int* __restrict__ overflow) {
+    __shared__ float h_tmin[4][BUFF_MAX_HITS], h_tmax[4][BUFF_MAX_HITS], s_tmin[4][BUFF_MAX_HITS], s_cum[4][BUFF_MAX_HITS];
+    __shared__ int h_id[4][BUFF_MAX_HITS], s_id[4][BUFF_MAX_HITS];
+    __shared__ float p_s[4][BUFF_MAX_SAMPLES], p_z[4][BUFF_MAX_SAMPLES];
+    __shared__ int p_bucket[4][BUFF_MAX_SAMPLES], p_vid[4][BUFF_MAX_SAMPLES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + wv; ray < rays; ray += (int64_t)gridDim.x * 4) {
+        const float* o = origins + (origins_per_ray ? 3 * ray : 0);
+        float inv[3], org[3];
+        int sgn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            org[a] = o[a];
+            inv[a] = 1.0f / dirs[3 * ray + a];
+            sgn[a] = inv[a] < 0.0f ? 1 : 0;
+        }
+        // ---- slab test over all boxes, ballot-compaction of the crossed ones (in box-index order)
+        int K = 0;
+        float best_t = 0.0f;
+        int best_i = 0x7fffffff;
+        bool have_best = false;
+        for (int base = 0; base < nvox; base += 64) {
+            const int n = base + lane;
+            bool valid = false;
+            float tmin = 0.0f, tmax = 0.0f;
+            if (n < nvox) {
+                const float* b = voxels + 6 * (int64_t)n;   // [min xyz | max xyz]
+                float lo_t[3], hi_t[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    lo_t[a] = (b[3 * sgn[a] + a] - org[a]) * inv[a];
+                    hi_t[a] = (b[3 * (1 - sgn[a]) + a] - org[a]) * inv[a];
+                }
+                valid = (lo_t[0] <= hi_t[1]) && (lo_t[1] <= hi_t[0]);
+                tmin = lo_t[1] > lo_t[0] ? lo_t[1] : lo_t[0];
+                tmax = hi_t[1] < hi_t[0] ? hi_t[1] : hi_t[0];
+                valid = valid && (tmin <= hi_t[2]) && (lo_t[2] <= tmax);
+                tmin = lo_t[2] > tmin ? lo_t[2] : tmin;
+                tmax = hi_t[2] < tmax ? hi_t[2] : tmax;
+                valid = valid && (tmin >= near_) && (tmax <= far_);
+                // stable argmin of tmin over ALL boxes: what the reference reports for rays that miss everything
+                if (!have_best || tmin < best_t) { best_t = tmin; best_i = n; have_best = true; }
+            }
+            const unsigned long long bal = __ballot(valid);
+            if (valid) {
+                const int pos = K + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < BUFF_MAX_HITS) { h_tmin[wv][pos] = tmin; h_tmax[wv][pos] = tmax; h_id[wv][pos] = n; }
+            }
+            K += __popcll(bal);
+        }
+        if (K > BUFF_MAX_HITS) { if (lane == 0) atomicExch(overflow, 1); K = BUFF_MAX_HITS; }
+        // wave argmin (ties -> lowest index); NaN entry depths never win, as in a stable ascending sort
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ot = __shfl_xor(best_t, off);
+            const int oi = __shfl_xor(best_i, off);
+            const bool oh = __shfl_xor((int)have_best, off) != 0;
+            if (oh && (!have_best || ot < best_t || (ot == best_t && oi < best_i))) { best_t = ot; best_i = oi; have_best = true; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- order the crossed boxes by entry depth (rank sort, ties keep box-index order)
+        for (int i = lane; i < K; i += 64) {
+            const float t = h_tmin[wv][i];
+            int rank = 0;
+            for (int k = 0; k < K; ++k) {
+                const float ot = h_tmin[wv][k];
+                rank += (ot < t || (ot == t && k < i)) ? 1 : 0;
+            }
+            s_tmin[wv][rank] = t;
+            s_cum[wv][rank] = h_tmax[wv][i] - t;     // crossed length, turned into its running sum below
+            s_id[wv][rank] = h_id[wv][i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- cumulative crossed length: fp64 accumulation, fp32 per element (torch.cumsum on CPU)
+        double carry = 0.0;
+        for (int base = 0; base < K; base += 64) {
+            const int i = base + lane;
+            double incl = i < K ? (double)s_cum[wv][i] : 0.0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double p = shfl_up_d(incl, off);
+                if (lane >= off) incl += p;
+            }
+            incl += carry;
+            if (i < K) s_cum[wv][i] = (float)incl;
+            const int lo = __double2loint(incl), hi = __double2hiint(incl);
+            carry = __hiloint2double(__shfl(hi, 63), __shfl(lo, 63));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float total = K > 0 ? s_cum[wv][K - 1] : 0.0f;
+        // ---- place the samples
+        for (int j = lane; j < samples; j += 64) {
+            const float s = u[j] * total;
+            int lo = 0, hi = K > 0 ? K - 1 : 0;     // first i with cum[i] >= s (cum[K-1] == total >= s)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cum[wv][mid] < s) lo = mid + 1; else hi = mid;
+            }
+            p_s[wv][j] = s;
+            p_bucket[wv][j] = lo;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < samples; j += 64) {
+            const int bkt = p_bucket[wv][j];
+            int lo = 0, hi = j;                      // first sample of the same bucket
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (p_bucket[wv][mid] < bkt) lo = mid + 1; else hi = mid;
+            }
+            const float offset = p_s[wv][j] - p_s[wv][lo];
+            p_z[wv][j] = (K > 0 ? s_tmin[wv][bkt] : 0.0f) + offset;
+            p_vid[wv][j] = K > 0 ? s_id[wv][bkt] : best_i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- final ascending sort of the depths (stable), voxel ids follow
+        for (int j = lane; j < samples; j += 64) {
+            const float zj = p_z[wv][j];
+            int rank = 0;
+            for (int k = 0; k < samples; ++k) {
+                const float zk = p_z[wv][k];
+                rank += (zk < zj || (zk == zj && k < j)) ? 1 : 0;
+            }
+            z_out[ray * samples + rank] = zj;
+            idx_out[ray * samples + rank] = p_vid[wv][j];
+        }
+        if (lane == 0) mask_out[ray] = K > 0 ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace nm
+
+using namespace nm;
+
+extern "C" int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                                 const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
+                                 int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream_) {
+    NM_REQUIRE(d_voxels && d_origins && d_dirs && d_u && d_z && d_idx && d_mask, "bad argument");
+    NM_REQUIRE(nvox > 0 && samples > 0 && samples <= BUFF_MAX_SAMPLES, "buff_intersect: samples must be in [1, 512]");
+    if (rays <= 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static int* d_overflow = nullptr;
+    if (!d_overflow) {
+        NM_HIP_CHECK(hipMalloc(&d_overflow, sizeof(int)));
+        NM_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
+    }
+    const int64_t blocks = (rays + 3) / 4;
+    hipLaunchKernelGGL(buff_intersect_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream,
+                       d_voxels, nvox, d_origins, origins_per_ray, d_dirs, near_, far_, d_u, rays, samples, d_z, d_idx,
+                       d_mask, d_overflow);
+    NM_HIP_CHECK(hipGetLastError());
+    int h = 0;
+    NM_HIP_CHECK(hipMemcpyAsync(&h, d_overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+    NM_HIP_CHECK(hipStreamSynchronize(stream));
+    if (h) {
+        NM_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
+        set_error("buff_intersect: a ray crosses more than 512 voxels (BUFF_MAX_HITS)");
+        return 4;
+    }
+    return 0;
+}

@@ -1,0 +1,74 @@
+"""Multi-GPU sharding of the hot path (one process per GPU, torch.distributed; backend "nccl" = RCCL over
+xGMI on the MI355X node, "gloo" in the CPU tests).
+
+The path is embarrassingly parallel: rays never interact, grid voxels never interact,
+weights (2.4 MB / network) are replicated.  So there is NO collective inside the data path; each rank renders
+a contiguous range of rays / axis-0 slab of the grid, and ONE all-gather at the end assembles the pixels or the
+density grid on every rank (marching cubes then runs on the full grid, which keeps the vertex numbering
+identical to the single-GPU result by construction).
+"""
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world():
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def split_range(n, rank, world_size):
+    """Contiguous near-equal split of range(n): the first n % world ranks get one extra item."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def slab_range(n0, rank, world_size):
+    """Axis-0 planes of the density grid owned by `rank` (axis 0 is the outermost marching-cubes scan axis)."""
+    return split_range(n0, rank, world_size)
+
+
+def all_gather_rows(local, counts):
+    """All-gather a ragged first dimension: `local` is this rank's (counts[rank], ...) tensor; returns the
+    concatenation over ranks on every rank.  Equal shards take the single-collective fast path
+    (all_gather_into_tensor -> one RCCL ring over xGMI); ragged shards are padded to the largest."""
+    dist = _dist()
+    rank, ws = world()
+    if ws == 1:
+        return local
+    tail = tuple(local.shape[1:])
+    if len(set(counts)) == 1:
+        out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    m = max(counts)
+    padded = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    out = torch.empty((ws * m,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded)
+    out = out.view((ws, m) + tail)
+    return torch.cat([out[r, :counts[r]] for r in range(ws)], 0)
+
+
+def render_view_sharded(render_fn, num_rays):
+    """Each rank renders rays [lo, hi) with `render_fn(lo, hi) -> (hi-lo, C)` and all ranks receive the
+    full (num_rays, C) image."""
+    rank, ws = world()
+    counts = [b - a for a, b in (split_range(num_rays, r, ws) for r in range(ws))]
+    lo, hi = split_range(num_rays, rank, ws)
+    return all_gather_rows(render_fn(lo, hi), counts)
+
+
+def density_grid_sharded(query_fn, n0, n1, n2):
+    """Each rank evaluates its slab of axis-0 planes with `query_fn(plane_lo, plane_hi) -> ((hi-lo)*n1*n2,)`
+    and all ranks receive the full (n0, n1, n2) grid."""
+    rank, ws = world()
+    counts = [(b - a) * n1 * n2 for a, b in (slab_range(n0, r, ws) for r in range(ws))]
+    lo, hi = slab_range(n0, rank, ws)
+    return all_gather_rows(query_fn(lo, hi), counts).view(n0, n1, n2)

@@ -221,20 +221,20 @@ def mlp_profile_read():
 
 
 def buff_intersect(voxels, origins, dirs, near, far, samples):
-    """TreeSampling.batch_ray_voxel_intersect on the GPU (nm_buff_intersect)."""
+    """TreeSampling.batch_ray_voxel_intersect on the GPU (nm_buff_intersect):
+    (z (R,S) f32, voxel ids (R,S) i64, ray_mask (R,) bool)."""
     lib = _lib.load()
-    if not hasattr(lib, "nm_buff_intersect"):
-        raise _lib.HipLibraryError("libnerfmeshes_hip.so was built without nm_buff_intersect")
     voxels = _dev32(voxels, name="voxels")
     dev = voxels.device
     origins, dirs = _dev32(origins, dev, "origins").reshape(-1, 3), _dev32(dirs, dev, "dirs").reshape(-1, 3)
     rays = dirs.shape[0]
+    u = torch.linspace(0, 1.0, samples).to(dev)                   # tree.py:318
     z = torch.empty(rays, samples, dtype=torch.float32, device=dev)
     idx = torch.empty(rays, samples, dtype=torch.int64, device=dev)
     mask = torch.empty(rays, dtype=torch.uint8, device=dev)
     check(lib.nm_buff_intersect(_ptr(voxels), voxels.shape[0], _ptr(origins), int(origins.shape[0] == rays and rays > 1),
-                                _ptr(dirs), float(near), float(far), rays, samples, _ptr(z), _ptr(idx), _ptr(mask),
-                                _stream()), "nm_buff_intersect")
+                                _ptr(dirs), float(near), float(far), _ptr(u), rays, samples, _ptr(z), _ptr(idx),
+                                _ptr(mask), _stream()), "nm_buff_intersect")
     return z, idx, mask.bool()
 
 

@@ -323,3 +323,63 @@ def iso_level(density, requested):
     """mesh_nerf.py:56-65 on a numpy fp32 volume."""
     lo, hi, sd = density.min(), density.max(), density.std()
     return min(max(requested, lo + sd), hi - sd)
+
+
+# ----------------------------------------------------------------------------- BuFF voxel tree (R9, R10)
+
+def buff_initial_voxels(near, far, outer_count):
+    """TreeSampling.__init__ + Node.subdivide + consolidate for a fresh tree (tree.py:71-92,19-33,162-175):
+    outer_count^3 voxels tiling [near - mean, far - mean]^3, x-major / z-fastest, (N,2,3) min/max corners."""
+    mean = (near + far) / 2
+    lo, hi = torch.tensor([near - mean] * 3), torch.tensor([far - mean] * 3)
+    extent = hi - lo
+    out = []
+    for i in range(outer_count):
+        for g in range(outer_count):
+            for h in range(outer_count):
+                a = torch.tensor([i, g, h], dtype=torch.float) / outer_count * extent
+                b = torch.tensor([i + 1, g + 1, h + 1], dtype=torch.float) / outer_count * extent
+                out.append(torch.stack((lo + a, lo + b), 0))
+    return torch.stack(out, 0)
+
+
+def buff_intersect(voxels, origins, dirs, near, far, samples_count):
+    """TreeSampling.batch_ray_voxel_intersect, deterministic branch (tree.py:215-343).
+    Returns (z_vals (R,S), voxel indices (R,S) int64, ray_mask (R,) bool); sorts are made stable so that the
+    voxel indices are well defined (the reference leaves ties to the sort implementation)."""
+    voxels, origins, dirs = _t(voxels), _t(origins), _t(dirs)
+    R, N = dirs.shape[0], voxels.shape[0]
+    inv = 1 / dirs
+    signs = (inv < 0).long()
+    b = voxels.transpose(0, 1)                                     # (2,N,3)
+    ax = torch.arange(3)
+
+    def pick(s):                                                   # (R,N,3): bounds[s[r,a], n, a]
+        return b[s[:, None, :].expand(R, N, 3), torch.arange(N)[None, :, None].expand(R, N, 3), ax[None, None, :].expand(R, N, 3)]
+
+    o = origins[:, None, :]
+    tvmin = (pick(signs) - o) * inv[:, None, :]
+    tvmax = (pick(1 - signs) - o) * inv[:, None, :]
+    mask = (tvmin[..., 0] <= tvmax[..., 1]) & (tvmin[..., 1] <= tvmax[..., 0])
+    tmin = torch.where(tvmin[..., 1] > tvmin[..., 0], tvmin[..., 1], tvmin[..., 0])
+    tmax = torch.where(tvmax[..., 1] < tvmax[..., 0], tvmax[..., 1], tvmax[..., 0])
+    mask = mask & (tmin <= tvmax[..., 2]) & (tvmin[..., 2] <= tmax)
+    tmin = torch.where(tvmin[..., 2] > tmin, tvmin[..., 2], tmin)
+    tmax = torch.where(tvmax[..., 2] < tmax, tvmax[..., 2], tmax)
+    mask = mask & (tmin >= near) & (tmax <= far)
+    ray_mask = mask.sum(-1) > 0
+    order = torch.sort(tmin, dim=-1, stable=True)
+    inter = torch.stack((tmin, tmax), -1).gather(-2, order.indices[..., None].expand(R, N, 2))
+    mask_sorted = mask.gather(-1, order.indices)
+    start = torch.sort(mask_sorted.long(), dim=-1, descending=True, stable=True)
+    res = torch.zeros_like(inter)
+    res[start.values.bool()] = inter[mask_sorted]
+    cums = torch.cumsum(res[..., 1] - res[..., 0], -1)
+    samples = torch.linspace(0, 1.0, samples_count) * cums[..., -1][..., None]
+    bucket = torch.searchsorted(cums, samples)
+    first = torch.searchsorted(bucket, bucket, right=False)
+    offset = samples - samples.gather(-1, first)
+    z = res[..., 0].gather(-1, bucket) + offset
+    vox = order.indices.gather(-1, start.indices.gather(-1, bucket))
+    z, zorder = torch.sort(z, dim=-1, stable=True)
+    return z, vox.gather(-1, zorder), ray_mask

@@ -179,5 +179,42 @@ def main():
     case_eval_loss("eval_loss")
 
 
+
+
+def case_buff(name):
+    """R9/R10: the reference's TreeSampling (fresh 12^3 tree of buff-colmap-fern) and BuFFModel.forward."""
+    nerf, models = ref_import.load()
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2,
+                   dataset_type="colmap")
+    m = models.BuFFModel(hp).eval()
+    w = S.make_mlp_weights(9, density_gain=1500.0, density_bias=60.0, **mlp_kwargs(hp, "coarse"))
+    load_weights(m, "model.", w)
+    g = torch.Generator().manual_seed(21)
+    # cameras on a sphere of radius ~1 around the voxel cube [-0.6, 0.6]^3, looking roughly at the centre
+    n = 160
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * (0.75 + 0.5 * torch.rand(n, 1, generator=g))
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 0.9
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    d[:8] = torch.nn.functional.normalize(o[:8], dim=-1)            # looking away: no voxel hit
+    bounds = torch.tensor([0.0, 1.2])
+    with torch.no_grad():
+        z, idx, mask = m.tree.batch_ray_voxel_intersect(o, d, 0.0, 1.2, samples_count=192)
+        bundle = m.forward((o, d, bounds))
+    out = dict(origins=o.numpy(), directions=d.numpy(), voxels=m.tree.voxels.numpy(), z=z.numpy(), idx=idx.numpy(),
+               mask=mask.numpy(), seed=9, gain=1500.0, bias=60.0,
+               hparams_keys=np.array(list(hp.keys())), hparams_vals=np.array([repr(v) for v in hp.values()]))
+    bundle_to_np("bundle.", bundle, out)
+    # single shared origin variant (origins (1,3)), as eval_nerf feeds it
+    with torch.no_grad():
+        z1, idx1, mask1 = m.tree.batch_ray_voxel_intersect(o[40:41], d, 0.0, 1.2, samples_count=192)
+    out.update(z_shared=z1.numpy(), idx_shared=idx1.numpy(), mask_shared=mask1.numpy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "hit rays", int(mask.sum()), "/", n, "acc", float(bundle.acc_map.mean()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--buff" in sys.argv:
+        case_buff("buff_fern")
+    else:
+        main()
+        case_buff("buff_fern")
