@@ -49,3 +49,15 @@ def golden_weights(g, hp):
 
 RENDER_CASES = ("render_lego_scene", "render_lego_rough", "render_lego_default_init", "render_lego_perray_white_lindisp",
                 "render_tiny", "render_fern_8x128")
+
+
+def well_conditioned_rays(g):
+    """Rays whose hierarchical resampling is numerically meaningful.  SamplePDF normalises
+    (weights[1:-1] + 1e-5); when the coarse pass saw (almost) nothing -- sum of coarse weights within ~10x of
+    that 62 * 1e-5 floor -- the pdf is dominated by the fp32 noise (~1e-4 absolute) of individual coarse weights,
+    every fine sample moves, and a grazing sliver of density is integrated differently.  The reference shows
+    the same sensitivity to its own summation order; such rays are compared loosely."""
+    if "fine.rgb_map" not in g.files:
+        return np.ones(g["coarse.acc_map"].shape, dtype=bool)
+    acc = g["coarse.acc_map"]
+    return ~((acc > 0) & (acc < 5e-3))    # exactly-empty rays (all coarse weights 0) are perfectly stable
