@@ -66,6 +66,9 @@ typedef struct nm_mlp nm_mlp;
  * Unsupported (hidden_size, num_encoding_fn_*) combinations fail with a message. */
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
 void nm_mlp_destroy(nm_mlp* mlp);
+/* Which tuning variant of the kernel the handle was bound to (0 = production; NM_MLP_VARIANT selects others
+ * for A/B measurements) and its waves per workgroup. */
+int nm_mlp_kernel_variant(const nm_mlp* mlp, int* waves_per_workgroup);
 /* FLOP of one sample through the net (weights-only count). */
 int64_t nm_mlp_flops_per_sample(const nm_mlp* mlp, int density_only);
 

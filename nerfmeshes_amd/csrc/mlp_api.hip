@@ -223,6 +223,13 @@ void nm_mlp_destroy(nm_mlp* m) {
     delete m;
 }
 
+int nm_mlp_kernel_variant(const nm_mlp* m, int* waves_per_workgroup) {
+    int nw = 0;
+    const int v = mlp_plan_info(m->plan, &nw);
+    if (waves_per_workgroup) *waves_per_workgroup = nw;
+    return v;
+}
+
 int64_t nm_mlp_flops_per_sample(const nm_mlp* m, int density_only) {
     return density_only ? m->flops_density : m->flops_full;
 }

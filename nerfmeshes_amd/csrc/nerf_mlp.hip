@@ -24,6 +24,8 @@
 //
 // Roofline: MFMA (fp32 matrix peak 157.3 TFLOP/s).  593 408 MAC per sample for the 8x256 net; the
 // kernel issues 9 280 MFMAs (1 024 MAC each) per 16-sample tile = 99.9 % useful work.
+#include <stdlib.h>
+
 #include "nm_internal.h"
 
 namespace nm {
@@ -31,9 +33,9 @@ namespace nm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int H_, int FX_, int FD_>
+template <int H_, int FX_, int FD_, int KCH_ = KC>
 struct Net {
-    static constexpr int H = H_, FX = FX_, FD = FD_;
+    static constexpr int H = H_, FX = FX_, FD = FD_, KCH = KCH_;
     static constexpr int NT = H / 16;                // 16-row output tiles of a hidden layer
     static constexpr int KH = H / 4;                 // k-steps across a hidden activation
     static constexpr int EX = (3 * FX + 1) / 2 + 1;  // k-steps across the xyz encoding
@@ -42,9 +44,10 @@ struct Net {
     static constexpr int KD = H / 8;                 // k-steps across the view layer output
     static constexpr int STEP = NT * 256;            // bytes of A operands per k-step (hidden out)
     static constexpr int STEPD = NTD * 256;
-    static constexpr int LDSBUF = KC * STEP;         // one ring slot
-    static constexpr int L1_FIRST = (EX < KC ? EX : KC) * STEP;
-    static constexpr int DIR_FIRST = KC * STEPD;     // KH + ED >= KC always
+    static constexpr int LDSBUF = KCH * STEP;        // one ring slot
+    static constexpr int L1_FIRST = (EX < KCH ? EX : KCH) * STEP;
+    static constexpr int DIR_FIRST = (KH + ED < KCH ? KH + ED : KCH) * STEPD;
+    static_assert(KH >= KCH, "a hidden layer must span at least one full chunk");
 };
 
 // ---- weight stream: HBM/L2 -> LDS DMA, 1 KiB per wave-instruction, LDS image == stream image ------
@@ -61,46 +64,62 @@ __device__ __forceinline__ void stream_to_lds(const char* src, char* dst, int by
 // One GEMM "stage": acc[NT tiles] += W_stage * B, B = KS1 registers of b1 followed by KS2 of b2.
 // On entry chunk 0 of the stage is resident in ring slot `par`; on exit the chunk described by
 // (tail_src, tail_bytes) -- the first chunk of whatever runs next -- is resident in slot `par`.
-template <int NT, int KS1, int KS2, int NW, int LDSBUF>
+// Per chunk: start the DMA of the following chunk, run this chunk's MFMAs with the A operands of the NEXT
+// k-step already in flight (PIPE; pinned with sched_barrier -- hipcc otherwise sinks the ds_reads next to
+// their use, and the two waves of a SIMD, released together by the barrier, then expose the LDS latency
+// together every 8 MFMAs), one barrier.  (The cursor is SGPR arithmetic on purpose: a chunk table fetched
+// with s_load costs 3 % -- its s_waitcnt lgkmcnt(0) also drains the in-flight ds_reads.)
+template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE>
 __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[KS1],
                                            const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
                                            const char* tail_src, int tail_bytes, char* lds, int& par,
                                            int wave, int lane) {
     constexpr int KS = KS1 + KS2;
-    constexpr int NCH = (KS + KC - 1) / KC;
+    constexpr int NCH = (KS + KCH - 1) / KCH;
     constexpr int VW = NT >= 4 ? 4 : NT;  // A operands fetched per LDS read
     constexpr int NB = NT / VW;
     constexpr int STEP_BYTES = NT * 256;
+    typedef float avec __attribute__((ext_vector_type(VW)));
     static_assert(NT % VW == 0 && (VW == 4 || VW == 2), "tile count");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int steps = (KS - c * KC) < KC ? (KS - c * KC) : KC;
+        const int steps = (KS - c * KCH) < KCH ? (KS - c * KCH) : KCH;
         char* next_slot = lds + (par ^ 1) * LDSBUF;
         if (c + 1 < NCH) {
-            const int nsteps = (KS - (c + 1) * KC) < KC ? (KS - (c + 1) * KC) : KC;
-            stream_to_lds<NW>(gw + (c + 1) * KC * STEP_BYTES, next_slot, nsteps * STEP_BYTES, wave, lane);
+            const int nsteps = (KS - (c + 1) * KCH) < KCH ? (KS - (c + 1) * KCH) : KCH;
+            stream_to_lds<NW>(gw + (c + 1) * KCH * STEP_BYTES, next_slot, nsteps * STEP_BYTES, wave, lane);
         } else {
             stream_to_lds<NW>(tail_src, next_slot, tail_bytes, wave, lane);
         }
         const char* buf = lds + par * LDSBUF + lane * (VW * 4);
+        avec a_next[NB];
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) a_next[blk] = *reinterpret_cast<const avec*>(buf + blk * (64 * VW * 4));
+        }
 #pragma unroll
         for (int ks = 0; ks < steps; ++ks) {
-            const int s = c * KC + ks;
+            const int s = c * KCH + ks;
             const float b = s < KS1 ? b1[s < KS1 ? s : 0] : b2[s >= KS1 ? s - KS1 : 0];
+            avec a_cur[NB];
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
-                if constexpr (VW == 4) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(buf + (ks * NB + blk) * (64 * 16));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[blk * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b, acc[blk * 4 + q], 0, 0, 0);
-                } else {
-                    const f32x2 a = *reinterpret_cast<const f32x2*>(buf + (ks * NB + blk) * (64 * 8));
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        acc[blk * 2 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b, acc[blk * 2 + q], 0, 0, 0);
-                }
+                if constexpr (PIPE) a_cur[blk] = a_next[blk];
+                else a_cur[blk] = *reinterpret_cast<const avec*>(buf + (ks * NB + blk) * (64 * VW * 4));
             }
+            if constexpr (PIPE) {
+                if (ks + 1 < steps) {
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk)
+                        a_next[blk] = *reinterpret_cast<const avec*>(buf + ((ks + 1) * NB + blk) * (64 * VW * 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int q = 0; q < VW; ++q)
+                    acc[blk * VW + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[blk][q], b, acc[blk * VW + q], 0, 0, 0);
         }
         __syncthreads();  // drains the DMA (vmcnt(0)) and releases slot `par` for the next fill
         par ^= 1;
@@ -146,11 +165,32 @@ __device__ __forceinline__ float group_sum(float v) {  // sum over the 4 lane gr
     return v;
 }
 
-template <int H, int FX, int FD, int NW>
+template <int H>
+__device__ __forceinline__ float alpha_gemv(const float (&in)[H / 4], const float* walpha, int g) {
+    float part = 0.0f;   // fc_alpha (models.py:71): 1-row GEMV on the VALU + lane-group reduction
+    const float* wa = walpha + g * (H / 4);
+#pragma unroll
+    for (int s = 0; s < H / 4; s += 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + s);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part = fmaf(in[s + q], w4[q], part);
+    }
+    return group_sum(part);
+}
+
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS>
 __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const int num_layers,
                                                       const int density_only) {
-    using N = Net<H, FX, FD>;
+    using N = Net<H, FX, FD, KCH>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // LBIAS: every bias of the network lives in LDS behind the ring for the whole launch (a bias fetched from
+    // L2 at the top of a layer is ~1 us of exposed latency in front of that layer's first MFMA)
+    float* lds_bias = reinterpret_cast<float*>(lds + 2 * N::LDSBUF);
+    if constexpr (LBIAS) {
+        const int nb = H * (1 + num_layers) + H / 2;
+        for (int i = threadIdx.x; i < nb; i += NW * 64) lds_bias[i] = args.bias[i];
+    }
+    const float* bias_src = LBIAS ? lds_bias : args.bias;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
@@ -166,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const 
         const bool valid = sample < args.n;
         const int64_t sidx = valid ? sample : args.n - 1;
 
-        // ---- prologue: fetch the sample, build both encodings in registers
+        // ---- prologue: fetch the sample
         float p[3], d[3];
         if (args.mode == MODE_POINTS) {
 #pragma unroll
@@ -190,74 +230,65 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const 
             p[0] = args.a[i0]; p[1] = args.b[i1]; p[2] = args.c[i2];
             d[0] = p[0]; d[1] = p[1]; d[2] = p[2];   // mesh_nerf.py:45: sample_points(samples, samples)
         }
-        float encx[N::EX], encd[N::ED];
-        encode<FX, N::EX>(encx, p, args.bands_xyz, g);
-        encode<FD, N::ED>(encd, d, args.bands_dir, g);
         const float dummy[1] = {0.0f};
+        float encx_keep[KEEP_ENC ? N::EX : 1];
+        if constexpr (KEEP_ENC) encode<FX, N::EX>(encx_keep, p, args.bands_xyz, g);
 
         f32x4 acc[N::NT];
         float in[N::KH];
         __syncthreads();  // first chunk of layer1 resident (its DMA was issued one tile earlier)
 
         // ---- layer1: xyz_enc -> H, no activation (models.py:62)
-        load_bias<N::NT>(acc, args.bias, g);
-        gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF, lds, par,
-                                                    wave, lane);
+        load_bias<N::NT>(acc, bias_src, g);
+        if constexpr (KEEP_ENC) {
+            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx_keep, dummy, gw, gw + N::EX * N::STEP,
+                                                                   N::LDSBUF, lds, par, wave, lane);
+        } else {   // the encoding registers live only for this stage; the skip layer recomputes them
+            float encx[N::EX];
+            encode<FX, N::EX>(encx, p, args.bands_xyz, g);
+            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF,
+                                                                   lds, par, wave, lane);
+        }
         gw += N::EX * N::STEP;
         acc_to_operand<N::NT, false>(acc, in);
 
-        // ---- layers_xyz[0 .. L-2], then fc_feat as iteration L-1 (models.py:63-70)
+        // ---- layers_xyz[0 .. L-2], then (full evaluation only) fc_feat as iteration L-1 (models.py:63-70)
         float sigma = 0.0f;
-        bool done = false;
+        const int trunk_iters = density_only ? num_layers - 1 : num_layers;
 #pragma unroll 1
-        for (int i = 0; i < num_layers && !done; ++i) {
+        for (int i = 0; i < trunk_iters; ++i) {
             const bool is_feat = i == num_layers - 1;
-            if (is_feat) {
-                // fc_alpha on the pre-feature activation (models.py:71): 1-row GEMV on the VALU
-                float part = 0.0f;
-                const float* wa = args.walpha + g * N::KH;
-#pragma unroll
-                for (int s = 0; s < N::KH; s += 4) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + s);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) part = fmaf(in[s + q], w4[q], part);
-                }
-                sigma = group_sum(part) + args.balpha;
-            }
+            if (is_feat) sigma = alpha_gemv<H>(in, args.walpha, g) + args.balpha;   // on the pre-feature activation
             const bool skip = !is_feat && ((args.skip_mask >> i) & 1u);
             const bool last_density = density_only && i == num_layers - 2;
-            load_bias<N::NT>(acc, args.bias + H * (1 + i), g);
+            load_bias<N::NT>(acc, bias_src + H * (1 + i), g);
             {
                 const char* tsrc = gw + N::KH * N::STEP;
                 int tbytes = N::LDSBUF;
                 if (skip) tbytes = N::L1_FIRST;               // the skip layer's encoding columns follow
                 else if (is_feat) tbytes = N::DIR_FIRST;      // view layer follows
                 else if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
-                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 gw += N::KH * N::STEP;
             }
             if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
                 const char* tsrc = gw + N::EX * N::STEP;
                 int tbytes = N::LDSBUF;
                 if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
-                gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                if constexpr (KEEP_ENC) {
+                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx_keep, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                } else {
+                    float encx[N::EX];
+                    encode<FX, N::EX>(encx, p, args.bands_xyz, g);
+                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                }
                 gw += N::EX * N::STEP;
             }
             acc_to_operand<N::NT, true>(acc, in);
-            done = last_density;
         }
 
         if (density_only) {
-            // the iteration that would compute sigma was skipped: do it here on the trunk output
-            float part = 0.0f;
-            const float* wa = args.walpha + g * N::KH;
-#pragma unroll
-            for (int s = 0; s < N::KH; s += 4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + s);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) part = fmaf(in[s + q], w4[q], part);
-            }
-            sigma = group_sum(part) + args.balpha;
+            sigma = alpha_gemv<H>(in, args.walpha, g) + args.balpha;
             if (valid && g == 0) args.out[sample] = sigma;
             gw = args.wstream;
             continue;
@@ -266,9 +297,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const 
         // ---- layers_dir[0]: cat(feat, dir_enc) -> H/2, relu (models.py:72-74)
         f32x4 accd[N::NTD];
         float v[N::KD];
-        load_bias<N::NTD>(accd, args.bias + H * (1 + num_layers), g);
-        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF>(accd, in, encd, gw, args.wstream,
-                                                         has_next ? N::L1_FIRST : 0, lds, par, wave, lane);
+        load_bias<N::NTD>(accd, bias_src + H * (1 + num_layers), g);
+        float encd[N::ED];
+        encode<FD, N::ED>(encd, d, args.bands_dir, g);
+        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE>(accd, in, encd, gw, args.wstream,
+                                                                    has_next ? N::L1_FIRST : 0, lds, par, wave, lane);
         gw = args.wstream;
         acc_to_operand<N::NTD, true>(accd, v);
 
@@ -296,45 +329,62 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const 
 
 // ---- host side: plan table + launcher ------------------------------------------------------
 struct MlpPlan {
-    int H, FX, FD, NW;
-    int lds_bytes;
+    int H, FX, FD, NW, KCH, variant;
+    int ring_bytes;
+    bool lds_bias;
     void (*kernel)(const MlpArgs, const int, const int);
 };
 
-template <int H, int FX, int FD, int NW>
-static MlpPlan make_plan() {
-    return MlpPlan{H, FX, FD, NW, 2 * Net<H, FX, FD>::LDSBUF, &mlp_kernel<H, FX, FD, NW>};
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS>
+static MlpPlan make_plan(int variant) {
+    return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
+                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS>};
 }
 
+// variant 0 is the production choice; the others exist for within-process A/B runs (scripts/bench_mlp.py,
+// NM_MLP_VARIANT=<n>) and are only instantiated for the headline 8x256 network.
 static const MlpPlan g_plans[] = {
-    make_plan<256, 10, 4, 8>(),
-    make_plan<128, 10, 4, 8>(),
-    make_plan<64, 10, 4, 8>(),
-    make_plan<256, 6, 4, 8>(),
-    make_plan<128, 6, 4, 8>(),
-    make_plan<64, 6, 4, 8>(),
+    make_plan<256, 10, 4, 8, 8, true, true, true>(0),
+    make_plan<128, 10, 4, 8, 8, true, true, true>(0),
+    make_plan<64, 10, 4, 8, 8, true, true, true>(0),
+    make_plan<256, 6, 4, 8, 8, true, true, true>(0),
+    make_plan<128, 6, 4, 8, 8, true, true, true>(0),
+    make_plan<64, 6, 4, 8, 8, true, true, true>(0),
+    // measured on MI355X, 2^23 points, 8x256 (profiles/r01_mlp_variants.json): v0 141.1 TFLOP/s
+    make_plan<256, 10, 4, 8, 16, true, true, true>(1),     // 16-k-step chunks: 137.6
+    make_plan<256, 10, 4, 8, 8, false, true, false>(2),    // round-1 first version (no prefetch, L2 biases): 133.7
+    make_plan<256, 10, 4, 8, 8, true, false, true>(3),     // encodings recomputed at the skip layer: ~135
+    make_plan<256, 10, 4, 8, 8, true, true, false>(4),     // prefetch only, biases from L2: 138.3
 };
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
+    int want = 0;
+    if (const char* v = getenv("NM_MLP_VARIANT")) want = atoi(v);
+    const MlpPlan* fallback = nullptr;
     for (const MlpPlan& p : g_plans)
-        if (p.H == H && p.FX == FX && p.FD == FD) return &p;
-    return nullptr;
+        if (p.H == H && p.FX == FX && p.FD == FD) {
+            if (p.variant == want) return &p;
+            if (p.variant == 0) fallback = &p;
+        }
+    return fallback;
 }
 
 int mlp_plan_info(const MlpPlan* p, int* nw) {
     *nw = p->NW;
-    return 0;
+    return p->variant;
 }
 
 int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream) {
     const MlpPlan* p = m->plan;
     if (args.n <= 0) return 0;
-    static bool attr_done[sizeof(g_plans) / sizeof(g_plans[0])] = {};
+    const int L = m->desc.num_layers, H = m->desc.hidden_size;
+    const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2) * 4 + 255) & ~255) : 0);
+    NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
+    static int attr_bytes[sizeof(g_plans) / sizeof(g_plans[0])] = {};
     const int idx = (int)(p - g_plans);
-    if (!attr_done[idx]) {
-        NM_HIP_CHECK(hipFuncSetAttribute((const void*)p->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         p->lds_bytes));
-        attr_done[idx] = true;
+    if (attr_bytes[idx] < lds_bytes) {
+        NM_HIP_CHECK(hipFuncSetAttribute((const void*)p->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_bytes[idx] = lds_bytes;
     }
     const int64_t wg_iters = (args.n + p->NW * 16 - 1) / (p->NW * 16);
     const int64_t resident = (int64_t)m->num_cus * 1;
@@ -345,7 +395,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
         const int64_t rounds = (wg_iters + grid - 1) / grid;
         grid = (wg_iters + rounds - 1) / rounds;
     }
-    hipLaunchKernelGGL(p->kernel, dim3((unsigned)grid), dim3(p->NW * 64), p->lds_bytes, stream, args,
+    hipLaunchKernelGGL(p->kernel, dim3((unsigned)grid), dim3(p->NW * 64), lds_bytes, stream, args,
                        (int)m->desc.num_layers, density_only);
     NM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -86,6 +86,10 @@ class HipMLP:
     def handle(self):
         return self._h
 
+    def kernel_variant(self):
+        nw = C.c_int()
+        return int(self._lib.nm_mlp_kernel_variant(self._h, C.byref(nw))), nw.value
+
     def flops_per_sample(self, density_only=False):
         return int(self._lib.nm_mlp_flops_per_sample(self._h, int(density_only)))
 
