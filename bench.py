@@ -86,7 +86,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("NM_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path on a 1-GPU box
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -105,18 +106,19 @@ def main():
         o, d = hip_ops.ray_bundle(poses[s * world + rank], H, W, S.LEGO_FOCAL_800, device=dev)
         views.append((o[None].contiguous(), d))
     image = torch.empty(H * W, 3, device=dev)
-    gathered = torch.empty(world * H * W, 3, device=dev) if world > 1 else None
+    use_dist = dist is not None
+    gathered = torch.empty(world * H * W, 3, device=dev) if use_dist else None
 
     def step(i):
         o, d = views[i]
         for s in range(0, H * W, args.chunk):
             _, fb = hip_ops.render_rays(coarse, fine, o, d[s:s + args.chunk], near, far, u_c, u_f)
             image[s:s + args.chunk] = fb["rgb_map"]
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, image)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +134,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launches, kernel_ms, kernel_flops = hip_ops.mlp_profile_read()
     hip_ops.mlp_profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -186,7 +188,7 @@ def main():
                          "rays": n}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
