@@ -179,7 +179,7 @@ __device__ __forceinline__ float alpha_gemv(const float (&in)[H / 4], const floa
 }
 
 template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS>
-__global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpArgs args, const int num_layers,
+__global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, const int num_layers,
                                                       const int density_only) {
     using N = Net<H, FX, FD, KCH>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -355,6 +355,8 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 8, 8, false, true, false>(2),    // round-1 first version (no prefetch, L2 biases): 133.7
     make_plan<256, 10, 4, 8, 8, true, false, true>(3),     // encodings recomputed at the skip layer: ~135
     make_plan<256, 10, 4, 8, 8, true, true, false>(4),     // prefetch only, biases from L2: 138.3
+    make_plan<256, 10, 4, 4, 8, true, true, true>(5),      // 4-wave workgroups, two per CU (decoupled barriers)
+    make_plan<256, 10, 4, 4, 16, true, true, true>(6),
 };
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
@@ -387,7 +389,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
         attr_bytes[idx] = lds_bytes;
     }
     const int64_t wg_iters = (args.n + p->NW * 16 - 1) / (p->NW * 16);
-    const int64_t resident = (int64_t)m->num_cus * 1;
+    const int64_t resident = (int64_t)m->num_cus * (8 / p->NW);   // workgroups co-resident per CU (2 waves / SIMD)
     // persistent-style launch: a few workgroups per CU queue so the tail is balanced.
     int64_t grid = wg_iters < resident * 4 ? wg_iters : resident * 4;
     // keep the per-workgroup iteration count even across the grid where possible

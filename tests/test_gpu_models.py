@@ -180,3 +180,31 @@ def test_mesh_pipeline_vs_oracle(pkg, tmp_path):
             assert sum(l.startswith("f ") for l in lines) == ff.shape[0]
             a = [int(t.split("//")[0]) for t in next(l for l in lines if l.startswith("f ")).split()[1:]]
             assert a == [int(x) + 1 for x in ff[0].tolist()]
+
+
+def test_eval_nerf_loop_matches_oracle_bookkeeping(pkg):
+    """eval_nerf mirror: per-view loss with the reference's float batch_count quirk (eval_nerf.py:57,76),
+    dataset loss = mean over views, PSNR = -10 log10; rendered through model.query in ragged chunks."""
+    from nerfmeshes_amd import eval_nerf as ev
+    hp = S.hparams(chunksize=1500)
+    m = pkg["models"].NeRFModel(hp)
+    w = S.make_scene_weights()
+    _load(m, "model_coarse.", w)
+    _load(m, "model_fine.", w)
+    m = m.eval().to("cuda")
+    views = list(ev.synthetic_views(2, height=40, width=52, focal=70.0))
+    with torch.no_grad():
+        losses, total, psnr, rgb = ev.eval_nerf(m, views, m.cfg, "cuda")
+    assert len(losses) == 2 and rgb.shape == (40 * 52, 3)
+    spec, rs = O.MLPSpec(), O.RenderSpec()
+    ref_losses = []
+    for pose, h, wd, f, tgt in views:
+        o, d = O.get_ray_bundle(h, wd, f, pose)
+        _, fb = O.render(w, w, spec, spec, rs, o[None], d.reshape(-1, 3), 2.0, 6.0)
+        ref_losses.append(O.view_loss(fb["rgb_map"], tgt, 1500))
+    ref_total = O.dataset_loss(ref_losses)
+    assert abs(float(total) - float(ref_total)) < 1e-5
+    assert abs(float(psnr) - float(O.mse2psnr(ref_total))) < 1e-3
+    # the quirk is really there: 2080 rays / 1500 = 1.387 "batches" although 2 chunks ran
+    plain = torch.nn.functional.mse_loss(rgb.cpu(), views[-1][4])
+    assert abs(float(losses[-1]) - float(plain)) > 1e-3
