@@ -12,7 +12,7 @@
 //                 the edge position ("no earlier cube contains it").
 //   2. scan       exclusive prefix sums of (created vertices, triangles) over cubes in scan order
 //                 (block sums -> single-block scan of the sums; the intra-block scan is redone in LDS by the
-//                 emit kernels, so no per-cube offsets are stored).
+//                 emit kernels, so no per-cube offsets are stored -- per-cube state is ONE byte).
 //   3. vertices   each cube walks its tiling; every first use of an owned edge (or of the centre vertex,
 //                 edge id 12) creates vertex base+k: position (fp64 inverse-|v| interpolation rounded to
 //                 fp32, as skimage), its index goes into an edge->vertex table (one int32 volume per axis).
@@ -29,7 +29,7 @@ namespace nm {
 
 constexpr double SK_EPS = 2.220446049250313e-16;   // skimage's "FLT_EPSILON" is np.spacing(1.0)
 constexpr int MC_BLOCK = 256;
-constexpr int MC_ITEMS = 4;                          // cubes per thread in scan-partitioned kernels
+constexpr int MC_ITEMS = 4;                          // CONSECUTIVE cubes per thread (their 4 code bytes = one dword)
 constexpr int MC_TILE = MC_BLOCK * MC_ITEMS;
 
 struct McDims {
@@ -239,115 +239,137 @@ __device__ __forceinline__ int count_created(int offset, int nt, int z, int y, i
     return n;
 }
 
-// code word per cube: [14:0] tiling offset, [18:15] triangles, [22:19] created vertices
-__device__ __forceinline__ uint32_t pack_code(int offset, int nt, int ncreated) {
-    return (uint32_t)offset | ((uint32_t)nt << 15) | ((uint32_t)ncreated << 19);
-}
-__device__ __forceinline__ int code_offset(uint32_t c) { return c & 0x7fff; }
-__device__ __forceinline__ int code_nt(uint32_t c) { return (c >> 15) & 0xf; }
-__device__ __forceinline__ int code_created(uint32_t c) { return (c >> 19) & 0xf; }
+// code byte per cube: low nibble = triangles (<= 12), high nibble = vertices this cube creates (<= 13).
+// The tiling row itself is NOT stored: the ~1 % of cubes that are active re-derive it in the emit passes,
+// which keeps the per-cube state at 1 B instead of 4 B (the volume itself is 4 B / voxel).
+__device__ __forceinline__ uint32_t pack_code(int nt, int ncreated) { return (uint32_t)nt | ((uint32_t)ncreated << 4); }
+__device__ __forceinline__ int code_nt(uint32_t c) { return c & 0xf; }
+__device__ __forceinline__ int code_created(uint32_t c) { return (c >> 4) & 0xf; }
 
+// (z, y, x) of cube `id`; 32-bit arithmetic whenever the cube count allows (64-bit division is emulated)
 __device__ __forceinline__ void cube_coords(const McDims& d, int64_t id, int& z, int& y, int& x) {
-    const int64_t plane = (int64_t)d.c1 * d.c2;
-    z = (int)(id / plane);
-    const int64_t r = id - (int64_t)z * plane;
-    y = (int)(r / d.c2);
-    x = (int)(r - (int64_t)y * d.c2);
+    if (d.cubes < (int64_t(1) << 31)) {
+        const uint32_t plane = (uint32_t)d.c1 * (uint32_t)d.c2, i = (uint32_t)id;
+        const uint32_t zz = i / plane, r = i - zz * plane, yy = r / (uint32_t)d.c2;
+        z = (int)zz; y = (int)yy; x = (int)(r - yy * (uint32_t)d.c2);
+    } else {
+        const int64_t plane = (int64_t)d.c1 * d.c2;
+        z = (int)(id / plane);
+        const int64_t r = id - (int64_t)z * plane;
+        y = (int)(r / d.c2);
+        x = (int)(r - (int64_t)y * d.c2);
+    }
+}
+
+__device__ __forceinline__ void next_cube(const McDims& d, int& z, int& y, int& x) {
+    if (++x == d.c2) { x = 0; if (++y == d.c1) { y = 0; ++z; } }
+}
+
+// corner sign pattern without forming the differences: (double)v - iso > 0  <=>  (double)v > iso
+__device__ __forceinline__ int cube_index(const float* __restrict__ vol, const McDims& d, int z, int y, int x, double iso) {
+    const int64_t s1 = d.n2, s0 = (int64_t)d.n1 * d.n2;
+    const float* p = vol + (int64_t)z * s0 + (int64_t)y * s1 + x;
+    int index = 0;
+    index |= ((double)p[0] > iso) ? 1 : 0;            index |= ((double)p[1] > iso) ? 2 : 0;
+    index |= ((double)p[s1 + 1] > iso) ? 4 : 0;       index |= ((double)p[s1] > iso) ? 8 : 0;
+    index |= ((double)p[s0] > iso) ? 16 : 0;          index |= ((double)p[s0 + 1] > iso) ? 32 : 0;
+    index |= ((double)p[s0 + s1 + 1] > iso) ? 64 : 0; index |= ((double)p[s0 + s1] > iso) ? 128 : 0;
+    return index;
+}
+
+__device__ __forceinline__ int index_of(const Cube& c) {
+    int index = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) index |= (c.v[k] > 0.0) ? (1 << k) : 0;
+    return index;
 }
 
 // ---- pass 1: classify ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(MC_BLOCK) void mc_classify(const float* __restrict__ vol, McDims d, double iso,
-                                                        uint32_t* __restrict__ codes, uint2* __restrict__ tile_sums) {
+                                                        uint32_t* __restrict__ codes4, uint2* __restrict__ tile_sums) {
     __shared__ uint32_t s_v[MC_BLOCK / 64], s_t[MC_BLOCK / 64];
-    uint32_t nv = 0, ntri = 0;
-    const int64_t base = (int64_t)blockIdx.x * MC_TILE;
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        const int64_t id = base + it * MC_BLOCK + threadIdx.x;   // coalesced along x within a tile
-        if (id >= d.cubes) continue;
+    uint32_t nv = 0, ntri = 0, word = 0;
+    const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
+    if (first < d.cubes) {
         int z, y, x;
-        cube_coords(d, id, z, y, x);
-        Cube c;
-        load_cube(vol, d, z, y, x, iso, c);
-        int index = 0;
+        cube_coords(d, first, z, y, x);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) index |= (c.v[k] > 0.0) ? (1 << k) : 0;
-        uint32_t code = 0;
-        if (index != 0 && index != 255) {
-            int off, nt;
-            select_tiling(c, index, off, nt);
-            const int created = count_created(off, nt, z, y, x);
-            code = pack_code(off, nt, created);
-            nv += created; ntri += nt;
+        for (int it = 0; it < MC_ITEMS; ++it) {
+            if (first + it < d.cubes) {
+                const int index = cube_index(vol, d, z, y, x, iso);
+                if (index != 0 && index != 255) {
+                    Cube c;
+                    load_cube(vol, d, z, y, x, iso, c);
+                    int off, nt;
+                    select_tiling(c, index, off, nt);
+                    const int created = count_created(off, nt, z, y, x);
+                    word |= pack_code(nt, created) << (8 * it);
+                    nv += created; ntri += nt;
+                }
+                next_cube(d, z, y, x);
+            }
         }
-        codes[id] = code;
     }
-    // block reduction of the two counters
+    const int64_t w = (int64_t)blockIdx.x * MC_BLOCK + threadIdx.x;     // code dword of this thread
+    if (w * MC_ITEMS < ((d.cubes + 3) & ~int64_t(3))) codes4[w] = word;
     for (int o = 32; o > 0; o >>= 1) { nv += __shfl_xor(nv, o); ntri += __shfl_xor(ntri, o); }
     if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = nv; s_t[threadIdx.x >> 6] = ntri; }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t a = 0, b = 0;
-        for (int w = 0; w < MC_BLOCK / 64; ++w) { a += s_v[w]; b += s_t[w]; }
+        for (int q = 0; q < MC_BLOCK / 64; ++q) { a += s_v[q]; b += s_t[q]; }
         tile_sums[blockIdx.x] = make_uint2(a, b);
     }
 }
 
-// ---- pass 2: exclusive scan of the per-tile sums (single block; <= ~27k tiles at 480^3) -------------
+// ---- pass 2: exclusive scan of the per-tile sums (one block; every thread owns a contiguous run) ------
 __global__ __launch_bounds__(1024) void mc_scan_tiles(uint2* __restrict__ tile_sums, int64_t tiles,
                                                       uint32_t* __restrict__ totals) {
     __shared__ uint32_t s_a[1024], s_b[1024];
-    __shared__ uint32_t carry_a, carry_b;
-    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    const int64_t per = (tiles + 1023) / 1024;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < tiles ? lo + per : tiles;
+    uint32_t a = 0, b = 0;
+    for (int64_t i = lo; i < hi; ++i) { const uint2 v = tile_sums[i]; a += v.x; b += v.y; }
+    s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
     __syncthreads();
-    for (int64_t start = 0; start < tiles; start += 1024) {
-        const int64_t i = start + threadIdx.x;
-        const uint2 v = i < tiles ? tile_sums[i] : make_uint2(0, 0);
-        s_a[threadIdx.x] = v.x; s_b[threadIdx.x] = v.y;
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan of the 1024 run totals
+        uint32_t pa = 0, pb = 0;
+        if ((int)threadIdx.x >= o) { pa = s_a[threadIdx.x - o]; pb = s_b[threadIdx.x - o]; }
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
-            uint32_t a = 0, b = 0;
-            if ((int)threadIdx.x >= o) { a = s_a[threadIdx.x - o]; b = s_b[threadIdx.x - o]; }
-            __syncthreads();
-            s_a[threadIdx.x] += a; s_b[threadIdx.x] += b;
-            __syncthreads();
-        }
-        if (i < tiles) tile_sums[i] = make_uint2(carry_a + s_a[threadIdx.x] - v.x, carry_b + s_b[threadIdx.x] - v.y);
-        __syncthreads();
-        if (threadIdx.x == 1023) { carry_a += s_a[1023]; carry_b += s_b[1023]; }
+        s_a[threadIdx.x] += pa; s_b[threadIdx.x] += pb;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { totals[0] = carry_a; totals[1] = carry_b; }
+    uint32_t ra = s_a[threadIdx.x] - a, rb = s_b[threadIdx.x] - b;   // exclusive prefix of this run
+    for (int64_t i = lo; i < hi; ++i) {
+        const uint2 v = tile_sums[i];
+        tile_sums[i] = make_uint2(ra, rb);
+        ra += v.x; rb += v.y;
+    }
+    if (threadIdx.x == 1023) { totals[0] = s_a[1023]; totals[1] = s_b[1023]; }
 }
 
-// exclusive (vertex, triangle) offsets of this thread's MC_ITEMS cubes inside the tile + tile prefix.
-// Cube order inside a tile: id = base + it*MC_BLOCK + tid, so the scan runs over `it` outermost.
-__device__ __forceinline__ void tile_offsets(const uint32_t (&codes)[MC_ITEMS], uint2 tile_prefix, uint32_t (&vbase)[MC_ITEMS],
+// exclusive (vertex, triangle) offsets of this thread's MC_ITEMS consecutive cubes: tile prefix + block scan.
+__device__ __forceinline__ void tile_offsets(uint32_t word, uint2 tile_prefix, uint32_t (&vbase)[MC_ITEMS],
                                              uint32_t (&tbase)[MC_ITEMS]) {
-    __shared__ uint32_t s_wv[MC_ITEMS][MC_BLOCK / 64], s_wt[MC_ITEMS][MC_BLOCK / 64];
+    __shared__ uint32_t s_wv[MC_BLOCK / 64], s_wt[MC_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc_v[MC_ITEMS], inc_t[MC_ITEMS];
+    uint32_t tv = 0, tt = 0;
 #pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        uint32_t v = code_created(codes[it]), t = code_nt(codes[it]);
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t pv = __shfl_up(v, o), pt = __shfl_up(t, o);
-            if (lane >= o) { v += pv; t += pt; }
-        }
-        inc_v[it] = v; inc_t[it] = t;
-        if (lane == 63) { s_wv[it][wave] = v; s_wt[it][wave] = t; }
+    for (int it = 0; it < MC_ITEMS; ++it) { tv += code_created(word >> (8 * it)); tt += code_nt(word >> (8 * it)); }
+    uint32_t v = tv, t = tt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t pv = __shfl_up(v, o), pt = __shfl_up(t, o);
+        if (lane >= o) { v += pv; t += pt; }
     }
+    if (lane == 63) { s_wv[wave] = v; s_wt[wave] = t; }
     __syncthreads();
-    uint32_t run_v = tile_prefix.x, run_t = tile_prefix.y;
+    uint32_t pre_v = tile_prefix.x + v - tv, pre_t = tile_prefix.y + t - tt;
+    for (int q = 0; q < MC_BLOCK / 64; ++q)
+        if (q < wave) { pre_v += s_wv[q]; pre_t += s_wt[q]; }
 #pragma unroll
     for (int it = 0; it < MC_ITEMS; ++it) {
-        uint32_t pre_v = run_v, pre_t = run_t;
-        for (int w = 0; w < MC_BLOCK / 64; ++w) {
-            if (w < wave) { pre_v += s_wv[it][w]; pre_t += s_wt[it][w]; }
-            run_v += s_wv[it][w]; run_t += s_wt[it][w];
-        }
-        vbase[it] = pre_v + inc_v[it] - code_created(codes[it]);
-        tbase[it] = pre_t + inc_t[it] - code_nt(codes[it]);
+        vbase[it] = pre_v; tbase[it] = pre_t;
+        pre_v += code_created(word >> (8 * it)); pre_t += code_nt(word >> (8 * it));
     }
 }
 
@@ -362,114 +384,114 @@ struct McOut {
 
 // ---- pass 3: create vertices -------------------------------------------------------------------------------
 __global__ __launch_bounds__(MC_BLOCK) void mc_emit_vertices(const float* __restrict__ vol, McDims d, double iso,
-                                                             const uint32_t* __restrict__ codes,
+                                                             const uint32_t* __restrict__ codes4,
                                                              const uint2* __restrict__ tile_prefix, McOut out,
                                                              int64_t* __restrict__ vertex_cube, int8_t* __restrict__ vertex_edge) {
-    uint32_t code[MC_ITEMS], vbase[MC_ITEMS], tbase[MC_ITEMS];
-    const int64_t base = (int64_t)blockIdx.x * MC_TILE;
+    uint32_t vbase[MC_ITEMS], tbase[MC_ITEMS];
+    const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
+    const uint32_t word = first < d.cubes ? codes4[(int64_t)blockIdx.x * MC_BLOCK + threadIdx.x] : 0u;
+    tile_offsets(word, tile_prefix[blockIdx.x], vbase, tbase);
+    if ((word & 0xf0f0f0f0u) == 0) return;            // none of this thread's cubes creates a vertex
+    int z, y, x;
+    cube_coords(d, first, z, y, x);
 #pragma unroll
     for (int it = 0; it < MC_ITEMS; ++it) {
-        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
-        code[it] = id < d.cubes ? codes[id] : 0u;
-    }
-    tile_offsets(code, tile_prefix[blockIdx.x], vbase, tbase);
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        if (code_created(code[it]) == 0) continue;
-        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
-        int z, y, x;
-        cube_coords(d, id, z, y, x);
-        Cube c;
-        load_cube(vol, d, z, y, x, iso, c);
-        const int off = code_offset(code[it]), nt = code_nt(code[it]);
-        unsigned seen = 0;
-        uint32_t next = vbase[it];
-        for (int i = 0; i < 3 * nt; ++i) {
-            const int e = lut(off + i);
-            if (seen & (1u << e)) continue;
-            seen |= 1u << e;
-            if (!owns_edge(e, z, y, x)) continue;
-            double px, py, pz;
-            if (e == 12) {
-                double fx = 0, fy = 0, fz = 0, ff = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double w = 1.0 / (SK_EPS + fabs(c.v[k]));
-                    const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
-                    fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
-                }
-                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
-            } else {
-                const signed char* a = MC_EDGE_A[e];
-                const signed char* b = MC_EDGE_B[e];
-                // skimage: endpoints 1 and 2 are EDGESREL*[e][0] / [1] = our A / B
-                const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
-                const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
-                const double w1 = 1.0 / (SK_EPS + fabs(c.v[ka])), w2 = 1.0 / (SK_EPS + fabs(c.v[kb]));
-                double fx = 0, fy = 0, fz = 0, ff = 0;
-                fx += (double)a[2] * w1; fy += (double)a[1] * w1; fz += (double)a[0] * w1; ff += w1;
-                fx += (double)b[2] * w2; fy += (double)b[1] * w2; fz += (double)b[0] * w2; ff += w2;
-                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
-                const signed char* lo = MC_EDGE_LO[e];
-                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
-                out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
-            }
-            // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
-            out.verts[3 * (int64_t)next] = (float)pz;
-            out.verts[3 * (int64_t)next + 1] = (float)py;
-            out.verts[3 * (int64_t)next + 2] = (float)px;
-            vertex_cube[next] = id;
-            vertex_edge[next] = (int8_t)e;
-            ++next;
-        }
-    }
-}
-
-// ---- pass 4: faces -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MC_BLOCK) void mc_emit_faces(McDims d, const uint32_t* __restrict__ codes,
-                                                          const uint2* __restrict__ tile_prefix, McOut out) {
-    uint32_t code[MC_ITEMS], vbase[MC_ITEMS], tbase[MC_ITEMS];
-    const int64_t base = (int64_t)blockIdx.x * MC_TILE;
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
-        code[it] = id < d.cubes ? codes[id] : 0u;
-    }
-    tile_offsets(code, tile_prefix[blockIdx.x], vbase, tbase);
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        const int nt = code_nt(code[it]);
-        if (nt == 0) continue;
-        const int64_t id = base + it * MC_BLOCK + threadIdx.x;
-        int z, y, x;
-        cube_coords(d, id, z, y, x);
-        const int off = code_offset(code[it]);
-        // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
-        int centre = -1;
-        {
+        if (code_created(word >> (8 * it)) != 0) {
+            const int64_t id = first + it;
+            Cube c;
+            load_cube(vol, d, z, y, x, iso, c);
+            int off, nt;
+            select_tiling(c, index_of(c), off, nt);
             unsigned seen = 0;
-            int k = 0;
+            uint32_t next = vbase[it];
             for (int i = 0; i < 3 * nt; ++i) {
                 const int e = lut(off + i);
                 if (seen & (1u << e)) continue;
                 seen |= 1u << e;
-                if (e == 12) { centre = (int)vbase[it] + k; break; }
-                k += owns_edge(e, z, y, x) ? 1 : 0;
-            }
-        }
-        for (int t = 0; t < nt; ++t) {
-            int idx[3];
+                if (!owns_edge(e, z, y, x)) continue;
+                double px, py, pz;
+                if (e == 12) {
+                    double fx = 0, fy = 0, fz = 0, ff = 0;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = lut(off + 3 * t + j);
-                if (e == 12) { idx[j] = centre; continue; }
-                const signed char* lo = MC_EDGE_LO[e];
-                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
-                idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
+                    for (int k = 0; k < 8; ++k) {
+                        const double w = 1.0 / (SK_EPS + fabs(c.v[k]));
+                        const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
+                        fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
+                    }
+                    px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+                } else {
+                    const signed char* a = MC_EDGE_A[e];
+                    const signed char* b = MC_EDGE_B[e];
+                    const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
+                    const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
+                    const double w1 = 1.0 / (SK_EPS + fabs(c.v[ka])), w2 = 1.0 / (SK_EPS + fabs(c.v[kb]));
+                    double fx = 0, fy = 0, fz = 0, ff = 0;
+                    fx += (double)a[2] * w1; fy += (double)a[1] * w1; fz += (double)a[0] * w1; ff += w1;
+                    fx += (double)b[2] * w2; fy += (double)b[1] * w2; fz += (double)b[0] * w2; ff += w2;
+                    px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+                    const signed char* lo = MC_EDGE_LO[e];
+                    const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
+                    out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
+                }
+                // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
+                out.verts[3 * (int64_t)next] = (float)pz;
+                out.verts[3 * (int64_t)next + 1] = (float)py;
+                out.verts[3 * (int64_t)next + 2] = (float)px;
+                vertex_cube[next] = id;
+                vertex_edge[next] = (int8_t)e;
+                ++next;
             }
-            int32_t* f = out.faces + 3 * ((int64_t)tbase[it] + t);
-            f[0] = idx[2]; f[1] = idx[1]; f[2] = idx[0];   // gradient_direction='descent' reverses each triple
         }
+        next_cube(d, z, y, x);
+    }
+}
+
+// ---- pass 4: faces -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MC_BLOCK) void mc_emit_faces(const float* __restrict__ vol, McDims d, double iso,
+                                                          const uint32_t* __restrict__ codes4,
+                                                          const uint2* __restrict__ tile_prefix, McOut out) {
+    uint32_t vbase[MC_ITEMS], tbase[MC_ITEMS];
+    const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
+    const uint32_t word = first < d.cubes ? codes4[(int64_t)blockIdx.x * MC_BLOCK + threadIdx.x] : 0u;
+    tile_offsets(word, tile_prefix[blockIdx.x], vbase, tbase);
+    if (word == 0) return;
+    int z, y, x;
+    cube_coords(d, first, z, y, x);
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        if (code_nt(word >> (8 * it)) != 0) {
+            Cube c;
+            load_cube(vol, d, z, y, x, iso, c);
+            int off, nt;
+            select_tiling(c, index_of(c), off, nt);
+            // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
+            int centre = -1;
+            {
+                unsigned seen = 0;
+                int k = 0;
+                for (int i = 0; i < 3 * nt; ++i) {
+                    const int e = lut(off + i);
+                    if (seen & (1u << e)) continue;
+                    seen |= 1u << e;
+                    if (e == 12) { centre = (int)vbase[it] + k; break; }
+                    k += owns_edge(e, z, y, x) ? 1 : 0;
+                }
+            }
+            for (int t = 0; t < nt; ++t) {
+                int idx[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int e = lut(off + 3 * t + j);
+                    if (e == 12) { idx[j] = centre; continue; }
+                    const signed char* lo = MC_EDGE_LO[e];
+                    const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
+                    idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
+                }
+                int32_t* f = out.faces + 3 * ((int64_t)tbase[it] + t);
+                f[0] = idx[2]; f[1] = idx[1]; f[2] = idx[0];   // gradient_direction='descent' reverses each triple
+            }
+        }
+        next_cube(d, z, y, x);
     }
 }
 
@@ -494,7 +516,6 @@ __device__ __constant__ signed char MC_SHARE[3][4][4] = {
     {{0, -1, -1, 10}, {0, -1, 0, 11}, {0, 0, -1, 9}, {0, 0, 0, 8}}};  // z edge
 
 __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restrict__ vol, McDims d, double iso,
-                                                            const uint32_t* __restrict__ codes,
                                                             const int64_t* __restrict__ vertex_cube,
                                                             const int8_t* __restrict__ vertex_edge, int64_t nverts,
                                                             McOut out) {
@@ -519,11 +540,11 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
             z = lz + s[0]; y = ly + s[1]; x = lx + s[2]; e = s[3];
             if (z < 0 || y < 0 || x < 0 || z >= d.c0 || y >= d.c1 || x >= d.c2) continue;
         }
-        const uint32_t code = codes[((int64_t)z * d.c1 + y) * d.c2 + x];
-        const int nt = code_nt(code), off = code_offset(code);
-        if (nt == 0) continue;
         Cube c;
         load_cube(vol, d, z, y, x, iso, c);
+        int off, nt;
+        select_tiling(c, index_of(c), off, nt);
+        if (nt == 0) continue;
         // vmax of the cube = max(v,0) - min(v,0)
         double lo = 0.0, hi = 0.0;
 #pragma unroll
@@ -585,7 +606,7 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
     char* p;
-    p = take((size_t)d.cubes * 4); if (ws) ws->codes = (uint32_t*)p;
+    p = take((((size_t)d.cubes + 3) & ~size_t(3)) + 4096); if (ws) ws->codes = (uint32_t*)p;
     p = take((size_t)tiles * 8); if (ws) ws->tile_sums = (uint2*)p;
     p = take(256); if (ws) ws->totals = (uint32_t*)p;
     for (int a = 0; a < 3; ++a) { p = take(vox * 4); if (ws) ws->edge[a] = (int32_t*)p; }
@@ -644,9 +665,10 @@ int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double
     out.vertex_home = nullptr;
     hipLaunchKernelGGL(mc_emit_vertices, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
                        ws.tile_sums, out, ws.vertex_cube, ws.vertex_edge);
-    hipLaunchKernelGGL(mc_emit_faces, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d, ws.codes, ws.tile_sums, out);
+    hipLaunchKernelGGL(mc_emit_faces, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
+                       ws.tile_sums, out);
     hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((vertices + 255) / 256)), dim3(256), 0, stream, d_volume, d, iso,
-                       ws.codes, ws.vertex_cube, ws.vertex_edge, vertices, out);
+                       ws.vertex_cube, ws.vertex_edge, vertices, out);
     NM_HIP_CHECK(hipGetLastError());
     (void)faces;
     return 0;
