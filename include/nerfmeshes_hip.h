@@ -171,12 +171,12 @@ int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origin
  *   nm_mc_count  classifies every cube and returns V and F (synchronises the stream);
  *   nm_mc_emit   writes the four arrays (caller-allocated from those counts).
  * d_workspace (nm_mc_workspace_bytes) must be kept between the two calls; d_vertex_scratch
- * (nm_mc_vertex_scratch_bytes(V)) is only used by nm_mc_emit.  V == 0 is skimage's
+ * (nm_mc_vertex_scratch_bytes(V, F)) is only used by nm_mc_emit.  V == 0 is skimage's
  * RuntimeError('No surface found at the given iso value.'); the level-in-range ValueError is the
  * host wrapper's check, as in skimage's Python wrapper.
  * ------------------------------------------------------------------------------------------ */
 int64_t nm_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2);
-int64_t nm_mc_vertex_scratch_bytes(int64_t vertices);
+int64_t nm_mc_vertex_scratch_bytes(int64_t vertices, int64_t faces);
 int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
                 int64_t* h_vertices, int64_t* h_faces, void* stream);
 int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,

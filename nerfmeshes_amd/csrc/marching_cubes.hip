@@ -10,13 +10,16 @@
 //                 An edge vertex is created by the first cube in scan order that contains the edge; every
 //                 tiling of a cube uses exactly its sign-changing edges, so ownership is a pure function of
 //                 the edge position ("no earlier cube contains it").
-//   2. scan       exclusive prefix sums of (created vertices, triangles) over cubes in scan order
-//                 (block sums -> single-block scan of the sums; the intra-block scan is redone in LDS by the
-//                 emit kernels, so no per-cube offsets are stored -- per-cube state is ONE byte).
-//   3. vertices   each cube walks its tiling; every first use of an owned edge (or of the centre vertex,
-//                 edge id 12) creates vertex base+k: position (fp64 inverse-|v| interpolation rounded to
-//                 fp32, as skimage), its index goes into an edge->vertex table (one int32 volume per axis).
-//   4. faces      each cube walks its tiling again and looks the indices up; triples are reversed ('descent').
+//                 Sign patterns are computed by every lane (phase A); the ~1 % of cubes the surface cuts go
+//                 through an LDS queue so the MC33 tests run densely (phase B).  Per-cube state: ONE byte.
+//   2. scan       exclusive prefix sums of (created vertices, triangles, active cubes) over 1024-cube tiles in
+//                 scan order (1024-tile groups scanned in parallel, then the group totals).
+//   3. compact    active cubes -> list (cube id, vertex base, triangle base), still in scan order.
+//   4. vertices   one thread per ACTIVE cube walks its tiling; every first use of an owned edge (or of the
+//                 centre vertex, edge id 12) creates vertex base+k: position (fp64 inverse-|v| interpolation
+//                 rounded to fp32, as skimage), index stored in an edge->vertex table (int32 volume per axis).
+//      faces      one thread per active cube walks its tiling again and looks the indices up; triples are
+//                 reversed ('descent').
 //   5. normals    one thread per vertex: re-plays, in scan order, the <= 4 cubes sharing its edge and
 //                 accumulates their gradient contributions in fp32 in exactly skimage's order, takes the
 //                 max of the cubes' value ranges, normalises in fp64.
@@ -286,91 +289,136 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 
 // ---- pass 1: classify ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(MC_BLOCK) void mc_classify(const float* __restrict__ vol, McDims d, double iso,
-                                                        uint32_t* __restrict__ codes4, uint2* __restrict__ tile_sums) {
-    __shared__ uint32_t s_v[MC_BLOCK / 64], s_t[MC_BLOCK / 64];
-    uint32_t nv = 0, ntri = 0, word = 0;
-    const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
+                                                        uint32_t* __restrict__ codes4, uint4* __restrict__ tile_sums) {
+    __shared__ uint32_t s_v[MC_BLOCK / 64], s_t[MC_BLOCK / 64], s_a[MC_BLOCK / 64];
+    __shared__ uint32_t s_code[MC_BLOCK];            // the tile's 1024 code bytes
+    __shared__ uint32_t s_queue[MC_TILE];            // active cubes of the tile: local id | corner pattern << 16
+    __shared__ uint32_t s_count;
+    uint32_t nv = 0, ntri = 0, nact = 0;
+    const int64_t tile_base = (int64_t)blockIdx.x * MC_TILE;
+    const int64_t first = tile_base + (int64_t)threadIdx.x * MC_ITEMS;
+    s_code[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    // ---- phase A (uniform, every lane busy): corner sign patterns; surface cubes go to an LDS queue.
+    // Only ~1 % of the cubes are cut by the surface, but 84 % of the 256-cube wavefronts contain at least one:
+    // running the MC33 tests in place would serialise almost every wave on a handful of lanes.
     if (first < d.cubes) {
         int z, y, x;
         cube_coords(d, first, z, y, x);
+        int idx4[MC_ITEMS];
+        const bool same_row = x + MC_ITEMS <= d.c2 && first + MC_ITEMS <= d.cubes;
+        if (same_row) {
+            // the 4 cubes share 4 voxel rows of 5 voxels: one 16-byte + one 4-byte load per row
+            struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+            const int64_t s1 = d.n2, s0 = (int64_t)d.n1 * d.n2;
+            const float* p = vol + (int64_t)z * s0 + (int64_t)y * s1 + x;
+            const float* rows[4] = {p, p + s1, p + s0, p + s0 + s1};
+            unsigned bits[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const F4 q = *reinterpret_cast<const F4*>(rows[r]);
+                const float last = rows[r][4];
+                bits[r] = ((double)q.v[0] > iso ? 1u : 0u) | ((double)q.v[1] > iso ? 2u : 0u) | ((double)q.v[2] > iso ? 4u : 0u) |
+                          ((double)q.v[3] > iso ? 8u : 0u) | ((double)last > iso ? 16u : 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < MC_ITEMS; ++k) {
+                const unsigned a = bits[0] >> k, b = bits[1] >> k, c = bits[2] >> k, e = bits[3] >> k;
+                idx4[k] = (int)((a & 1u) | ((a >> 1 & 1u) << 1) | ((b >> 1 & 1u) << 2) | ((b & 1u) << 3) |
+                                ((c & 1u) << 4) | ((c >> 1 & 1u) << 5) | ((e >> 1 & 1u) << 6) | ((e & 1u) << 7));
+            }
+        }
 #pragma unroll
         for (int it = 0; it < MC_ITEMS; ++it) {
             if (first + it < d.cubes) {
-                const int index = cube_index(vol, d, z, y, x, iso);
-                if (index != 0 && index != 255) {
-                    Cube c;
-                    load_cube(vol, d, z, y, x, iso, c);
-                    int off, nt;
-                    select_tiling(c, index, off, nt);
-                    const int created = count_created(off, nt, z, y, x);
-                    word |= pack_code(nt, created) << (8 * it);
-                    nv += created; ntri += nt;
-                }
+                const int index = same_row ? idx4[it] : cube_index(vol, d, z, y, x, iso);
+                if (index != 0 && index != 255)
+                    s_queue[atomicAdd(&s_count, 1u)] = (uint32_t)(threadIdx.x * MC_ITEMS + it) | ((uint32_t)index << 16);
                 next_cube(d, z, y, x);
             }
         }
     }
+    __syncthreads();
+    // ---- phase B (dense): MC33 face / interior tests and the created-vertex count of the queued cubes
+    const uint32_t queued = s_count;
+    for (uint32_t q = threadIdx.x; q < queued; q += MC_BLOCK) {
+        const uint32_t ent = s_queue[q];
+        const int local = (int)(ent & 0xffffu), index = (int)(ent >> 16);
+        int z, y, x;
+        cube_coords(d, tile_base + local, z, y, x);
+        Cube c;
+        load_cube(vol, d, z, y, x, iso, c);
+        int off, nt;
+        select_tiling(c, index, off, nt);
+        const int created = count_created(off, nt, z, y, x);
+        atomicOr(&s_code[local >> 2], pack_code(nt, created) << (8 * (local & 3)));
+        nv += created; ntri += nt; nact += nt > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    const uint32_t word = s_code[threadIdx.x];
     const int64_t w = (int64_t)blockIdx.x * MC_BLOCK + threadIdx.x;     // code dword of this thread
     if (w * MC_ITEMS < ((d.cubes + 3) & ~int64_t(3))) codes4[w] = word;
-    for (int o = 32; o > 0; o >>= 1) { nv += __shfl_xor(nv, o); ntri += __shfl_xor(ntri, o); }
-    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = nv; s_t[threadIdx.x >> 6] = ntri; }
+    for (int o = 32; o > 0; o >>= 1) { nv += __shfl_xor(nv, o); ntri += __shfl_xor(ntri, o); nact += __shfl_xor(nact, o); }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = nv; s_t[threadIdx.x >> 6] = ntri; s_a[threadIdx.x >> 6] = nact; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t a = 0, b = 0;
-        for (int q = 0; q < MC_BLOCK / 64; ++q) { a += s_v[q]; b += s_t[q]; }
-        tile_sums[blockIdx.x] = make_uint2(a, b);
+        uint32_t a = 0, b = 0, c = 0;
+        for (int q = 0; q < MC_BLOCK / 64; ++q) { a += s_v[q]; b += s_t[q]; c += s_a[q]; }
+        tile_sums[blockIdx.x] = make_uint4(a, b, c, 0);
     }
 }
 
-// ---- pass 2: exclusive scan of the per-tile sums (one block; every thread owns a contiguous run) ------
-__global__ __launch_bounds__(1024) void mc_scan_tiles(uint2* __restrict__ tile_sums, int64_t tiles,
-                                                      uint32_t* __restrict__ totals) {
-    __shared__ uint32_t s_a[1024], s_b[1024];
-    const int64_t per = (tiles + 1023) / 1024;
-    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < tiles ? lo + per : tiles;
-    uint32_t a = 0, b = 0;
-    for (int64_t i = lo; i < hi; ++i) { const uint2 v = tile_sums[i]; a += v.x; b += v.y; }
-    s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+// ---- pass 2: exclusive scan of the per-tile sums: 1024-tile groups in parallel, then the group totals ------
+__device__ __forceinline__ void block_scan3(uint32_t (&inc)[3], uint32_t (&tot)[3], uint32_t (*s_w)[16]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 1024 threads: inclusive scan in place
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t pv = __shfl_up(inc[k], o);
+            if (lane >= o) inc[k] += pv;
+        }
+    if (lane == 63) { s_w[0][wave] = inc[0]; s_w[1][wave] = inc[1]; s_w[2][wave] = inc[2]; }
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan of the 1024 run totals
-        uint32_t pa = 0, pb = 0;
-        if ((int)threadIdx.x >= o) { pa = s_a[threadIdx.x - o]; pb = s_b[threadIdx.x - o]; }
-        __syncthreads();
-        s_a[threadIdx.x] += pa; s_b[threadIdx.x] += pb;
-        __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t w = lane < 16 ? s_w[k][lane] : 0u;
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t pw = __shfl_up(w, o);
+            if (lane >= o) w += pw;
+        }
+        tot[k] = __shfl(w, 15);
+        const uint32_t below = __shfl(w, wave > 0 ? wave - 1 : 0);
+        inc[k] += wave > 0 ? below : 0u;
     }
-    uint32_t ra = s_a[threadIdx.x] - a, rb = s_b[threadIdx.x] - b;   // exclusive prefix of this run
-    for (int64_t i = lo; i < hi; ++i) {
-        const uint2 v = tile_sums[i];
-        tile_sums[i] = make_uint2(ra, rb);
-        ra += v.x; rb += v.y;
-    }
-    if (threadIdx.x == 1023) { totals[0] = s_a[1023]; totals[1] = s_b[1023]; }
 }
 
-// exclusive (vertex, triangle) offsets of this thread's MC_ITEMS consecutive cubes: tile prefix + block scan.
-__device__ __forceinline__ void tile_offsets(uint32_t word, uint2 tile_prefix, uint32_t (&vbase)[MC_ITEMS],
-                                             uint32_t (&tbase)[MC_ITEMS]) {
-    __shared__ uint32_t s_wv[MC_BLOCK / 64], s_wt[MC_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t tv = 0, tt = 0;
+__global__ __launch_bounds__(1024) void mc_scan_groups(uint4* __restrict__ tile_sums, int64_t tiles,
+                                                       uint4* __restrict__ group_sums) {
+    __shared__ uint32_t s_w[3][16];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint4 v = i < tiles ? tile_sums[i] : make_uint4(0, 0, 0, 0);
+    uint32_t inc[3] = {v.x, v.y, v.z}, tot[3];
+    block_scan3(inc, tot, s_w);
+    if (i < tiles) tile_sums[i] = make_uint4(inc[0] - v.x, inc[1] - v.y, inc[2] - v.z, 0);   // exclusive within the group
+    if (threadIdx.x == 0) group_sums[blockIdx.x] = make_uint4(tot[0], tot[1], tot[2], 0);
+}
+
+__global__ __launch_bounds__(1024) void mc_scan_totals(uint4* __restrict__ group_sums, int64_t groups,
+                                                       uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_w[3][16];
+    uint32_t carry[3] = {0, 0, 0};
+    for (int64_t start = 0; start < groups; start += 1024) {      // one round up to 1M tiles = 1G cubes
+        const int64_t i = start + threadIdx.x;
+        const uint4 v = i < groups ? group_sums[i] : make_uint4(0, 0, 0, 0);
+        uint32_t inc[3] = {v.x, v.y, v.z}, tot[3];
+        block_scan3(inc, tot, s_w);
+        if (i < groups) group_sums[i] = make_uint4(carry[0] + inc[0] - v.x, carry[1] + inc[1] - v.y, carry[2] + inc[2] - v.z, 0);
 #pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) { tv += code_created(word >> (8 * it)); tt += code_nt(word >> (8 * it)); }
-    uint32_t v = tv, t = tt;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t pv = __shfl_up(v, o), pt = __shfl_up(t, o);
-        if (lane >= o) { v += pv; t += pt; }
+        for (int k = 0; k < 3; ++k) carry[k] += tot[k];
+        __syncthreads();
     }
-    if (lane == 63) { s_wv[wave] = v; s_wt[wave] = t; }
-    __syncthreads();
-    uint32_t pre_v = tile_prefix.x + v - tv, pre_t = tile_prefix.y + t - tt;
-    for (int q = 0; q < MC_BLOCK / 64; ++q)
-        if (q < wave) { pre_v += s_wv[q]; pre_t += s_wt[q]; }
-#pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        vbase[it] = pre_v; tbase[it] = pre_t;
-        pre_v += code_created(word >> (8 * it)); pre_t += code_nt(word >> (8 * it));
-    }
+    if (threadIdx.x == 0) { totals[0] = carry[0]; totals[1] = carry[1]; totals[2] = carry[2]; }
 }
 
 struct McOut {
@@ -379,119 +427,134 @@ struct McOut {
     float* normals;    // (V,3)
     float* values;     // (V,)
     int32_t* edge_vertex[3];   // per axis (x,y,z): vertex id of the edge whose lower corner is the voxel
-    uint32_t* vertex_home;     // per vertex: creating cube (low 28 bits: tile-local... see below) -- 2 words
 };
 
-// ---- pass 3: create vertices -------------------------------------------------------------------------------
-__global__ __launch_bounds__(MC_BLOCK) void mc_emit_vertices(const float* __restrict__ vol, McDims d, double iso,
-                                                             const uint32_t* __restrict__ codes4,
-                                                             const uint2* __restrict__ tile_prefix, McOut out,
-                                                             int64_t* __restrict__ vertex_cube, int8_t* __restrict__ vertex_edge) {
-    uint32_t vbase[MC_ITEMS], tbase[MC_ITEMS];
+struct McActive {      // one entry per cube that emits triangles, in scan order
+    int64_t id;
+    uint32_t vbase, tbase;
+};
+
+// ---- pass 3a: compact the active cubes (scan order) with their vertex / triangle bases -----------------------
+__global__ __launch_bounds__(MC_BLOCK) void mc_compact(McDims d, const uint32_t* __restrict__ codes4,
+                                                       const uint4* __restrict__ tile_prefix,
+                                                       const uint4* __restrict__ group_prefix, McActive* __restrict__ list) {
+    __shared__ uint32_t s_w[3][MC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
     const uint32_t word = first < d.cubes ? codes4[(int64_t)blockIdx.x * MC_BLOCK + threadIdx.x] : 0u;
-    tile_offsets(word, tile_prefix[blockIdx.x], vbase, tbase);
-    if ((word & 0xf0f0f0f0u) == 0) return;            // none of this thread's cubes creates a vertex
-    int z, y, x;
-    cube_coords(d, first, z, y, x);
+    uint32_t own[3] = {0, 0, 0};
 #pragma unroll
     for (int it = 0; it < MC_ITEMS; ++it) {
-        if (code_created(word >> (8 * it)) != 0) {
-            const int64_t id = first + it;
-            Cube c;
-            load_cube(vol, d, z, y, x, iso, c);
-            int off, nt;
-            select_tiling(c, index_of(c), off, nt);
+        const uint32_t c = word >> (8 * it);
+        own[0] += code_created(c); own[1] += code_nt(c); own[2] += code_nt(c) ? 1 : 0;
+    }
+    uint32_t inc[3] = {own[0], own[1], own[2]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t pv = __shfl_up(inc[k], o);
+            if (lane >= o) inc[k] += pv;
+        }
+    if (lane == 63) { s_w[0][wave] = inc[0]; s_w[1][wave] = inc[1]; s_w[2][wave] = inc[2]; }
+    __syncthreads();
+    if (word == 0) return;
+    const uint4 tp = tile_prefix[blockIdx.x], gp = group_prefix[blockIdx.x >> 10];
+    uint32_t pre[3] = {gp.x + tp.x + inc[0] - own[0], gp.y + tp.y + inc[1] - own[1], gp.z + tp.z + inc[2] - own[2]};
+    for (int q = 0; q < MC_BLOCK / 64; ++q)
+        if (q < wave) { pre[0] += s_w[0][q]; pre[1] += s_w[1][q]; pre[2] += s_w[2][q]; }
+#pragma unroll
+    for (int it = 0; it < MC_ITEMS; ++it) {
+        const uint32_t c = word >> (8 * it);
+        if (code_nt(c)) {
+            McActive e; e.id = first + it; e.vbase = pre[0]; e.tbase = pre[1];
+            list[pre[2]++] = e;
+        }
+        pre[0] += code_created(c); pre[1] += code_nt(c);
+    }
+}
+
+// ---- pass 3b: vertices and faces, one thread per ACTIVE cube (all lanes busy) ---------------------------------
+template <bool FACES>
+__global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, McDims d, double iso,
+                                               const McActive* __restrict__ list, const uint32_t* __restrict__ totals,
+                                               McOut out, int64_t* __restrict__ vertex_cube,
+                                               int8_t* __restrict__ vertex_edge) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= (int64_t)totals[2]) return;     // number of active cubes, left on the device by the scan
+    const McActive ent = list[a];
+    int z, y, x;
+    cube_coords(d, ent.id, z, y, x);
+    Cube c;
+    load_cube(vol, d, z, y, x, iso, c);
+    int off, nt;
+    select_tiling(c, index_of(c), off, nt);
+    if constexpr (!FACES) {
+        unsigned seen = 0;
+        uint32_t next = ent.vbase;
+        for (int i = 0; i < 3 * nt; ++i) {
+            const int e = lut(off + i);
+            if (seen & (1u << e)) continue;
+            seen |= 1u << e;
+            if (!owns_edge(e, z, y, x)) continue;
+            double px, py, pz;
+            if (e == 12) {
+                double fx = 0, fy = 0, fz = 0, ff = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double w = 1.0 / (SK_EPS + fabs(c.v[k]));
+                    const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
+                    fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
+                }
+                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+            } else {
+                const signed char* ea = MC_EDGE_A[e];
+                const signed char* eb = MC_EDGE_B[e];
+                const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
+                const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
+                const double w1 = 1.0 / (SK_EPS + fabs(c.v[ka])), w2 = 1.0 / (SK_EPS + fabs(c.v[kb]));
+                double fx = 0, fy = 0, fz = 0, ff = 0;
+                fx += (double)ea[2] * w1; fy += (double)ea[1] * w1; fz += (double)ea[0] * w1; ff += w1;
+                fx += (double)eb[2] * w2; fy += (double)eb[1] * w2; fz += (double)eb[0] * w2; ff += w2;
+                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+                const signed char* lo = MC_EDGE_LO[e];
+                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
+                out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
+            }
+            // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
+            out.verts[3 * (int64_t)next] = (float)pz;
+            out.verts[3 * (int64_t)next + 1] = (float)py;
+            out.verts[3 * (int64_t)next + 2] = (float)px;
+            vertex_cube[next] = ent.id;
+            vertex_edge[next] = (int8_t)e;
+            ++next;
+        }
+    } else {
+        // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
+        int centre = -1;
+        {
             unsigned seen = 0;
-            uint32_t next = vbase[it];
+            int k = 0;
             for (int i = 0; i < 3 * nt; ++i) {
                 const int e = lut(off + i);
                 if (seen & (1u << e)) continue;
                 seen |= 1u << e;
-                if (!owns_edge(e, z, y, x)) continue;
-                double px, py, pz;
-                if (e == 12) {
-                    double fx = 0, fy = 0, fz = 0, ff = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const double w = 1.0 / (SK_EPS + fabs(c.v[k]));
-                        const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
-                        fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
-                    }
-                    px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
-                } else {
-                    const signed char* a = MC_EDGE_A[e];
-                    const signed char* b = MC_EDGE_B[e];
-                    const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
-                    const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
-                    const double w1 = 1.0 / (SK_EPS + fabs(c.v[ka])), w2 = 1.0 / (SK_EPS + fabs(c.v[kb]));
-                    double fx = 0, fy = 0, fz = 0, ff = 0;
-                    fx += (double)a[2] * w1; fy += (double)a[1] * w1; fz += (double)a[0] * w1; ff += w1;
-                    fx += (double)b[2] * w2; fy += (double)b[1] * w2; fz += (double)b[0] * w2; ff += w2;
-                    px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
-                    const signed char* lo = MC_EDGE_LO[e];
-                    const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
-                    out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
-                }
-                // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
-                out.verts[3 * (int64_t)next] = (float)pz;
-                out.verts[3 * (int64_t)next + 1] = (float)py;
-                out.verts[3 * (int64_t)next + 2] = (float)px;
-                vertex_cube[next] = id;
-                vertex_edge[next] = (int8_t)e;
-                ++next;
+                if (e == 12) { centre = (int)ent.vbase + k; break; }
+                k += owns_edge(e, z, y, x) ? 1 : 0;
             }
         }
-        next_cube(d, z, y, x);
-    }
-}
-
-// ---- pass 4: faces -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MC_BLOCK) void mc_emit_faces(const float* __restrict__ vol, McDims d, double iso,
-                                                          const uint32_t* __restrict__ codes4,
-                                                          const uint2* __restrict__ tile_prefix, McOut out) {
-    uint32_t vbase[MC_ITEMS], tbase[MC_ITEMS];
-    const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
-    const uint32_t word = first < d.cubes ? codes4[(int64_t)blockIdx.x * MC_BLOCK + threadIdx.x] : 0u;
-    tile_offsets(word, tile_prefix[blockIdx.x], vbase, tbase);
-    if (word == 0) return;
-    int z, y, x;
-    cube_coords(d, first, z, y, x);
+        for (int t = 0; t < nt; ++t) {
+            int idx[3];
 #pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        if (code_nt(word >> (8 * it)) != 0) {
-            Cube c;
-            load_cube(vol, d, z, y, x, iso, c);
-            int off, nt;
-            select_tiling(c, index_of(c), off, nt);
-            // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
-            int centre = -1;
-            {
-                unsigned seen = 0;
-                int k = 0;
-                for (int i = 0; i < 3 * nt; ++i) {
-                    const int e = lut(off + i);
-                    if (seen & (1u << e)) continue;
-                    seen |= 1u << e;
-                    if (e == 12) { centre = (int)vbase[it] + k; break; }
-                    k += owns_edge(e, z, y, x) ? 1 : 0;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const int e = lut(off + 3 * t + j);
+                if (e == 12) { idx[j] = centre; continue; }
+                const signed char* lo = MC_EDGE_LO[e];
+                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
+                idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
             }
-            for (int t = 0; t < nt; ++t) {
-                int idx[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int e = lut(off + 3 * t + j);
-                    if (e == 12) { idx[j] = centre; continue; }
-                    const signed char* lo = MC_EDGE_LO[e];
-                    const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
-                    idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
-                }
-                int32_t* f = out.faces + 3 * ((int64_t)tbase[it] + t);
-                f[0] = idx[2]; f[1] = idx[1]; f[2] = idx[0];   // gradient_direction='descent' reverses each triple
-            }
+            int32_t* f = out.faces + 3 * ((int64_t)ent.tbase + t);
+            f[0] = idx[2]; f[1] = idx[1]; f[2] = idx[0];   // gradient_direction='descent' reverses each triple
         }
-        next_cube(d, z, y, x);
     }
 }
 
@@ -591,7 +654,8 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
 static inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct McWorkspace {
-    uint32_t* codes; uint2* tile_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
+    uint32_t* codes; uint4* tile_sums; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
+    McActive* active;
     int64_t tiles;
 };
 
@@ -607,7 +671,8 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
     char* p;
     p = take((((size_t)d.cubes + 3) & ~size_t(3)) + 4096); if (ws) ws->codes = (uint32_t*)p;
-    p = take((size_t)tiles * 8); if (ws) ws->tile_sums = (uint2*)p;
+    p = take((size_t)tiles * 16); if (ws) ws->tile_sums = (uint4*)p;
+    p = take((size_t)((tiles + 1023) / 1024) * 16); if (ws) ws->group_sums = (uint4*)p;
     p = take(256); if (ws) ws->totals = (uint32_t*)p;
     for (int a = 0; a < 3; ++a) { p = take(vox * 4); if (ws) ws->edge[a] = (int32_t*)p; }
     if (ws) ws->tiles = tiles;
@@ -625,7 +690,10 @@ int64_t nm_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2) {
     return (int64_t)carve(make_dims(n0, n1, n2), nullptr, nullptr);
 }
 
-int64_t nm_mc_vertex_scratch_bytes(int64_t vertices) { return (int64_t)(al((size_t)vertices * 8) + al((size_t)vertices)); }
+int64_t nm_mc_vertex_scratch_bytes(int64_t vertices, int64_t faces) {
+    // per vertex: creating cube (8 B) + edge id (1 B); per active cube (<= faces): one 16-byte list entry
+    return (int64_t)(al((size_t)vertices * 8) + al((size_t)vertices) + al((size_t)faces * sizeof(McActive)));
+}
 
 int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
                 int64_t* h_vertices, int64_t* h_faces, void* stream_) {
@@ -638,9 +706,11 @@ int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, doubl
     carve(d, static_cast<char*>(d_workspace), &ws);
     hipLaunchKernelGGL(mc_classify, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
                        ws.tile_sums);
-    hipLaunchKernelGGL(mc_scan_tiles, dim3(1), dim3(1024), 0, stream, ws.tile_sums, ws.tiles, ws.totals);
+    const int64_t groups = (ws.tiles + 1023) / 1024;
+    hipLaunchKernelGGL(mc_scan_groups, dim3((unsigned)groups), dim3(1024), 0, stream, ws.tile_sums, ws.tiles, ws.group_sums);
+    hipLaunchKernelGGL(mc_scan_totals, dim3(1), dim3(1024), 0, stream, ws.group_sums, groups, ws.totals);
     NM_HIP_CHECK(hipGetLastError());
-    uint32_t totals[2];
+    uint32_t totals[3];
     NM_HIP_CHECK(hipMemcpyAsync(totals, ws.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
     NM_HIP_CHECK(hipStreamSynchronize(stream));
     *h_vertices = totals[0];
@@ -659,14 +729,17 @@ int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double
     carve(d, static_cast<char*>(d_workspace), &ws);
     ws.vertex_cube = static_cast<int64_t*>(d_vertex_scratch);
     ws.vertex_edge = reinterpret_cast<int8_t*>(static_cast<char*>(d_vertex_scratch) + al((size_t)vertices * 8));
+    ws.active = reinterpret_cast<McActive*>(static_cast<char*>(d_vertex_scratch) + al((size_t)vertices * 8) + al((size_t)vertices));
     McOut out;
     out.verts = d_verts; out.faces = d_faces; out.normals = d_normals; out.values = d_values;
     for (int a = 0; a < 3; ++a) out.edge_vertex[a] = ws.edge[a];
-    out.vertex_home = nullptr;
-    hipLaunchKernelGGL(mc_emit_vertices, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
-                       ws.tile_sums, out, ws.vertex_cube, ws.vertex_edge);
-    hipLaunchKernelGGL(mc_emit_faces, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
-                       ws.tile_sums, out);
+    const unsigned ablocks = (unsigned)((faces + 255) / 256);   // active cubes <= faces; surplus threads exit
+    hipLaunchKernelGGL(mc_compact, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d, ws.codes, ws.tile_sums, ws.group_sums,
+                       ws.active);
+    hipLaunchKernelGGL(mc_emit<false>, dim3(ablocks), dim3(256), 0, stream, d_volume, d, iso, ws.active, ws.totals, out,
+                       ws.vertex_cube, ws.vertex_edge);
+    hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, d, iso, ws.active, ws.totals, out,
+                       ws.vertex_cube, ws.vertex_edge);
     hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((vertices + 255) / 256)), dim3(256), 0, stream, d_volume, d, iso,
                        ws.vertex_cube, ws.vertex_edge, vertices, out);
     NM_HIP_CHECK(hipGetLastError());

@@ -267,7 +267,7 @@ def marching_cubes(volume, level):
     normals = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)
     values = torch.empty(nv.value, dtype=torch.float32, device=dev)
     faces = torch.empty(nf.value, 3, dtype=torch.int32, device=dev)
-    scratch = torch.empty(int(lib.nm_mc_vertex_scratch_bytes(nv.value)) + 256, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(int(lib.nm_mc_vertex_scratch_bytes(nv.value, nf.value)) + 256, dtype=torch.uint8, device=dev)
     check(lib.nm_mc_emit(_ptr(vol), n0, n1, n2, level, _ptr(ws), _ptr(scratch), nv.value, nf.value, _ptr(verts),
                          _ptr(faces), _ptr(normals), _ptr(values), _stream()), "nm_mc_emit")
     return verts, faces, normals, values
