@@ -69,7 +69,7 @@ __device__ __forceinline__ void stream_to_lds(const char* src, char* dst, int by
 // their use, and the two waves of a SIMD, released together by the barrier, then expose the LDS latency
 // together every 8 MFMAs), one barrier.  (The cursor is SGPR arithmetic on purpose: a chunk table fetched
 // with s_load costs 3 % -- its s_waitcnt lgkmcnt(0) also drains the in-flight ds_reads.)
-template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE>
+template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE, bool SPREAD = false>
 __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[KS1],
                                            const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
                                            const char* tail_src, int tail_bytes, char* lds, int& par,
@@ -85,12 +85,20 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[K
     for (int c = 0; c < NCH; ++c) {
         const int steps = (KS - c * KCH) < KCH ? (KS - c * KCH) : KCH;
         char* next_slot = lds + (par ^ 1) * LDSBUF;
+        const char* next_src;
+        int next_bytes;
         if (c + 1 < NCH) {
             const int nsteps = (KS - (c + 1) * KCH) < KCH ? (KS - (c + 1) * KCH) : KCH;
-            stream_to_lds<NW>(gw + (c + 1) * KCH * STEP_BYTES, next_slot, nsteps * STEP_BYTES, wave, lane);
+            next_src = gw + (c + 1) * KCH * STEP_BYTES; next_bytes = nsteps * STEP_BYTES;
         } else {
-            stream_to_lds<NW>(tail_src, next_slot, tail_bytes, wave, lane);
+            next_src = tail_src; next_bytes = tail_bytes;
         }
+        // DMA of the following chunk: either all of this wave's 1 KiB pieces up front, or (SPREAD) one piece per
+        // k-step inside the MFMA stream -- issued together right after the barrier they keep BOTH waves of a
+        // SIMD away from the matrix pipe for ~100 cycles per piece, 73 times per tile
+        const int next_units = (next_bytes + 1023) >> 10;
+        int next_u = wave;
+        if constexpr (!SPREAD) stream_to_lds<NW>(next_src, next_slot, next_bytes, wave, lane);
         const char* buf = lds + par * LDSBUF + lane * (VW * 4);
         avec a_next[NB];
         if constexpr (PIPE) {
@@ -115,11 +123,26 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[K
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (SPREAD) {
+                if (next_u < next_units) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(next_src + (size_t)next_u * 1024 + lane * 16),
+                        (__attribute__((address_space(3))) void*)(next_slot + next_u * 1024), 16, 0, 0);
+                    next_u += NW;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
                 for (int q = 0; q < VW; ++q)
                     acc[blk * VW + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[blk][q], b, acc[blk * VW + q], 0, 0, 0);
+        }
+        if constexpr (SPREAD) {   // pieces beyond the chunk's k-step count (short chunks)
+            for (; next_u < next_units; next_u += NW)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(next_src + (size_t)next_u * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(next_slot + next_u * 1024), 16, 0, 0);
         }
         __syncthreads();  // drains the DMA (vmcnt(0)) and releases slot `par` for the next fill
         par ^= 1;
@@ -178,7 +201,7 @@ __device__ __forceinline__ float alpha_gemv(const float (&in)[H / 4], const floa
     return group_sum(part);
 }
 
-template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS>
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, const int num_layers,
                                                       const int density_only) {
     using N = Net<H, FX, FD, KCH>;
@@ -186,11 +209,17 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
     // LBIAS: every bias of the network lives in LDS behind the ring for the whole launch (a bias fetched from
     // L2 at the top of a layer is ~1 us of exposed latency in front of that layer's first MFMA)
     float* lds_bias = reinterpret_cast<float*>(lds + 2 * N::LDSBUF);
+    const int nbias = H * (1 + num_layers) + H / 2;
+    float* lds_walpha = lds_bias + nbias;          // [4][H/4]
+    float* lds_wrgb = lds_walpha + H;              // [3][4][H/8]
     if constexpr (LBIAS) {
-        const int nb = H * (1 + num_layers) + H / 2;
-        for (int i = threadIdx.x; i < nb; i += NW * 64) lds_bias[i] = args.bias[i];
+        for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
+        for (int i = threadIdx.x; i < H; i += NW * 64) lds_walpha[i] = args.walpha[i];
+        for (int i = threadIdx.x; i < 3 * H / 2; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
     }
     const float* bias_src = LBIAS ? lds_bias : args.bias;
+    const float* walpha_src = LBIAS ? lds_walpha : args.walpha;
+    const float* wrgb_src = LBIAS ? lds_wrgb : args.wrgb;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
@@ -241,12 +270,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         // ---- layer1: xyz_enc -> H, no activation (models.py:62)
         load_bias<N::NT>(acc, bias_src, g);
         if constexpr (KEEP_ENC) {
-            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx_keep, dummy, gw, gw + N::EX * N::STEP,
+            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx_keep, dummy, gw, gw + N::EX * N::STEP,
                                                                    N::LDSBUF, lds, par, wave, lane);
         } else {   // the encoding registers live only for this stage; the skip layer recomputes them
             float encx[N::EX];
             encode<FX, N::EX>(encx, p, args.bands_xyz, g);
-            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF,
+            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF,
                                                                    lds, par, wave, lane);
         }
         gw += N::EX * N::STEP;
@@ -258,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
 #pragma unroll 1
         for (int i = 0; i < trunk_iters; ++i) {
             const bool is_feat = i == num_layers - 1;
-            if (is_feat) sigma = alpha_gemv<H>(in, args.walpha, g) + args.balpha;   // on the pre-feature activation
+            if (is_feat) sigma = alpha_gemv<H>(in, walpha_src, g) + args.balpha;   // on the pre-feature activation
             const bool skip = !is_feat && ((args.skip_mask >> i) & 1u);
             const bool last_density = density_only && i == num_layers - 2;
             load_bias<N::NT>(acc, bias_src + H * (1 + i), g);
@@ -268,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
                 if (skip) tbytes = N::L1_FIRST;               // the skip layer's encoding columns follow
                 else if (is_feat) tbytes = N::DIR_FIRST;      // view layer follows
                 else if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
-                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 gw += N::KH * N::STEP;
             }
             if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
@@ -276,11 +305,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
                 int tbytes = N::LDSBUF;
                 if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
                 if constexpr (KEEP_ENC) {
-                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx_keep, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx_keep, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 } else {
                     float encx[N::EX];
                     encode<FX, N::EX>(encx, p, args.bands_xyz, g);
-                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 }
                 gw += N::EX * N::STEP;
             }
@@ -288,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         }
 
         if (density_only) {
-            sigma = alpha_gemv<H>(in, args.walpha, g) + args.balpha;
+            sigma = alpha_gemv<H>(in, walpha_src, g) + args.balpha;
             if (valid && g == 0) args.out[sample] = sigma;
             gw = args.wstream;
             continue;
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         load_bias<N::NTD>(accd, bias_src + H * (1 + num_layers), g);
         float encd[N::ED];
         encode<FD, N::ED>(encd, d, args.bands_dir, g);
-        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE>(accd, in, encd, gw, args.wstream,
+        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE, SPREAD>(accd, in, encd, gw, args.wstream,
                                                                     has_next ? N::L1_FIRST : 0, lds, par, wave, lane);
         gw = args.wstream;
         acc_to_operand<N::NTD, true>(accd, v);
@@ -310,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float part = 0.0f;
-            const float* wr = args.wrgb + (ch * 4 + g) * N::KD;
+            const float* wr = wrgb_src + (ch * 4 + g) * N::KD;
 #pragma unroll
             for (int s = 0; s < N::KD; s += 4) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + s);
@@ -335,10 +364,10 @@ struct MlpPlan {
     void (*kernel)(const MlpArgs, const int, const int);
 };
 
-template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS>
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD = false>
 static MlpPlan make_plan(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
-                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS>};
+                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD>};
 }
 
 // variant 0 is the production choice; the others exist for within-process A/B runs (scripts/bench_mlp.py,
@@ -355,8 +384,9 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 8, 8, false, true, false>(2),    // round-1 first version (no prefetch, L2 biases): 133.7
     make_plan<256, 10, 4, 8, 8, true, false, true>(3),     // encodings recomputed at the skip layer: ~135
     make_plan<256, 10, 4, 8, 8, true, true, false>(4),     // prefetch only, biases from L2: 138.3
-    make_plan<256, 10, 4, 4, 8, true, true, true>(5),      // 4-wave workgroups, two per CU (decoupled barriers)
-    make_plan<256, 10, 4, 4, 16, true, true, true>(6),
+    make_plan<256, 10, 4, 4, 8, true, true, true>(5),      // 4-wave workgroups, two per CU (decoupled barriers): 132.3
+    make_plan<256, 10, 4, 8, 8, true, true, true, true>(6),  // DMA pieces spread over the k-steps
+    make_plan<256, 10, 4, 8, 16, true, true, true, true>(7), // ... with 16-k-step chunks
 };
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
@@ -380,7 +410,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     const MlpPlan* p = m->plan;
     if (args.n <= 0) return 0;
     const int L = m->desc.num_layers, H = m->desc.hidden_size;
-    const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2) * 4 + 255) & ~255) : 0);
+    const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + H + 3 * H / 2) * 4 + 255) & ~255) : 0);
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     static int attr_bytes[sizeof(g_plans) / sizeof(g_plans[0])] = {};
     const int idx = (int)(p - g_plans);
