@@ -37,8 +37,12 @@ def eval_nerf(model, views, cfg, device="cuda", chunksize=None):
     """Returns (per-view losses, dataset loss, dataset PSNR, last rgb map)."""
     chunksize = chunksize or cfg.nerf.validation.chunksize
     bounds = torch.tensor([cfg.dataset.near, cfg.dataset.far], dtype=torch.float32)
+    from . import dist as nd
+    rank, world = nd.world()
     losses, rgb = [], None
-    for pose, h, w, focal, targets in views:
+    for view_nr, (pose, h, w, focal, targets) in enumerate(views):
+        if view_nr % world != rank:           # views are independent: round-robin over the ranks
+            continue
         rgb, _ = render_view(model, pose, h, w, focal, bounds, chunksize, device)
         if targets is not None:
             targets = targets.to(device)
@@ -49,6 +53,9 @@ def eval_nerf(model, views, cfg, device="cuda", chunksize=None):
             loss /= batch_count
             losses.append(loss)
             print(f"[EVAL] Iter: {len(losses) - 1} Loss MSE {loss} / PSNR: {mse2psnr(loss)}")
+    if world > 1 and losses:                  # assemble the per-view losses of all ranks (same count per rank assumed)
+        mine = torch.stack(losses).to(device)
+        losses = list(nd.all_gather_rows(mine, [mine.shape[0]] * world))
     total = torch.stack(losses).mean() if losses else None
     if total is not None:
         print(f"Dataset loss MSE: {total} / PSNR: {mse2psnr(total)}")

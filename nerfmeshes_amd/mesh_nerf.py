@@ -54,9 +54,22 @@ def extract_radiance(model, args, device, nums):
 
 
 def extract_density(model, args, device, nums):
-    """Density grid (n0,n1,n2) as a GPU tensor (radiance[..., 3] of the reference, mesh_nerf.py:73)."""
-    out, nums = _grid_query(model, args, device, nums, density_only=True)
-    return out.view(*nums)
+    """Density grid (n0,n1,n2) as a GPU tensor (radiance[..., 3] of the reference, mesh_nerf.py:73).
+    Under torch.distributed (one process per GPU) every rank evaluates its slab of axis-0 planes and one
+    all-gather (RCCL over xGMI) assembles the full grid on every rank; marching cubes then runs on the full
+    grid, so the mesh is identical to the single-GPU one by construction."""
+    from . import dist as nd
+    rank, world = nd.world()
+    if world == 1:
+        out, nums = _grid_query(model, args, device, nums, density_only=True)
+        return out.view(*nums)
+    nums = _nums(nums)
+    net = model.get_model().hip()
+    ax = _axes(args, nums, device)
+    plane = nums[1] * nums[2]
+    return nd.density_grid_sharded(
+        lambda lo, hi: net.grid_query(ax[0], ax[1], ax[2], first=lo * plane, count=(hi - lo) * plane, density_only=True),
+        *nums)
 
 
 def extract_iso_level(density, args):
