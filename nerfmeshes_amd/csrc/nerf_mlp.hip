@@ -69,7 +69,7 @@ __device__ __forceinline__ void stream_to_lds(const char* src, char* dst, int by
 // their use, and the two waves of a SIMD, released together by the barrier, then expose the LDS latency
 // together every 8 MFMAs), one barrier.  (The cursor is SGPR arithmetic on purpose: a chunk table fetched
 // with s_load costs 3 % -- its s_waitcnt lgkmcnt(0) also drains the in-flight ds_reads.)
-template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE, bool SPREAD = false>
+template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE, bool SPREAD = false, int ABL = 0>
 __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[KS1],
                                            const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
                                            const char* tail_src, int tail_bytes, char* lds, int& par,
@@ -98,7 +98,7 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[K
         // SIMD away from the matrix pipe for ~100 cycles per piece, 73 times per tile
         const int next_units = (next_bytes + 1023) >> 10;
         int next_u = wave;
-        if constexpr (!SPREAD) stream_to_lds<NW>(next_src, next_slot, next_bytes, wave, lane);
+        if constexpr (!SPREAD && !(ABL & 4)) stream_to_lds<NW>(next_src, next_slot, next_bytes, wave, lane);
         const char* buf = lds + par * LDSBUF + lane * (VW * 4);
         avec a_next[NB];
         if constexpr (PIPE) {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[K
                     (const __attribute__((address_space(1))) void*)(next_src + (size_t)next_u * 1024 + lane * 16),
                     (__attribute__((address_space(3))) void*)(next_slot + next_u * 1024), 16, 0, 0);
         }
-        __syncthreads();  // drains the DMA (vmcnt(0)) and releases slot `par` for the next fill
+        if constexpr (!(ABL & 2)) __syncthreads();  // drains the DMA (vmcnt(0)) and releases slot `par` for the next fill
         par ^= 1;
     }
 }
@@ -166,7 +166,7 @@ __device__ __forceinline__ void acc_to_operand(const f32x4 (&acc)[NT], float (&o
 // Positional encoding, laid out as MFMA B operands.  k-step s < STEPS-1 carries two encoding
 // arguments a0 = 2s, a1 = 2s+1 (a = coord * F + freq, the reference's coordinate-major order):
 // lane group 0: sin(a0)  1: cos(a0)  2: sin(a1)  3: cos(a1).  The last step carries (x, y, z, 0).
-template <int F, int STEPS>
+template <int F, int STEPS, int ABL = 0>
 __device__ __forceinline__ void encode(float (&enc)[STEPS], const float (&x)[3], const float* bands, int g) {
     const bool hi = (g >> 1) != 0;
     const bool want_cos = (g & 1) != 0;
@@ -176,7 +176,8 @@ __device__ __forceinline__ void encode(float (&enc)[STEPS], const float (&x)[3],
         const float x0 = x[a0 / F] * bands[a0 % F];
         const float x1 = (a1 < 3 * F) ? x[(a1 < 3 * F ? a1 : 0) / F] * bands[(a1 < 3 * F ? a1 : 0) % F] : 0.0f;
         float sv, cv;
-        sincosf(hi ? x1 : x0, &sv, &cv);
+        if constexpr (ABL & 1) { sv = hi ? x1 : x0; cv = sv + 1.0f; }
+        else sincosf(hi ? x1 : x0, &sv, &cv);
         enc[s] = want_cos ? cv : sv;
     }
     enc[STEPS - 1] = g == 0 ? x[0] : (g == 1 ? x[1] : (g == 2 ? x[2] : 0.0f));
@@ -201,7 +202,7 @@ __device__ __forceinline__ float alpha_gemv(const float (&in)[H / 4], const floa
     return group_sum(part);
 }
 
-template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD>
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD, int ABL>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, const int num_layers,
                                                       const int density_only) {
     using N = Net<H, FX, FD, KCH>;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         }
         const float dummy[1] = {0.0f};
         float encx_keep[KEEP_ENC ? N::EX : 1];
-        if constexpr (KEEP_ENC) encode<FX, N::EX>(encx_keep, p, args.bands_xyz, g);
+        if constexpr (KEEP_ENC) encode<FX, N::EX, ABL>(encx_keep, p, args.bands_xyz, g);
 
         f32x4 acc[N::NT];
         float in[N::KH];
@@ -270,12 +271,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         // ---- layer1: xyz_enc -> H, no activation (models.py:62)
         load_bias<N::NT>(acc, bias_src, g);
         if constexpr (KEEP_ENC) {
-            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx_keep, dummy, gw, gw + N::EX * N::STEP,
+            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, encx_keep, dummy, gw, gw + N::EX * N::STEP,
                                                                    N::LDSBUF, lds, par, wave, lane);
         } else {   // the encoding registers live only for this stage; the skip layer recomputes them
             float encx[N::EX];
-            encode<FX, N::EX>(encx, p, args.bands_xyz, g);
-            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF,
+            encode<FX, N::EX, ABL>(encx, p, args.bands_xyz, g);
+            gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF,
                                                                    lds, par, wave, lane);
         }
         gw += N::EX * N::STEP;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
                 if (skip) tbytes = N::L1_FIRST;               // the skip layer's encoding columns follow
                 else if (is_feat) tbytes = N::DIR_FIRST;      // view layer follows
                 else if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
-                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 gw += N::KH * N::STEP;
             }
             if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
@@ -305,11 +306,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
                 int tbytes = N::LDSBUF;
                 if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
                 if constexpr (KEEP_ENC) {
-                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx_keep, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, encx_keep, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 } else {
                     float encx[N::EX];
-                    encode<FX, N::EX>(encx, p, args.bands_xyz, g);
-                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                    encode<FX, N::EX, ABL>(encx, p, args.bands_xyz, g);
+                    gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, encx, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
                 }
                 gw += N::EX * N::STEP;
             }
@@ -328,8 +329,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         float v[N::KD];
         load_bias<N::NTD>(accd, bias_src + H * (1 + num_layers), g);
         float encd[N::ED];
-        encode<FD, N::ED>(encd, d, args.bands_dir, g);
-        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE, SPREAD>(accd, in, encd, gw, args.wstream,
+        encode<FD, N::ED, ABL>(encd, d, args.bands_dir, g);
+        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(accd, in, encd, gw, args.wstream,
                                                                     has_next ? N::L1_FIRST : 0, lds, par, wave, lane);
         gw = args.wstream;
         acc_to_operand<N::NTD, true>(accd, v);
@@ -364,10 +365,10 @@ struct MlpPlan {
     void (*kernel)(const MlpArgs, const int, const int);
 };
 
-template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD = false>
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD = false, int ABL = 0>
 static MlpPlan make_plan(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
-                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD>};
+                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL>};
 }
 
 // variant 0 is the production choice; the others exist for within-process A/B runs (scripts/bench_mlp.py,
@@ -387,6 +388,12 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 4, 8, true, true, true>(5),      // 4-wave workgroups, two per CU (decoupled barriers): 132.3
     make_plan<256, 10, 4, 8, 8, true, true, true, true>(6),  // DMA pieces spread over the k-steps
     make_plan<256, 10, 4, 8, 16, true, true, true, true>(7), // ... with 16-k-step chunks
+    // timing-only ablations (WRONG results): 1 = no sincos, 2 = no barrier, 4 = no weight DMA
+    make_plan<256, 10, 4, 8, 8, true, true, true, false, 1>(11),
+    make_plan<256, 10, 4, 8, 8, true, true, true, false, 2>(12),
+    make_plan<256, 10, 4, 8, 8, true, true, true, false, 4>(14),
+    make_plan<256, 10, 4, 8, 8, true, true, true, false, 6>(16),
+    make_plan<256, 10, 4, 8, 8, true, true, true, false, 7>(17),
 };
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
