@@ -285,3 +285,50 @@ def test_render_rough_scene_at_the_reference_noise_floor(ops):
     comp = ops.composite(rad, t_ref, d.cuda())
     _close(comp["rgb_map"], g["fine.rgb_map"], 5e-5, what="fine rgb_map on reference depths")
     _close(comp["acc_map"], g["fine.acc_map"], 5e-5, what="fine acc_map on reference depths")
+
+
+def test_full_size_view_properties(ops):
+    """BASELINE.json configs[1] at full size (800x800 = 640 000 rays, 64+128 samples, 8x256): properties that
+    do not need the (12-minute) CPU reference -- chunking invariance (rays are independent: any chunking, and
+    therefore any ray sharding across GPUs, must give bit-identical pixels), determinism, and the compositing
+    invariants acc = sum(weights) in [0, 1], rgb in [0, 1], depths sorted inside the bounds."""
+    kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    w = S.make_scene_weights(**kw)
+    mlp = ops.HipMLP(w, kw, "cuda")
+    o, d = ops.ray_bundle(S.orbit_poses(4)[2], 800, 800, S.LEGO_FOCAL_800)
+    near, far = torch.tensor([2.0]), torch.tensor([6.0])
+    uc, uf = torch.linspace(0, 1, 64), torch.linspace(0, 1, 128)
+
+    def render(chunk):
+        rgb, acc, wsum = [], [], []
+        for s in range(0, d.shape[0], chunk):
+            _, fb = ops.render_rays(mlp, mlp, o[None], d[s:s + chunk], near, far, uc, uf)
+            rgb.append(fb["rgb_map"].clone()); acc.append(fb["acc_map"].clone()); wsum.append(fb["weights"].sum(-1))
+        return torch.cat(rgb), torch.cat(acc), torch.cat(wsum)
+
+    rgb_a, acc_a, wsum_a = render(640000)         # one call
+    rgb_b, acc_b, _ = render(65536)               # bench chunking (ragged tail of 50 176 rays)
+    rgb_c, _, _ = render(640000)                  # again
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(acc_a, acc_b), "chunking changed the pixels"
+    assert torch.equal(rgb_a, rgb_c), "non-deterministic"
+    # the reference's chunk size on a slice (313 chunks would be slow in Python; 20 chunks suffice)
+    sl = slice(123456, 123456 + 20 * 2048)
+    parts = [ops.render_rays(mlp, mlp, o[None], d[sl][s:s + 2048], near, far, uc, uf)[1]["rgb_map"].clone()
+             for s in range(0, 20 * 2048, 2048)]
+    assert torch.equal(torch.cat(parts), rgb_a[sl])
+    assert float(rgb_a.min()) >= 0.0 and float(rgb_a.max()) <= 1.0 + 1e-5
+    assert float(acc_a.min()) >= 0.0 and float(acc_a.max()) <= 1.0 + 1e-5
+    assert float((acc_a - wsum_a).abs().max()) < 1e-5
+    assert 0.2 < float(acc_a.mean()) < 0.8, "the synthetic scene should be neither empty nor opaque"
+
+
+def test_ndc_rays_on_gpu_tensors(ops):
+    from nerfmeshes_amd.nerf import ndc_rays
+    g = load_golden("rays")
+    for i in range(2):
+        h, w, f = (float(v) for v in g[f"hwf{i}"])
+        o = torch.from_numpy(g[f"origin{i}"]).cuda()
+        d = torch.from_numpy(g[f"dirs{i}"]).cuda()
+        no, nd = ndc_rays(int(h), int(w), f, 1.0, o.expand(int(h), int(w), 3) * 0.3, d)
+        _close(no, g[f"ndc_o{i}"], 2e-6, rtol=2e-6, what="ndc origins")
+        _close(nd, g[f"ndc_d{i}"], 2e-6, rtol=2e-6, what="ndc directions")
