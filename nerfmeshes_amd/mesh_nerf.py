@@ -122,15 +122,18 @@ def export_marching_cubes(model, args, cfg, device):
 
     targets, directions = vertices, -normals
     diffuse = []
+    # --batch-size bounds the reference's per-call memory (default 1024); on a 288 GB device the per-call overhead
+    # of a 1024-ray launch sequence dominates, so at least 65 536 vertices go into one call
+    chunk = max(int(args.batch_size), 65536)
     if args.no_view_dependence:
         print("Diffuse map query directly  without specific-views...")
-        for pos, dirs in batchify(targets, directions, batch_size=args.batch_size, device=device, progress=False):
+        for pos, dirs in batchify(targets, directions, batch_size=chunk, device=device, progress=False):
             diffuse.append(model.sample_points(pos, dirs)[..., :3])
     else:
         print("Diffuse map query with view dependence...")
         ray_bounds = torch.tensor([0.0, args.view_disparity_max_bound], dtype=directions.dtype)
         ray_origins = targets - args.view_disparity * directions
-        for o, d in batchify(ray_origins, directions, batch_size=args.batch_size, device=device, progress=False):
+        for o, d in batchify(ray_origins, directions, batch_size=chunk, device=device, progress=False):
             diffuse.append(model.query((o, d, ray_bounds)).rgb_map)
     diffuse = torch.cat(diffuse, dim=0).cpu().numpy()
     export_obj(vertices.cpu(), triangles.cpu(), diffuse, normals.cpu(), os.path.join(args.save_dir, args.mesh_name))

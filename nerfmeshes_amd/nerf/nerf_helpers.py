@@ -91,23 +91,26 @@ def cast_to_disparity_image(tensor, white_background=False):
 
 def export_obj(vertices, triangles, diffuse, normals, filename):
     """nerf_helpers.py:86-111 text format: `v x y z [r g b]`, `vn x y z`, `f a//a b//b c//c` (1-based).
-    Numbers are written exactly as the reference's `"{}".format(tensor_element)` does: the shortest
-    repr of the fp32 value widened to a Python float."""
+    Numbers are written exactly as the reference's `"{}".format(tensor_element)` does: the shortest repr of
+    the fp32 value widened to a Python float.  (Bulk `tolist()` + one join instead of a Python-level write per
+    element: 2.3 M lines of a 480^3 mesh take seconds, not minutes.)"""
     def rows(x):
         if isinstance(x, torch.Tensor):
             x = x.detach().cpu().numpy()
-        return np.asarray(x)
+        return np.asarray(x).tolist()
 
     v, c, n, t = rows(vertices), rows(diffuse), rows(normals), rows(triangles)
     print("Writing to obj...")
+    nc = len(c)
+    out = []
+    for i, p in enumerate(v):
+        if nc > i:
+            q = c[i]
+            out.append(f"v {p[0]!r} {p[1]!r} {p[2]!r} {q[0]!r} {q[1]!r} {q[2]!r}")
+        else:
+            out.append(f"v {p[0]!r} {p[1]!r} {p[2]!r}")
+    out.extend(f"vn {p[0]!r} {p[1]!r} {p[2]!r}" for p in n)
+    out.extend("f" + "".join(f" {a + 1}//{a + 1}" for a in f) for f in t)
     with open(filename, "w") as fh:
-        out = []
-        for i in range(len(v)):
-            line = "v {} {} {}".format(*(float(a) for a in v[i]))
-            if len(c) > i:
-                line += " {} {} {}".format(*(float(a) for a in c[i]))
-            out.append(line)
-        out.extend("vn {} {} {}".format(*(float(a) for a in row)) for row in n)
-        out.extend("f" + "".join(" {}//{}".format(int(a) + 1, int(a) + 1) for a in row) for row in t)
         fh.write("\n".join(out) + ("\n" if out else ""))
     print(f"Finished writing to {filename} with {len(v)} vertices")

@@ -212,9 +212,28 @@ def case_buff(name):
     print(name, "hit rays", int(mask.sum()), "/", n, "acc", float(bundle.acc_map.mean()))
 
 
+def case_obj(name):
+    """(f)-1: the reference's OBJ text writer (nerf_helpers.py:86-111) on a tiny mesh."""
+    import contextlib, io
+    nerf, _ = ref_import.load()
+    g = torch.Generator().manual_seed(8)
+    v = torch.randn(7, 3, generator=g) * 3.3
+    n = torch.nn.functional.normalize(torch.randn(7, 3, generator=g), dim=-1)
+    c = torch.rand(5, 3, generator=g).numpy()          # fewer colours than vertices, as the writer allows
+    f = torch.randint(0, 7, (9, 3), generator=g).int()
+    path = os.path.join(HERE, name + ".obj")
+    with contextlib.redirect_stdout(io.StringIO()):
+        nerf.export_obj(v, f, c, n, path)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), vertices=v.numpy(), triangles=f.numpy(), diffuse=c, normals=n.numpy())
+    print(name, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if "--buff" in sys.argv:
+    if "--obj" in sys.argv:
+        case_obj("export_obj")
+    elif "--buff" in sys.argv:
         case_buff("buff_fern")
     else:
         main()
         case_buff("buff_fern")
+        case_obj("export_obj")

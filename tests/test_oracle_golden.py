@@ -139,3 +139,15 @@ def test_buff_tree_and_intersect_match_reference():
 
     assert inside(idx.numpy()) == 1.0
     assert inside(g["idx"]) < 0.5
+
+
+def test_export_obj_text_matches_reference(tmp_path):
+    """(f)-1: the OBJ text writer reproduces the reference's file byte for byte."""
+    import os
+    from nerfmeshes_amd.nerf.nerf_helpers import export_obj
+    g = load_golden("export_obj")
+    out = tmp_path / "m.obj"
+    export_obj(torch.from_numpy(g["vertices"]), torch.from_numpy(g["triangles"]), g["diffuse"],
+               torch.from_numpy(g["normals"]), str(out))
+    ref = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "export_obj.obj")).read()
+    assert out.read_text() == ref
