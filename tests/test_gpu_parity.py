@@ -332,3 +332,39 @@ def test_ndc_rays_on_gpu_tensors(ops):
         no, nd = ndc_rays(int(h), int(w), f, 1.0, o.expand(int(h), int(w), 3) * 0.3, d)
         _close(no, g[f"ndc_o{i}"], 2e-6, rtol=2e-6, what="ndc origins")
         _close(nd, g[f"ndc_d{i}"], 2e-6, rtol=2e-6, what="ndc directions")
+
+
+@pytest.mark.parametrize("rays", [1, 17, 2049])
+@pytest.mark.parametrize("nc,nf,kw", [
+    (8, 8, dict(hidden_size=128, num_layers=4, num_encoding_fn_xyz=6)),     # tiny.yaml's literal sizes (4x128, 8+8)
+    (16, 0, dict(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6)),      # coarse only
+    (64, 128, dict()),                                                        # lego
+])
+def test_render_sweep_vs_oracle(ops, rays, nc, nf, kw):
+    """Ragged ray counts (1 ray, not a multiple of the 128-sample workgroup tile, one more than the reference's
+    2048-ray chunk) x sample counts, per-ray origins and bounds given as (R,) tensors."""
+    spec = O.MLPSpec(**kw)
+    full = dict(num_layers=spec.num_layers, hidden_size=spec.hidden_size, skip_step=spec.skip_step,
+                num_encoding_fn_xyz=spec.num_encoding_fn_xyz, num_encoding_fn_dir=spec.num_encoding_fn_dir)
+    w = (S.make_scene_weights(**full) if not kw else
+         S.make_mlp_weights(23, density_gain=60.0, density_bias=0.5, **full))
+    mlp = ops.HipMLP(w, full, "cuda")
+    g = torch.Generator().manual_seed(rays * 7 + nc)
+    o = torch.tensor([[0.3, -0.2, 4.0]]) + 0.05 * torch.randn(rays, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.tensor([[0.0, 0.05, -1.0]]) + 0.2 * torch.randn(rays, 3, generator=g), dim=-1)
+    near = 2.0 + 0.1 * torch.rand(rays, generator=g)
+    far = 6.0 - 0.1 * torch.rand(rays, generator=g)
+    if rays == 1:
+        near, far = near.reshape(()), far.reshape(())          # 0-dim bounds, as unpacking a (2,) tensor gives
+    rs = O.RenderSpec(num_coarse=nc, num_fine=nf)
+    c, f = O.render(w, w if nf else None, spec, spec if nf else None, rs, o, d, near, far)
+    cb, fb = ops.render_rays(mlp, mlp if nf else None, o.cuda(), d.cuda(), near, far, torch.linspace(0, 1, nc),
+                             torch.linspace(0, 1, nf) if nf else None)
+    # the band-limited scene scales fc_alpha by 1e5: sigma carries ~1e-2 of absolute fp32 noise (DESIGN.md section 5)
+    _close(cb["rgb_map"], c["rgb_map"], 2e-4, what="coarse rgb")
+    _close(cb["weights"], c["weights"], 5e-4, what="coarse weights")
+    if nf:
+        acc = c["acc_map"].numpy()
+        good = ~((acc > 0) & (acc < 5e-3))
+        err = (fb["rgb_map"].cpu() - f["rgb_map"]).abs().max(-1).values.numpy()
+        assert err[good].max() < 2e-3 and np.median(err) < 1e-5, (err.max(), np.median(err))
