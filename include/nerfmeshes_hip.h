@@ -152,6 +152,81 @@ int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training path: the arithmetic of NeRFModel.training_step
+ * (src/models/model_nerf.py:88-151) -- forward with perturb / radiance noise / random resampling
+ * (src/nerf/modules.py:82-91, 171-184, 224-228) and what loss.backward() computes for
+ * FlexibleNeRFModel.forward (src/nerf/models.py:60-80) and VolumeRenderer.forward
+ * (src/nerf/modules.py:67-121).  Random numbers are always the CALLER's device tensors
+ * (torch.rand / torch.randn), so a run is reproducible from torch's generator state.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Re-pack the network from DEVICE tensors (the live nn.Parameter storages, nn.Linear layout) after an
+ * optimizer step: one gather kernel, asynchronous on `stream`, no host round trip.  Pointers as in
+ * nm_mlp_weights; freq_xyz / freq_dir are ignored (buffers, fixed at nm_mlp_create). */
+int nm_mlp_refresh(nm_mlp* mlp, const nm_mlp_weights* d_weights, void* stream);
+
+/* Activations recorded by the training forward, n = rays * samples, tiles = ceil(n / 16), L = num_layers,
+ * H = hidden_size.  Rows are the operands of the weight-gradient GEMMs (dW = delta^T @ rows). */
+typedef struct nm_mlp_tape {
+    float* d_h;          /* (L, n, H): [0] layer1 output; [1+i] relu(layers_xyz[i](.))               */
+    float* d_feat;       /* (n, H): relu(fc_feat(x))                                               */
+    float* d_v;          /* (n, H/2): relu(layers_dir[0](cat(feat, view)))                         */
+    uint64_t* d_mask_h;  /* (L, tiles, 64) ReLU masks of layers_xyz[0..L-2] and fc_feat, kernel-private layout */
+    uint64_t* d_mask_v;  /* (tiles, 64)                                                            */
+} nm_mlp_tape;
+
+/* dL/d(pre-activation) of every layer, written by nm_mlp_backward (same row layout as the tape). */
+typedef struct nm_mlp_deltas {
+    float* d_h;          /* (L, n, H): [0] at layer1's output; [1+i] at layers_xyz[i]'s pre-activation */
+    float* d_feat;       /* (n, H) at fc_feat's pre-activation                                       */
+    float* d_v;          /* (n, H/2) at layers_dir[0]'s pre-activation                               */
+    float* d_last;       /* (n, 4): at fc_rgb's output (pre-sigmoid) x3, at fc_alpha's output        */
+} nm_mlp_deltas;
+
+/* FlexibleNeRFModel.forward over ray samples (as nm_mlp_eval_rays) that also records the tape. */
+int nm_mlp_forward_train(nm_mlp* mlp, const float* d_origins, int origins_per_ray, const float* d_dirs,
+                         const float* d_t, int64_t rays, int32_t samples, const nm_mlp_tape* tape,
+                         float* d_radiance, void* stream);
+
+/* Back-propagation through the network: d_grad_radiance (n,4) = dL/d(sigmoid(rgb), sigma) and the
+ * forward's own d_radiance (n,4) -> deltas.  Weight gradients are then plain GEMMs the caller runs with
+ * its BLAS: e.g. grad(layers_xyz[i].weight) = deltas.d_h[1+i]^T @ tape.d_h[i] (@ enc_xyz for the skip
+ * columns), grad(bias) = column sums (nerfmeshes_amd/hip_ops.py:HipMLP.backward lists all of them). */
+int nm_mlp_backward(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
+                    const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream);
+
+/* PositionalEncoding.forward (src/nerf/modules.py:26-34) of the sample points / view directions as
+ * rows in the reference's column order: d_enc_xyz (n, 3+6*Fx), d_enc_dir (n, 3+6*Fd); either may be NULL. */
+int nm_encode_samples(nm_mlp* mlp, const float* d_origins, int origins_per_ray, const float* d_dirs,
+                      const float* d_t, int64_t rays, int32_t samples, float* d_enc_xyz, float* d_enc_dir,
+                      void* stream);
+
+/* RaySampleInterval.forward's stratified jitter (src/nerf/modules.py:171-184): d_rand (rays,samples) in [0,1). */
+int nm_perturb_intervals(const float* d_t, const float* d_rand, int64_t rays, int32_t samples, float* d_t_out,
+                         void* stream);
+
+/* VolumeRenderer.forward in training mode: sigma + d_noise (rays,samples; NULL = no noise) before the
+ * ReLU (src/nerf/modules.py:82-93), depth_map not zeroed (modules.py:108). */
+int nm_composite_train(const float* d_radiance, const float* d_t, const float* d_dirs, const float* d_noise,
+                       int64_t rays, int32_t samples, float attenuation_threshold, int white_background,
+                       const nm_bundle_out* out, void* stream);
+
+/* Upstream gradients of the bundle (any may be NULL = zero); disp_map / mask_weights are not differentiable here. */
+typedef struct nm_bundle_grads {
+    const float* d_rgb_map;   /* (rays,3)       */
+    const float* d_acc_map;   /* (rays,)        */
+    const float* d_depth_map; /* (rays,)        */
+    const float* d_weights;   /* (rays,samples) */
+} nm_bundle_grads;
+int nm_composite_backward(const float* d_radiance, const float* d_t, const float* d_dirs, const float* d_noise,
+                          int64_t rays, int32_t samples, int white_background, const nm_bundle_grads* grads,
+                          float* d_grad_radiance, void* stream);
+
+/* SamplePDF.forward with per-ray random u (src/nerf/modules.py:224-228): d_u (rays,fine). */
+int nm_sample_pdf_rand(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int32_t coarse,
+                       int32_t fine, float* d_t_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * BuFF voxel-tree sampler: TreeSampling.batch_ray_voxel_intersect, deterministic branch
  * (src/nerf/tree.py:215-343).  d_voxels (nvox,2,3) min/max corners; d_origins (1,3) or (rays,3);
  * d_u = linspace(0,1,samples).  Outputs: d_z (rays,samples) sorted depths, d_idx (rays,samples) int64

@@ -34,6 +34,18 @@ class BundleOut(C.Structure):
                                         "d_disp_map")]
 
 
+class MlpTape(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v")]
+
+
+class MlpDeltas(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_last")]
+
+
+class BundleGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("d_rgb_map", "d_acc_map", "d_depth_map", "d_weights")]
+
+
 class RenderCfg(C.Structure):
     _fields_ = [("num_coarse", C.c_int32), ("num_fine", C.c_int32), ("lindisp", C.c_int32),
                 ("white_background", C.c_int32), ("training", C.c_int32), ("attenuation_threshold", C.c_float)]
@@ -66,6 +78,21 @@ SIGNATURES = {
     "nm_render_rays": (C.c_int, [c_void_p, c_void_p, C.POINTER(RenderCfg), c_void_p, C.c_int, c_void_p, c_void_p,
                                  c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, c_void_p, C.POINTER(BundleOut),
                                  C.POINTER(BundleOut), c_void_p]),
+    # training path
+    "nm_mlp_refresh": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p]),
+    "nm_mlp_forward_train": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32,
+                                       C.POINTER(MlpTape), c_void_p, c_void_p]),
+    "nm_mlp_backward": (C.c_int, [c_void_p, C.c_int64, C.POINTER(MlpTape), c_void_p, c_void_p, C.POINTER(MlpDeltas),
+                                  c_void_p]),
+    "nm_encode_samples": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p,
+                                    c_void_p, c_void_p]),
+    "nm_perturb_intervals": (C.c_int, [c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p, c_void_p]),
+    "nm_composite_train": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int,
+                                     C.POINTER(BundleOut), c_void_p]),
+    "nm_composite_backward": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int,
+                                        C.POINTER(BundleGrads), c_void_p, c_void_p]),
+    "nm_sample_pdf_rand": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p,
+                                     c_void_p]),
     "nm_buff_intersect": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
                                     C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_mc_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

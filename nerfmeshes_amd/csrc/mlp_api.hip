@@ -45,10 +45,11 @@ static void encoding_steps(std::vector<StepCols>& out, int F, bool include_input
     out.push_back(id);
 }
 
-// Append the A-operand stream of one GEMM: for k-step s, block b of VW tiles, lane l, slot q:
-// W[16*(VW*b+q) + (l&15)][cols[s][l>>4]].
-static void pack_gemm(std::vector<float>& out, const float* W, int ld, int rows, int ntiles,
-                      const std::vector<StepCols>& steps) {
+// Append the A-operand stream of one GEMM as SOURCE INDICES (tensor id << 24 | element): for k-step s,
+// block b of VW tiles, lane l, slot q: W[16*(VW*b+q) + (l&15)][cols[s][l>>4]]; `transposed` addresses W^T
+// (the backward stream: output row n is an input column of the stored nn.Linear weight).
+static void pack_gemm(std::vector<int32_t>& out, int tensor, int ld, int rows, int ntiles,
+                      const std::vector<StepCols>& steps, bool transposed = false) {
     const int vw = ntiles >= 4 ? 4 : ntiles;
     for (const StepCols& c : steps)
         for (int b = 0; b < ntiles / vw; ++b)
@@ -56,8 +57,51 @@ static void pack_gemm(std::vector<float>& out, const float* W, int ld, int rows,
                 for (int q = 0; q < vw; ++q) {
                     const int n = 16 * (vw * b + q) + (l & 15);
                     const int k = c[l >> 4];
-                    out.push_back((n < rows && k >= 0) ? W[(size_t)n * ld + k] : 0.0f);
+                    const int64_t off = transposed ? (int64_t)k * ld + n : (int64_t)n * ld + k;
+                    out.push_back((n < rows && k >= 0) ? (int32_t)((tensor << 24) | (int32_t)off) : -1);
                 }
+}
+
+static void pack_range(std::vector<int32_t>& out, int tensor, int count) {
+    for (int i = 0; i < count; ++i) out.push_back((tensor << 24) | i);
+}
+
+static void pad_to(std::vector<int32_t>& v, size_t multiple) {
+    while (v.size() % multiple) v.push_back(-1);
+}
+
+// blob[i] = parameter element index[i] names (or 0): the whole packing, on the device
+__global__ void gather_parameters(const int32_t* __restrict__ index, WeightPtrs ptrs, float* __restrict__ blob,
+                                  int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t s = index[i];
+    blob[i] = s < 0 ? 0.0f : ptrs.p[s >> 24][s & 0xffffff];
+}
+
+static bool is_skip(const nm_mlp_desc& d, int i) {   // models.py:37,63
+    return i % d.skip_step == 0 && i > 0 && i != d.num_layers - 1;
+}
+
+static void weight_pointers(const nm_mlp_desc& d, const nm_mlp_weights& w, WeightPtrs& p) {
+    std::memset(&p, 0, sizeof(p));
+    p.p[T_L1W] = w.layer1_w; p.p[T_L1B] = w.layer1_b;
+    for (int i = 0; i < d.num_layers - 1; ++i) {
+        p.p[T_XYZ0 + 2 * i] = w.layers_xyz_w[i];
+        p.p[T_XYZ0 + 2 * i + 1] = w.layers_xyz_b[i];
+    }
+    p.p[T_FEATW] = w.fc_feat_w; p.p[T_FEATB] = w.fc_feat_b;
+    p.p[T_ALPHAW] = w.fc_alpha_w; p.p[T_ALPHAB] = w.fc_alpha_b;
+    p.p[T_DIRW] = w.layers_dir0_w; p.p[T_DIRB] = w.layers_dir0_b;
+    p.p[T_RGBW] = w.fc_rgb_w; p.p[T_RGBB] = w.fc_rgb_b;
+}
+
+static int launch_gather(const nm_mlp* m, const WeightPtrs& ptrs, hipStream_t stream) {
+    const int64_t n = (int64_t)m->blob_floats;
+    hipLaunchKernelGGL(gather_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m->d_index, ptrs,
+                       static_cast<float*>(m->d_blob), n);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ---- optional per-launch timing of the dominant kernel (bench.py's roofline leg) ---------------
@@ -145,42 +189,57 @@ int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, 
     const int dx = 6 * FX + (d.include_input_xyz ? 3 : 0), dd = 6 * FD + (d.include_input_dir ? 3 : 0);
     const int NT = H / 16, NTD = H / 32;
 
-    std::vector<StepCols> enc_x, enc_d, hid, hid_skip_enc, dir_steps;
+    std::vector<StepCols> enc_x, hid, hid_half, hid_skip_enc, dir_steps;
     encoding_steps(enc_x, FX, d.include_input_xyz != 0, 0);
     hidden_steps(hid, H, 0);
+    hidden_steps(hid_half, H / 2, 0);
     encoding_steps(hid_skip_enc, FX, d.include_input_xyz != 0, H);  // cat(hidden, xyz): models.py:65
     hidden_steps(dir_steps, H, 0);
     encoding_steps(dir_steps, FD, d.include_input_dir != 0, H);     // cat(feat, view): models.py:72
 
-    std::vector<float> stream;
-    std::vector<float> bias;
+    // ---- the blob as an index map: forward stream | biases | fc_alpha | fc_rgb | backward stream
+    std::vector<int32_t> index;
     uint32_t skip_mask = 0;
-    pack_gemm(stream, w->layer1_w, dx, H, NT, enc_x);
-    bias.insert(bias.end(), w->layer1_b, w->layer1_b + H);
+    pack_gemm(index, T_L1W, dx, H, NT, enc_x);
     for (int i = 0; i < L - 1; ++i) {
-        const bool skip = i % d.skip_step == 0 && i > 0 && i != L - 1;  // models.py:37,63
+        const bool skip = is_skip(d, i);
         const int ld = H + (skip ? dx : 0);
-        pack_gemm(stream, w->layers_xyz_w[i], ld, H, NT, hid);
+        pack_gemm(index, T_XYZ0 + 2 * i, ld, H, NT, hid);
         if (skip) {
-            pack_gemm(stream, w->layers_xyz_w[i], ld, H, NT, hid_skip_enc);
+            pack_gemm(index, T_XYZ0 + 2 * i, ld, H, NT, hid_skip_enc);
             skip_mask |= 1u << i;
         }
-        bias.insert(bias.end(), w->layers_xyz_b[i], w->layers_xyz_b[i] + H);
     }
-    pack_gemm(stream, w->fc_feat_w, H, H, NT, hid);
-    bias.insert(bias.end(), w->fc_feat_b, w->fc_feat_b + H);
-    pack_gemm(stream, w->layers_dir0_w, H + dd, H / 2, NTD, dir_steps);
-    bias.insert(bias.end(), w->layers_dir0_b, w->layers_dir0_b + H / 2);
-    stream.resize(stream.size() + 1024, 0.0f);  // DMA granularity padding (4 KiB)
-
+    pack_gemm(index, T_FEATW, H, H, NT, hid);
+    pack_gemm(index, T_DIRW, H + dd, H / 2, NTD, dir_steps);
+    index.resize(index.size() + 1024, -1);  // DMA granularity padding (4 KiB)
+    pad_to(index, 64);
+    const size_t off_bias = index.size();
+    pack_range(index, T_L1B, H);
+    for (int i = 0; i < L - 1; ++i) pack_range(index, T_XYZ0 + 2 * i + 1, H);
+    pack_range(index, T_FEATB, H);
+    pack_range(index, T_DIRB, H / 2);
+    pack_range(index, T_ALPHAB, 1);
+    pack_range(index, T_RGBB, 3);
+    pad_to(index, 64);
     // fc_alpha / fc_rgb as per-lane-group GEMV operands
-    std::vector<float> walpha(4 * (H / 4)), wrgb(3 * 4 * (H / 8));
+    const size_t off_wa = index.size();
     for (int g = 0; g < 4; ++g)
-        for (int s = 0; s < H / 4; ++s) walpha[g * (H / 4) + s] = w->fc_alpha_w[16 * (s >> 2) + 4 * g + (s & 3)];
+        for (int s = 0; s < H / 4; ++s) index.push_back((T_ALPHAW << 24) | (16 * (s >> 2) + 4 * g + (s & 3)));
+    pad_to(index, 64);
+    const size_t off_wr = index.size();
     for (int c = 0; c < 3; ++c)
         for (int g = 0; g < 4; ++g)
             for (int s = 0; s < H / 8; ++s)
-                wrgb[(c * 4 + g) * (H / 8) + s] = w->fc_rgb_w[(size_t)c * (H / 2) + 16 * (s >> 2) + 4 * g + (s & 3)];
+                index.push_back((T_RGBW << 24) | (c * (H / 2) + 16 * (s >> 2) + 4 * g + (s & 3)));
+    pad_to(index, 64);
+    // backward (delta propagation): the same layers transposed, in reverse order, hidden columns only
+    const size_t off_bwd = index.size();
+    pack_gemm(index, T_DIRW, H + dd, H, NT, hid_half, true);
+    pack_gemm(index, T_FEATW, H, H, NT, hid, true);
+    for (int i = L - 2; i >= 0; --i) pack_gemm(index, T_XYZ0 + 2 * i, H + (is_skip(d, i) ? dx : 0), H, NT, hid, true);
+    index.resize(index.size() + 1024, -1);
+    pad_to(index, 64);
 
     nm_mlp* m = new nm_mlp();
     std::memset(m, 0, sizeof(*m));
@@ -191,35 +250,70 @@ int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, 
     hipDeviceProp_t prop;
     NM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     m->num_cus = prop.multiProcessorCount;
-    auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t off_bias = align(stream.size() * 4), off_wa = off_bias + align(bias.size() * 4);
-    const size_t off_wr = off_wa + align(walpha.size() * 4);
-    m->blob_bytes = off_wr + align(wrgb.size() * 4);
+    m->blob_floats = index.size();
+    m->blob_bytes = index.size() * 4;
     NM_HIP_CHECK(hipMalloc(&m->d_blob, m->blob_bytes));
-    char* base = static_cast<char*>(m->d_blob);
-    NM_HIP_CHECK(hipMemcpy(base, stream.data(), stream.size() * 4, hipMemcpyHostToDevice));
-    NM_HIP_CHECK(hipMemcpy(base + off_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
-    NM_HIP_CHECK(hipMemcpy(base + off_wa, walpha.data(), walpha.size() * 4, hipMemcpyHostToDevice));
-    NM_HIP_CHECK(hipMemcpy(base + off_wr, wrgb.data(), wrgb.size() * 4, hipMemcpyHostToDevice));
+    NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->d_index), m->blob_bytes));
+    NM_HIP_CHECK(hipMemcpy(m->d_index, index.data(), m->blob_bytes, hipMemcpyHostToDevice));
+    const float* base = static_cast<const float*>(m->d_blob);
     MlpArgs& a = m->base;
-    a.wstream = base;
-    a.bias = reinterpret_cast<const float*>(base + off_bias);
-    a.walpha = reinterpret_cast<const float*>(base + off_wa);
-    a.wrgb = reinterpret_cast<const float*>(base + off_wr);
-    a.balpha = w->fc_alpha_b[0];
-    for (int c = 0; c < 3; ++c) a.brgb[c] = w->fc_rgb_b[c];
+    a.wstream = reinterpret_cast<const char*>(base);
+    a.bias = base + off_bias;
+    a.walpha = base + off_wa;
+    a.wrgb = base + off_wr;
     for (int f = 0; f < FX; ++f) a.bands_xyz[f] = w->freq_xyz[f];
     for (int f = 0; f < FD; ++f) a.bands_dir[f] = w->freq_dir[f];
     a.skip_mask = skip_mask;
+    m->bwd.wstream = reinterpret_cast<const char*>(base + off_bwd);
+    m->bwd.walpha = a.walpha;
+    m->bwd.wrgb = a.wrgb;
     m->flops_full = 2 * mlp_macs(d, false);
     m->flops_density = 2 * mlp_macs(d, true);
+
+    // ---- fill it from the host tensors: stage them on the device and run the same gather nm_mlp_refresh uses
+    std::vector<float> flat;
+    std::vector<size_t> offs(T_COUNT, 0);
+    auto stage = [&](int t, const float* src, size_t count) { offs[t] = flat.size(); flat.insert(flat.end(), src, src + count); };
+    stage(T_L1W, w->layer1_w, (size_t)H * dx); stage(T_L1B, w->layer1_b, H);
+    for (int i = 0; i < L - 1; ++i) {
+        stage(T_XYZ0 + 2 * i, w->layers_xyz_w[i], (size_t)H * (H + (is_skip(d, i) ? dx : 0)));
+        stage(T_XYZ0 + 2 * i + 1, w->layers_xyz_b[i], H);
+    }
+    stage(T_FEATW, w->fc_feat_w, (size_t)H * H); stage(T_FEATB, w->fc_feat_b, H);
+    stage(T_ALPHAW, w->fc_alpha_w, H); stage(T_ALPHAB, w->fc_alpha_b, 1);
+    stage(T_DIRW, w->layers_dir0_w, (size_t)(H / 2) * (H + dd)); stage(T_DIRB, w->layers_dir0_b, H / 2);
+    stage(T_RGBW, w->fc_rgb_w, (size_t)3 * (H / 2)); stage(T_RGBB, w->fc_rgb_b, 3);
+    float* d_flat = nullptr;
+    NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_flat), flat.size() * 4));
+    NM_HIP_CHECK(hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    WeightPtrs ptrs;
+    std::memset(&ptrs, 0, sizeof(ptrs));
+    ptrs.p[T_L1W] = d_flat + offs[T_L1W]; ptrs.p[T_L1B] = d_flat + offs[T_L1B];
+    for (int t = T_XYZ0; t < T_XYZ0 + 2 * (L - 1); ++t) ptrs.p[t] = d_flat + offs[t];
+    for (int t = T_FEATW; t < T_COUNT; ++t) ptrs.p[t] = d_flat + offs[t];
+    int rc = launch_gather(m, ptrs, nullptr);
+    if (rc == 0 && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("parameter gather failed"); rc = 1; }
+    (void)hipFree(d_flat);
+    if (rc) { nm_mlp_destroy(m); return rc; }
     *out = m;
     return 0;
+}
+
+int nm_mlp_refresh(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream) {
+    NM_REQUIRE(m && d_weights, "null argument");
+    WeightPtrs ptrs;
+    weight_pointers(m->desc, *d_weights, ptrs);
+    for (int t = 0; t < T_COUNT; ++t) {
+        const bool used = t < T_XYZ0 + 2 * (m->desc.num_layers - 1) || t >= T_FEATW;
+        NM_REQUIRE(!used || ptrs.p[t], "nm_mlp_refresh: missing tensor");
+    }
+    return launch_gather(m, ptrs, static_cast<hipStream_t>(stream));
 }
 
 void nm_mlp_destroy(nm_mlp* m) {
     if (!m) return;
     if (m->d_blob) (void)hipFree(m->d_blob);
+    if (m->d_index) (void)hipFree(m->d_index);
     delete m;
 }
 

@@ -1,0 +1,283 @@
+// Training path of the fused MLP for gfx950: what autograd does for
+//   /root/reference/src/models/model_nerf.py:88-151   NeRFModel.training_step (loss.backward() through
+//   /root/reference/src/nerf/models.py:60-80          FlexibleNeRFModel.forward)
+// split the MI355X way:
+//   * forward  = the SAME fused kernel as inference with TAPE=true: every post-activation leaves the registers once,
+//     as fp32 rows (operands of the weight-gradient GEMMs) plus one 64-bit ReLU mask per lane and layer.
+//   * backward = mlp_backward_kernel below: the delta of every layer, propagated through the TRANSPOSED weights with
+//     the same register-resident MFMA chain (D layout of one stage == B layout of the next; the transposed
+//     A-operand stream is a second index map over the same parameters, mlp_api.hip).  It reads 16 B + 8 B x layers
+//     per sample and writes the deltas once.
+//   * weight gradients dW = delta^T @ activation are plain (H x n) @ (n x H) GEMMs over those rows: library work
+//     (rocBLAS through torch.mm in hip_ops.py), per the "library GEMMs only for plain GEMMs" rule.
+// Roofline: MFMA.  557 056 MAC / sample for the 8x256 net (vs 593 408 forward).
+#include "nm_internal.h"
+#include "mlp_device.h"
+
+namespace nm {
+
+template <int NT>
+__device__ __forceinline__ void masked_operand(const f32x4 (&acc)[NT], uint64_t mask, float (&op)[4 * NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[4 * nt + r] = ((mask >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+}
+
+template <int H, int NW, int KCH>
+__global__ __launch_bounds__(NW * 64, 2) void mlp_backward_kernel(const MlpBwdArgs args, const int num_layers) {
+    using N = Net<H, 10, 4, KCH>;   // only the hidden-width constants are used here
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_walpha = reinterpret_cast<float*>(lds + 2 * N::LDSBUF);   // [4][H/4]
+    float* lds_wrgb = lds_walpha + H;                                    // [3][4][H/8]
+    for (int i = threadIdx.x; i < H; i += NW * 64) lds_walpha[i] = args.walpha[i];
+    for (int i = threadIdx.x; i < 3 * H / 2; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int L = num_layers;
+    constexpr int FIRST = (N::KD < KCH ? N::KD : KCH) * N::STEP;   // first chunk of the layers_dir.0^T stage
+
+    const int64_t wg_iters = (args.n + NW * 16 - 1) / (NW * 16);
+    int par = 0;
+    const char* gw = args.wstream;
+    if ((int64_t)blockIdx.x < wg_iters) stream_to_lds<NW>(gw, lds, FIRST, wave, lane);
+
+    for (int64_t it = blockIdx.x; it < wg_iters; it += gridDim.x) {
+        const bool has_next = it + gridDim.x < wg_iters;
+        const int64_t sample = (it * NW + wave) * 16 + col;
+        const bool valid = sample < args.n;
+        const int64_t sidx = valid ? sample : args.n - 1;
+        const int64_t tile = it * NW + wave;
+        const bool tile_ok = tile < args.tiles;
+        const uint64_t* mrow = args.mask_h + tile * 64 + lane;      // + layer * tiles * 64
+        const int64_t mstride = args.tiles * 64;
+        const float dummy[1] = {0.0f};
+        __syncthreads();   // LDS caches filled; first chunk resident (its DMA was issued one tile earlier)
+
+        // ---- head: sigmoid', fc_rgb^T on the VALU (models.py:75)
+        const f32x4 go = *reinterpret_cast<const f32x4*>(args.grad_out + 4 * sidx);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(args.radiance + 4 * sidx);
+        float drgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) drgb[ch] = go[ch] * (y[ch] * (1.0f - y[ch]));
+        const float dsigma = go[3];
+        if (valid && g == 0) {
+            const f32x4 o4 = {drgb[0], drgb[1], drgb[2], dsigma};
+            *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = o4;
+        }
+        const uint64_t mv = tile_ok ? args.mask_v[tile * 64 + lane] : 0;
+        float dv[N::KD];
+#pragma unroll
+        for (int s = 0; s < N::KD; ++s) {
+            float a = lds_wrgb[(0 * 4 + g) * N::KD + s] * drgb[0];
+            a = fmaf(lds_wrgb[(1 * 4 + g) * N::KD + s], drgb[1], a);
+            a = fmaf(lds_wrgb[(2 * 4 + g) * N::KD + s], drgb[2], a);
+            dv[s] = ((mv >> s) & 1u) ? a : 0.0f;
+        }
+        store_rows<N::NTD>(args.d_v, H / 2, sample, valid, dv, g);
+
+        f32x4 acc[N::NT];
+        float in[N::KH];
+        // ---- layers_dir.0^T (hidden columns): delta at relu(fc_feat) -> masked -> delta at fc_feat's output
+        {
+#pragma unroll
+            for (int nt = 0; nt < N::NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const uint64_t m = tile_ok ? mrow[(int64_t)(L - 1) * mstride] : 0;
+            gemm_stage<N::NT, N::KD, 0, NW, N::LDSBUF, KCH, true>(acc, dv, dummy, gw, gw + N::KD * N::STEP, N::LDSBUF, lds,
+                                                                 par, wave, lane);
+            gw += N::KD * N::STEP;
+            masked_operand<N::NT>(acc, m, in);
+            store_rows<N::NT>(args.d_feat, H, sample, valid, in, g);
+        }
+        // ---- fc_feat^T + fc_alpha^T: delta at the output of layers_xyz[L-2]
+        {
+            const float* wa = lds_walpha + g * (H / 4);
+#pragma unroll
+            for (int nt = 0; nt < N::NT; ++nt) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
+                acc[nt] = f32x4{w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+            }
+            const uint64_t m = tile_ok ? mrow[(int64_t)(L - 2) * mstride] : 0;
+            gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, true>(acc, in, dummy, gw, gw + N::KH * N::STEP, N::LDSBUF, lds,
+                                                                 par, wave, lane);
+            gw += N::KH * N::STEP;
+            masked_operand<N::NT>(acc, m, in);
+            store_rows<N::NT>(args.d_h + (int64_t)(L - 1) * args.n * H, H, sample, valid, in, g);
+        }
+        // ---- layers_xyz[i]^T, i = L-2 .. 0: delta at the input of layers_xyz[i] (x[i-1] post-ReLU, or layer1's output)
+#pragma unroll 1
+        for (int i = L - 2; i >= 0; --i) {
+#pragma unroll
+            for (int nt = 0; nt < N::NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            uint64_t m = ~uint64_t(0);
+            if (i > 0) m = tile_ok ? mrow[(int64_t)(i - 1) * mstride] : 0;
+            const char* tsrc = gw + N::KH * N::STEP;
+            int tbytes = N::LDSBUF;
+            if (i == 0) { tsrc = args.wstream; tbytes = has_next ? FIRST : 0; }
+            gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, true>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+            gw += N::KH * N::STEP;
+            masked_operand<N::NT>(acc, m, in);
+            store_rows<N::NT>(args.d_h + (int64_t)i * args.n * H, H, sample, valid, in, g);
+        }
+        gw = args.wstream;
+    }
+}
+
+// ---- positional encodings as rows, reference column order (operands of the layer1 / skip / view weight gradients)
+struct EncodeArgs {
+    const float* origins; const float* dirs; const float* t;
+    int64_t n; int32_t samples, origins_per_ray;
+    int32_t fx, fd, include_x, include_d;
+    float bands_xyz[MAX_FREQ_XYZ];
+    float bands_dir[MAX_FREQ_DIR];
+    float* enc_x; float* enc_d;
+};
+
+__device__ __forceinline__ void encode_row(float* row, const float (&x)[3], int F, int include, const float* bands) {
+    const int base = include ? 3 : 0;
+    if (include) { row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; }
+    for (int a = 0; a < 3 * F; ++a) {
+        float sv, cv;
+        sincosf(x[a / F] * bands[a % F], &sv, &cv);   // the same call, on the same product, as encode<>()
+        row[base + a] = sv;
+        row[base + 3 * F + a] = cv;
+    }
+}
+
+__global__ __launch_bounds__(256) void encode_samples_kernel(const EncodeArgs args) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.n) return;
+    const int64_t ray = i / args.samples;
+    const float t = args.t[i];
+    const float* o = args.origins + (args.origins_per_ray ? 3 * ray : 0);
+    float p[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = args.dirs[3 * ray + k];
+        const float dt = d[k] * t;
+        p[k] = o[k] + dt;
+    }
+    const int dx = 6 * args.fx + (args.include_x ? 3 : 0), dd = 6 * args.fd + (args.include_d ? 3 : 0);
+    if (args.enc_x) encode_row(args.enc_x + i * dx, p, args.fx, args.include_x, args.bands_xyz);
+    if (args.enc_d) encode_row(args.enc_d + i * dd, d, args.fd, args.include_d, args.bands_dir);
+}
+
+// ---- plan tables -------------------------------------------------------------------------------------------
+struct TrainPlan {
+    int H, FX, FD;
+    void (*forward)(const MlpArgs, const int, const int);
+};
+template <int H, int FX, int FD>
+static TrainPlan make_train_plan() {
+    return TrainPlan{H, FX, FD, &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true>};
+}
+static const TrainPlan g_train_plans[] = {
+    make_train_plan<256, 10, 4>(), make_train_plan<128, 10, 4>(), make_train_plan<64, 10, 4>(),
+    make_train_plan<256, 6, 4>(),  make_train_plan<128, 6, 4>(),  make_train_plan<64, 6, 4>(),
+};
+
+struct BwdPlan {
+    int H;
+    void (*backward)(const MlpBwdArgs, const int);
+};
+static const BwdPlan g_bwd_plans[] = {
+    {256, &mlp_backward_kernel<256, 8, KC>}, {128, &mlp_backward_kernel<128, 8, KC>}, {64, &mlp_backward_kernel<64, 8, KC>},
+};
+
+static unsigned persistent_grid(int64_t wg_iters, int num_cus) {
+    const int64_t resident = num_cus;   // one 8-wave workgroup per CU (2 waves / SIMD)
+    int64_t grid = wg_iters < resident * 4 ? wg_iters : resident * 4;
+    if (wg_iters > grid) {
+        const int64_t rounds = (wg_iters + grid - 1) / grid;
+        grid = (wg_iters + rounds - 1) / rounds;
+    }
+    return (unsigned)grid;
+}
+
+static int set_lds(const void* fn, int bytes) {
+    NM_REQUIRE(bytes <= 160 * 1024, "LDS budget exceeded");
+    NM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+}  // namespace nm
+
+using namespace nm;
+
+extern "C" {
+
+int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
+                         int64_t rays, int32_t samples, const nm_mlp_tape* tape, float* d_radiance, void* stream) {
+    NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
+    NM_REQUIRE(tape->d_h && tape->d_feat && tape->d_v && tape->d_mask_h && tape->d_mask_v, "incomplete tape");
+    const nm_mlp_desc& d = m->desc;
+    const TrainPlan* plan = nullptr;
+    for (const TrainPlan& p : g_train_plans)
+        if (p.H == d.hidden_size && p.FX == d.num_encoding_fn_xyz && p.FD == d.num_encoding_fn_dir) plan = &p;
+    NM_REQUIRE(plan, "no training kernel instantiated for this network shape");
+    MlpArgs a = m->base;
+    a.mode = MODE_RAYS;
+    a.a = d_origins; a.b = d_dirs; a.c = d_t;
+    a.origins_per_ray = origins_per_ray; a.samples = samples;
+    a.n = rays * samples; a.out = d_radiance;
+    if (a.n == 0) return 0;
+    a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
+    a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
+    a.tiles = (a.n + 15) / 16;
+    const int H = d.hidden_size, L = d.num_layers;
+    const int ring = 2 * KC * (H / 16) * 256;
+    const int lds_bytes = ring + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255);
+    if (int rc = set_lds((const void*)plan->forward, lds_bytes)) return rc;
+    const int64_t wg_iters = (a.n + 127) / 128;
+    hipLaunchKernelGGL(plan->forward, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(512), lds_bytes,
+                       static_cast<hipStream_t>(stream), a, L, 0);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
+                    const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream) {
+    NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && deltas && n >= 0, "bad argument");
+    NM_REQUIRE(tape->d_mask_h && tape->d_mask_v, "incomplete tape");
+    NM_REQUIRE(deltas->d_h && deltas->d_feat && deltas->d_v && deltas->d_last, "incomplete delta buffers");
+    if (n == 0) return 0;
+    const nm_mlp_desc& d = m->desc;
+    const BwdPlan* plan = nullptr;
+    for (const BwdPlan& p : g_bwd_plans)
+        if (p.H == d.hidden_size) plan = &p;
+    NM_REQUIRE(plan, "no backward kernel instantiated for this hidden size");
+    MlpBwdArgs a = m->bwd;
+    a.radiance = d_radiance; a.grad_out = d_grad_radiance;
+    a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
+    a.n = n; a.tiles = (n + 15) / 16;
+    a.d_h = deltas->d_h; a.d_feat = deltas->d_feat; a.d_v = deltas->d_v; a.d_last = deltas->d_last;
+    const int H = d.hidden_size;
+    const int lds_bytes = 2 * KC * (H / 16) * 256 + (((H + 3 * H / 2) * 4 + 255) & ~255);
+    if (int rc = set_lds((const void*)plan->backward, lds_bytes)) return rc;
+    const int64_t wg_iters = (n + 127) / 128;
+    hipLaunchKernelGGL(plan->backward, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(512), lds_bytes,
+                       static_cast<hipStream_t>(stream), a, (int)d.num_layers);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nm_encode_samples(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
+                      int64_t rays, int32_t samples, float* d_enc_xyz, float* d_enc_dir, void* stream) {
+    NM_REQUIRE(m && d_origins && d_dirs && d_t && rays >= 0 && samples > 0, "bad argument");
+    EncodeArgs a;
+    a.origins = d_origins; a.dirs = d_dirs; a.t = d_t;
+    a.n = rays * samples; a.samples = samples; a.origins_per_ray = origins_per_ray;
+    a.fx = m->desc.num_encoding_fn_xyz; a.fd = m->desc.num_encoding_fn_dir;
+    a.include_x = m->desc.include_input_xyz; a.include_d = m->desc.include_input_dir;
+    for (int f = 0; f < MAX_FREQ_XYZ; ++f) a.bands_xyz[f] = m->base.bands_xyz[f];
+    for (int f = 0; f < MAX_FREQ_DIR; ++f) a.bands_dir[f] = m->base.bands_dir[f];
+    a.enc_x = d_enc_xyz; a.enc_d = d_enc_dir;
+    if (a.n == 0) return 0;
+    hipLaunchKernelGGL(encode_samples_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

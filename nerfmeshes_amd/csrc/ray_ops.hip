@@ -90,8 +90,8 @@ __global__ void coarse_intervals_kernel(const float* __restrict__ u, const float
 template <int PER>
 __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ radiance,
                                                         const float* __restrict__ t, const float* __restrict__ dirs,
-                                                        int64_t rays, int samples, float thr, int white_bg,
-                                                        int training, nm_bundle_out out) {
+                                                        const float* __restrict__ noise, int64_t rays, int samples,
+                                                        float thr, int white_bg, int training, nm_bundle_out out) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= rays) return;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
             rad[q] = rr[s];
             float dist = (s + 1 < samples) ? (tr[s + 1] - tt[q]) : 1e10f;
             dist = dist * norm;
-            const float sig = fmaxf(rad[q][3] + 0.0f, 0.0f);
+            const float sig = fmaxf(rad[q][3] + (noise ? noise[ray * samples + s] : 0.0f), 0.0f);   // modules.py:82-93
             alpha[q] = 1.0f - expf(-sig * dist);
             local *= (double)((1.0f - alpha[q]) + 1e-10f);
         }
@@ -150,8 +150,8 @@ constexpr int PDF_MAX_COARSE = 256;
 constexpr int PDF_MAX_TOTAL = 512;
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ t, const float* __restrict__ weights,
-                                                         const float* __restrict__ u, int64_t rays, int coarse,
-                                                         int fine, float* __restrict__ t_out) {
+                                                         const float* __restrict__ u, int u_per_ray, int64_t rays,
+                                                         int coarse, int fine, float* __restrict__ t_out) {
     __shared__ float s_cdf[4][PDF_MAX_COARSE];
     __shared__ float s_bins[4][PDF_MAX_COARSE];
     __shared__ float s_all[4][PDF_MAX_TOTAL];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
 
     // invert: idx = searchsorted(cdf, u, right=True)
     for (int j = lane; j < fine; j += 64) {
-        const float uj = u[j];
+        const float uj = u[(u_per_ray ? ray * fine : 0) + j];   // modules.py:221-228: linspace, or rand per ray
         int lo = 0, hi = nb;             // first index with cdf[idx] > uj
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -229,6 +229,69 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     }
 }
 
+// ---- training-mode pieces -----------------------------------------------------------
+// Stratified jitter of the coarse depths (modules.py:171-184): lower + (upper - lower) * rand, with
+// mids = 0.5 * (t[k+1] + t[k]); the random numbers are the caller's (torch.rand on the device).
+__global__ void perturb_intervals_kernel(const float* __restrict__ t, const float* __restrict__ rnd, int64_t rays,
+                                         int samples, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rays * samples) return;
+    const int k = (int)(i % samples);
+    const float tk = t[i];
+    const float upper = k + 1 < samples ? 0.5f * (t[i + 1] + tk) : tk;
+    const float lower = k > 0 ? 0.5f * (tk + t[i - 1]) : tk;
+    const float span = upper - lower;
+    const float step = span * rnd[i];
+    out[i] = lower + step;
+}
+
+// Backward of VolumeRenderer.forward (modules.py:67-121) for the differentiable outputs the losses use:
+//   w_k = alpha_k * T_k,  T_k = prod_{j<k} (1 - alpha_j + 1e-10),  alpha_k = 1 - exp(-relu(sigma_k + noise_k) * dist_k)
+//   dL/dw_k = G_rgb . rgb_k + G_acc + G_depth * t_k + G_w[k] (- sum(G_rgb) with a white background)
+//   dL/dalpha_k = dL/dw_k * T_k - (sum_{j>k} dL/dw_j * w_j) / (1 - alpha_k + 1e-10)
+// One thread per ray, two sweeps (T_k and alpha_k are parked in the output rows between them).
+__global__ __launch_bounds__(64) void composite_backward_kernel(const float* __restrict__ radiance,
+                                                                const float* __restrict__ t,
+                                                                const float* __restrict__ dirs,
+                                                                const float* __restrict__ noise, int64_t rays, int samples,
+                                                                int white_bg, nm_bundle_grads g,
+                                                                float* __restrict__ grad_radiance) {
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= rays) return;
+    const float norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    const float* tr = t + ray * samples;
+    const f32x4* rr = reinterpret_cast<const f32x4*>(radiance) + ray * samples;
+    f32x4* out = reinterpret_cast<f32x4*>(grad_radiance) + ray * samples;
+    double run = 1.0;
+    for (int s = 0; s < samples; ++s) {
+        float dist = (s + 1 < samples) ? (tr[s + 1] - tr[s]) : 1e10f;
+        dist = dist * norm;
+        const float sig = fmaxf(rr[s][3] + (noise ? noise[ray * samples + s] : 0.0f), 0.0f);
+        const float alpha = 1.0f - expf(-sig * dist);
+        out[s] = f32x4{alpha, dist, 0.0f, (float)run};
+        run *= (double)((1.0f - alpha) + 1e-10f);
+    }
+    float gr = 0.0f, gg = 0.0f, gb = 0.0f;
+    if (g.d_rgb_map) { gr = g.d_rgb_map[3 * ray]; gg = g.d_rgb_map[3 * ray + 1]; gb = g.d_rgb_map[3 * ray + 2]; }
+    const float gacc = (g.d_acc_map ? g.d_acc_map[ray] : 0.0f) - (white_bg ? (gr + gg + gb) : 0.0f);
+    const float gdepth = g.d_depth_map ? g.d_depth_map[ray] : 0.0f;
+    float suffix = 0.0f;   // sum_{j>k} dL/dw_j * w_j
+    for (int s = samples - 1; s >= 0; --s) {
+        const f32x4 parked = out[s];
+        const float alpha = parked[0], dist = parked[1], T = parked[3];
+        const f32x4 rad = rr[s];
+        const float w = alpha * T;
+        float dw = (gr * rad[0] + gg * rad[1] + gb * rad[2]) + gacc + gdepth * tr[s];
+        if (g.d_weights) dw += g.d_weights[ray * samples + s];
+        const float keep = (1.0f - alpha) + 1e-10f;
+        const float dalpha = dw * T - suffix / keep;
+        suffix += dw * w;
+        const float raw = rad[3] + (noise ? noise[ray * samples + s] : 0.0f);
+        const float dsigma = raw > 0.0f ? dalpha * dist * (1.0f - alpha) : 0.0f;
+        out[s] = f32x4{w * gr, w * gg, w * gb, dsigma};
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 int launch_ray_bundle(const float* c2w, int height, int width, float focal, int64_t first, int64_t count, float* d_dirs,
                       hipStream_t stream) {
@@ -252,15 +315,15 @@ int launch_coarse_intervals(const float* d_u, const float* d_near, const float* 
     return 0;
 }
 
-int launch_composite(const float* d_radiance, const float* d_t, const float* d_dirs, int64_t rays, int samples, float thr,
-                     int white_bg, int training, const nm_bundle_out& out, hipStream_t stream) {
+int launch_composite(const float* d_radiance, const float* d_t, const float* d_dirs, const float* d_noise, int64_t rays,
+                     int samples, float thr, int white_bg, int training, const nm_bundle_out& out, hipStream_t stream) {
     if (rays <= 0) return 0;
     NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
     const dim3 grid((unsigned)((rays + 3) / 4)), block(256);
     const int per = (samples + 63) / 64;
 #define NM_COMPOSITE(P)                                                                                      \
-    hipLaunchKernelGGL(composite_kernel<P>, grid, block, 0, stream, d_radiance, d_t, d_dirs, rays, samples, thr, \
-                       white_bg, training, out)
+    hipLaunchKernelGGL(composite_kernel<P>, grid, block, 0, stream, d_radiance, d_t, d_dirs, d_noise, rays, samples, \
+                       thr, white_bg, training, out)
     switch (per) {
         case 1: NM_COMPOSITE(1); break;
         case 2: NM_COMPOSITE(2); break;
@@ -273,13 +336,13 @@ int launch_composite(const float* d_radiance, const float* d_t, const float* d_d
     return 0;
 }
 
-int launch_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int coarse, int fine,
-                      float* d_t_out, hipStream_t stream) {
+int launch_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int u_per_ray, int64_t rays, int coarse,
+                      int fine, float* d_t_out, hipStream_t stream) {
     if (rays <= 0) return 0;
     NM_REQUIRE(coarse >= 3 && coarse <= PDF_MAX_COARSE, "sample_pdf: num_coarse must be in [3, 256]");
     NM_REQUIRE(fine >= 1 && coarse + fine <= PDF_MAX_TOTAL, "sample_pdf: num_coarse + num_fine must be <= 512");
     hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, stream, d_t, d_weights, d_u,
-                       rays, coarse, fine, d_t_out);
+                       u_per_ray, rays, coarse, fine, d_t_out);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -310,14 +373,52 @@ int nm_composite(const float* d_radiance, const float* d_t, const float* d_dirs,
                  float attenuation_threshold, int white_background, int training, const nm_bundle_out* out,
                  void* stream) {
     NM_REQUIRE(d_radiance && d_t && d_dirs && out && rays >= 0, "bad argument");
-    return launch_composite(d_radiance, d_t, d_dirs, rays, samples, attenuation_threshold, white_background, training,
-                            *out, static_cast<hipStream_t>(stream));
+    return launch_composite(d_radiance, d_t, d_dirs, nullptr, rays, samples, attenuation_threshold, white_background,
+                            training, *out, static_cast<hipStream_t>(stream));
 }
 
 int nm_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int32_t coarse,
                   int32_t fine, float* d_t_out, void* stream) {
     NM_REQUIRE(d_t && d_weights && d_u && d_t_out && rays >= 0, "bad argument");
-    return launch_sample_pdf(d_t, d_weights, d_u, rays, coarse, fine, d_t_out, static_cast<hipStream_t>(stream));
+    return launch_sample_pdf(d_t, d_weights, d_u, 0, rays, coarse, fine, d_t_out, static_cast<hipStream_t>(stream));
+}
+
+int nm_perturb_intervals(const float* d_t, const float* d_rand, int64_t rays, int32_t samples, float* d_t_out,
+                         void* stream) {
+    NM_REQUIRE(d_t && d_rand && d_t_out && rays >= 0 && samples > 0, "bad argument");
+    const int64_t n = rays * samples;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(perturb_intervals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_t, d_rand, rays, samples, d_t_out);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nm_composite_train(const float* d_radiance, const float* d_t, const float* d_dirs, const float* d_noise,
+                       int64_t rays, int32_t samples, float attenuation_threshold, int white_background,
+                       const nm_bundle_out* out, void* stream) {
+    NM_REQUIRE(d_radiance && d_t && d_dirs && out && rays >= 0, "bad argument");
+    return launch_composite(d_radiance, d_t, d_dirs, d_noise, rays, samples, attenuation_threshold, white_background, 1,
+                            *out, static_cast<hipStream_t>(stream));
+}
+
+int nm_composite_backward(const float* d_radiance, const float* d_t, const float* d_dirs, const float* d_noise,
+                          int64_t rays, int32_t samples, int white_background, const nm_bundle_grads* grads,
+                          float* d_grad_radiance, void* stream) {
+    NM_REQUIRE(d_radiance && d_t && d_dirs && grads && d_grad_radiance && rays >= 0, "bad argument");
+    NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
+    if (rays == 0) return 0;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((rays + 63) / 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), d_radiance, d_t, d_dirs, d_noise, rays, samples, white_background,
+                       *grads, d_grad_radiance);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nm_sample_pdf_rand(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int32_t coarse,
+                       int32_t fine, float* d_t_out, void* stream) {
+    NM_REQUIRE(d_t && d_weights && d_u && d_t_out && rays >= 0, "bad argument");
+    return launch_sample_pdf(d_t, d_weights, d_u, 1, rays, coarse, fine, d_t_out, static_cast<hipStream_t>(stream));
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -355,15 +456,15 @@ int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
     if ((rc = nm_mlp_eval_rays(coarse, d_origins, origins_per_ray, d_dirs, t_c, rays, sc, rad_c, stream))) return rc;
     nm_bundle_out co = *coarse_out;
     if (!co.d_weights) co.d_weights = w_c;
-    if ((rc = launch_composite(rad_c, t_c, d_dirs, rays, sc, cfg->attenuation_threshold, cfg->white_background,
+    if ((rc = launch_composite(rad_c, t_c, d_dirs, nullptr, rays, sc, cfg->attenuation_threshold, cfg->white_background,
                                cfg->training, co, stream))) return rc;
     if (!fine) return 0;
     // sample_pdf -> intervals_to_ray_points -> model_fine -> volume_renderer (model_nerf.py:65-76)
     float* t_f = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sf * 4);
     float* rad_f = reinterpret_cast<float*>(ws);
-    if ((rc = launch_sample_pdf(t_c, co.d_weights, d_u_fine, rays, sc, cfg->num_fine, t_f, stream))) return rc;
+    if ((rc = launch_sample_pdf(t_c, co.d_weights, d_u_fine, 0, rays, sc, cfg->num_fine, t_f, stream))) return rc;
     if ((rc = nm_mlp_eval_rays(fine, d_origins, origins_per_ray, d_dirs, t_f, rays, sf, rad_f, stream))) return rc;
-    return launch_composite(rad_f, t_f, d_dirs, rays, sf, cfg->attenuation_threshold, cfg->white_background,
+    return launch_composite(rad_f, t_f, d_dirs, nullptr, rays, sf, cfg->attenuation_threshold, cfg->white_background,
                             cfg->training, *fine_out, stream);
 }
 

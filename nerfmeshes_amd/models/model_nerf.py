@@ -32,12 +32,13 @@ class NeRFModel(BaseModel):
         ray_origins, ray_directions, bounds = x
         near, far = bounds
         nerf_cfg = self.cfg.nerf.train if self.model_coarse.training else self.cfg.nerf.validation
-        if nerf_cfg.perturb or (self.volume_renderer.train_radiance_field_noise_std > 0 and self.training):
-            raise NotImplementedError("perturb / radiance noise (training mode) are not implemented on the HIP "
-                                      "path; call model.eval() (all shipped validation configs are deterministic)")
         dev = self.model_coarse.layer1.weight.device
         near = torch.as_tensor(near, dtype=torch.float32).reshape(-1)
         far = torch.as_tensor(far, dtype=torch.float32).reshape(-1)
+        vr = self.volume_renderer
+        noise_std = vr.train_radiance_field_noise_std if vr.training else vr.val_radiance_field_noise_std
+        if nerf_cfg.perturb or noise_std > 0.0 or self.model_coarse.needs_grad():
+            return self._forward_stochastic(ray_origins.to(dev), ray_directions, near, far, nerf_cfg, noise_std)
         fine = self.model_fine.hip() if self.model_fine is not None else None
         cb, fb = hip_ops.render_rays(
             self.model_coarse.hip(), fine, ray_origins.to(dev), ray_directions, near, far,
@@ -46,6 +47,40 @@ class NeRFModel(BaseModel):
             training=bool(self.volume_renderer.training),
             attenuation_threshold=self.volume_renderer.attenuation_threshold)
         return OutputBundle(**cb), (OutputBundle(**fb) if fb is not None else None)
+
+    def _forward_stochastic(self, origins, dirs, near, far, nerf_cfg, noise_std):
+        """The same chain stage by stage, differentiable in the networks' parameters, with the training-mode
+        randomness of RaySampleInterval (modules.py:171-184), VolumeRenderer (:82-91) and SamplePDF (:224-228);
+        the draws are torch's (device generator), the arithmetic is the HIP kernels'."""
+        from .. import train_ops
+        vr = self.volume_renderer
+        dev = self.model_coarse.layer1.weight.device
+        dirs = hip_ops._dev32(dirs, dev, "ray_directions").reshape(-1, 3)
+        origins = hip_ops._dev32(origins, dev, "ray_origins").reshape(-1, 3)
+        rays = dirs.shape[0]
+        t = hip_ops.coarse_intervals(self.sampler.point_intervals.reshape(-1).to(dev), near, far, rays,
+                                     lindisp=bool(nerf_cfg.lindisp))
+        if nerf_cfg.perturb:
+            t = train_ops.perturb_intervals(t, torch.rand(t.shape, dtype=t.dtype, device=dev))
+
+        def render(net, t):
+            radiance = train_ops.mlp_rays(net, origins, dirs, t)
+            noise = torch.randn(t.shape, dtype=t.dtype, device=dev) * noise_std if noise_std > 0.0 else None
+            b = train_ops.composite(radiance, t, dirs, noise, vr.attenuation_threshold, bool(vr.white_background))
+            if not vr.training:                                         # modules.py:108-109
+                b["depth_map"] = torch.where(b["acc_map"] < 1.0, torch.zeros_like(b["depth_map"]), b["depth_map"])
+            return OutputBundle(**b)
+
+        coarse = render(self.model_coarse, t)
+        if self.model_fine is None:
+            return coarse, None
+        w = coarse.weights.detach()
+        if nerf_cfg.perturb:                                            # det = (perturb == 0.0), modules.py:201
+            u = torch.rand(rays, self.sample_pdf.num_samples, dtype=t.dtype, device=dev)
+            t_fine = train_ops.sample_pdf_rand(t, w, u)
+        else:
+            t_fine = hip_ops.sample_pdf(t, w, self.sample_pdf.u)
+        return coarse, render(self.model_fine, t_fine)
 
     def query(self, ray_batch):
         coarse, fine = self.forward(ray_batch)

@@ -2,7 +2,7 @@
 (/root/reference/src/nerf/models.py:4-80); forward runs the fused gfx950 MLP kernel."""
 import torch
 
-from .. import hip_ops
+from .. import hip_ops, train_ops
 from .modules import PositionalEncoding
 
 
@@ -39,20 +39,30 @@ class FlexibleNeRFModel(torch.nn.Module):
         return i % self.skip_step == 0 and i > 0 and i != self.num_layers - 1
 
     def hip(self):
-        """Packed device copy of the current parameters (rebuilt when they change or move)."""
+        """Packed device copy of the current parameters: built once per device, then re-packed on the GPU
+        (nm_mlp_refresh, one gather kernel) whenever a parameter changed -- e.g. after every optimizer step."""
         params = list(self.parameters()) + list(self.buffers())
         dev = params[0].device
         if dev.type != "cuda":
             raise hip_ops._lib.HipLibraryError(
                 "FlexibleNeRFModel lives on %s: move it to the MI355X (.to('cuda')); there is no CPU path" % dev)
-        key = (dev, tuple((p.data_ptr(), p._version) for p in params))
-        if self._hip is None or key != self._hip_key:
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._hip is None or self._hip.device != dev:
             self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev)
-            self._hip_key = key
+        elif key != self._hip_key:
+            train_ops.refresh(self._hip, dict(self.named_parameters()))
+        self._hip_key = key
         return self._hip
 
+    def needs_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def forward(self, ray_points, ray_directions=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("the HIP path implements inference; call under torch.no_grad() / .eval() "
-                                      "(training backward is a later scope row)")
-        return self.hip().sample_points(ray_points, ray_directions if ray_directions is not None else ray_points)
+        dirs = ray_directions if ray_directions is not None else ray_points
+        if self.needs_grad():
+            # differentiable path: every point is a one-sample ray (origin = point, t = 0: o + d * 0 == o exactly)
+            pts = ray_points.reshape(-1, 3)
+            t = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
+            out = train_ops.mlp_rays(self, pts, dirs.expand_as(ray_points).reshape(-1, 3), t)
+            return out.reshape(*ray_points.shape[:-1], 4)
+        return self.hip().sample_points(ray_points, dirs)

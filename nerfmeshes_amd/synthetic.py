@@ -141,7 +141,8 @@ def make_scene_weights(seed=SCENE_SEED, **mlp_kwargs):
 
 def hparams(model="NeRFModel", hidden_size=256, num_layers=8, skip_step=4, num_encoding_fn_xyz=10,
             num_encoding_fn_dir=4, num_coarse=64, num_fine=128, use_fine=True, near=2.0, far=6.0,
-            white_background=False, lindisp=False, chunksize=2048, dataset_type="blender", use_ndc=False):
+            white_background=False, lindisp=False, chunksize=2048, dataset_type="blender", use_ndc=False,
+            train_perturb=False, train_noise_std=0.2):
     """Flat dotted-key experiment config in the layout Lightning writes to `hparams.yaml`
     (cf. /root/reference/pretrained/*/default/version_0/hparams.yaml); every key the hot
     path or the three scripts read is present."""
@@ -175,8 +176,8 @@ def hparams(model="NeRFModel", hidden_size=256, num_layers=8, skip_step=4, num_e
     for part in ("coarse", "fine"):
         for k, v in mlp.items():
             flat[f"models.{part}.{k}"] = v
-    for mode, noise in (("train", 0.2), ("validation", 0.0)):
-        flat.update({f"nerf.{mode}.chunksize": chunksize, f"nerf.{mode}.perturb": False,
+    for mode, noise, perturb in (("train", train_noise_std, train_perturb), ("validation", 0.0, False)):
+        flat.update({f"nerf.{mode}.chunksize": chunksize, f"nerf.{mode}.perturb": perturb,
                      f"nerf.{mode}.num_coarse": num_coarse, f"nerf.{mode}.num_fine": num_fine,
                      f"nerf.{mode}.radiance_field_noise_std": noise, f"nerf.{mode}.lindisp": lindisp})
     flat["nerf.train.num_random_rays"] = 2048

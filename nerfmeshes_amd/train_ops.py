@@ -1,0 +1,188 @@
+"""Training-mode host wrappers over the training entry points of the C ABI.
+
+What `loss.backward()` does in the reference's `NeRFModel.training_step`
+(/root/reference/src/models/model_nerf.py:88-151) is split here as the library is:
+
+* `mlp_rays`       -- FlexibleNeRFModel.forward over ray samples as a `torch.autograd.Function`:
+                      forward = the fused HIP kernel recording a tape, backward = the HIP delta kernel +
+                      one rocBLAS GEMM per weight matrix (dW = delta^T @ activation rows).
+* `composite`      -- VolumeRenderer.forward (noise + ReLU + alpha compositing) with a HIP backward.
+* `perturb_intervals`, `sample_pdf_rand` -- the stochastic depth samplers; random numbers are torch's.
+
+torch is plumbing (device memory, autograd bookkeeping, the optimizer, the BLAS handle); there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, hip_ops
+from ._lib import BundleGrads, BundleOut, MlpDeltas, MlpTape, MlpWeights, check
+from .hip_ops import _dev32, _ptr, _stream
+
+
+def param_names(num_layers):
+    names = ["layer1.weight", "layer1.bias"]
+    for i in range(num_layers - 1):
+        names += [f"layers_xyz.{i}.weight", f"layers_xyz.{i}.bias"]
+    return names + ["fc_feat.weight", "fc_feat.bias", "fc_alpha.weight", "fc_alpha.bias", "layers_dir.0.weight",
+                    "layers_dir.0.bias", "fc_rgb.weight", "fc_rgb.bias"]
+
+
+def refresh(mlp, params):
+    """Re-pack `mlp` (hip_ops.HipMLP) from live device tensors: dict name -> CUDA fp32 tensor."""
+    L = int(mlp.desc["num_layers"])
+    keep = {k: _dev32(params[k], mlp.device, k) for k in param_names(L)}
+    p = lambda k: C.c_void_p(keep[k].data_ptr())  # noqa: E731
+    xs_w = (C.c_void_p * (L - 1))(*[p(f"layers_xyz.{i}.weight") for i in range(L - 1)])
+    xs_b = (C.c_void_p * (L - 1))(*[p(f"layers_xyz.{i}.bias") for i in range(L - 1)])
+    w = MlpWeights(p("layer1.weight"), p("layer1.bias"), xs_w, xs_b, p("layers_dir.0.weight"), p("layers_dir.0.bias"),
+                   p("fc_alpha.weight"), p("fc_alpha.bias"), p("fc_rgb.weight"), p("fc_rgb.bias"),
+                   p("fc_feat.weight"), p("fc_feat.bias"), None, None)
+    check(_lib.load().nm_mlp_refresh(mlp.handle, C.byref(w), _stream()), "nm_mlp_refresh")
+
+
+def _per_ray(origins, rays):
+    return int(origins.reshape(-1, 3).shape[0] == rays and rays > 1)
+
+
+def forward_train(mlp, origins, dirs, t):
+    """-> (radiance (R,S,4), tape dict of device tensors)."""
+    lib = _lib.load()
+    origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
+    rays, samples = t.shape
+    n, H, L = rays * samples, int(mlp.desc["hidden_size"]), int(mlp.desc["num_layers"])
+    tiles = (n + 15) // 16
+    f32 = dict(dtype=torch.float32, device=mlp.device)
+    tape = dict(h=torch.empty(L, n, H, **f32), feat=torch.empty(n, H, **f32), v=torch.empty(n, H // 2, **f32),
+                mask_h=torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
+                mask_v=torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
+    out = torch.empty(rays, samples, 4, **f32)
+    ct = MlpTape(_ptr(tape["h"]), _ptr(tape["feat"]), _ptr(tape["v"]), _ptr(tape["mask_h"]), _ptr(tape["mask_v"]))
+    check(lib.nm_mlp_forward_train(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays, samples,
+                                   C.byref(ct), _ptr(out), _stream()), "nm_mlp_forward_train")
+    return out, tape
+
+
+def encode_samples(mlp, origins, dirs, t):
+    """PositionalEncoding rows of the sample points / view directions: ((n, dim_xyz), (n, dim_dir))."""
+    origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
+    rays, samples = t.shape
+    d = mlp.desc
+    dx = 6 * int(d["num_encoding_fn_xyz"]) + (3 if d.get("include_input_xyz", True) else 0)
+    dd = 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
+    ex = torch.empty(rays * samples, dx, dtype=torch.float32, device=mlp.device)
+    ed = torch.empty(rays * samples, dd, dtype=torch.float32, device=mlp.device)
+    check(_lib.load().nm_encode_samples(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
+                                        samples, _ptr(ex), _ptr(ed), _stream()), "nm_encode_samples")
+    return ex, ed
+
+
+def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
+    """Parameter gradients of sum(radiance * grad_radiance): dict keyed like FlexibleNeRFModel.state_dict()."""
+    lib = _lib.load()
+    radiance, grad_radiance = _dev32(radiance, mlp.device), _dev32(grad_radiance, mlp.device)
+    d = mlp.desc
+    L, H, skip_step = int(d["num_layers"]), int(d["hidden_size"]), int(d["skip_step"])
+    n = radiance.numel() // 4
+    f32 = dict(dtype=torch.float32, device=mlp.device)
+    dh, dfeat = torch.empty(L, n, H, **f32), torch.empty(n, H, **f32)
+    dv, dlast = torch.empty(n, H // 2, **f32), torch.empty(n, 4, **f32)
+    ct = MlpTape(_ptr(tape["h"]), _ptr(tape["feat"]), _ptr(tape["v"]), _ptr(tape["mask_h"]), _ptr(tape["mask_v"]))
+    cd = MlpDeltas(_ptr(dh), _ptr(dfeat), _ptr(dv), _ptr(dlast))
+    check(lib.nm_mlp_backward(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), _stream()),
+          "nm_mlp_backward")
+    enc_x, enc_d = encode_samples(mlp, origins, dirs, t)
+    h, feat, v = tape["h"], tape["feat"], tape["v"]
+    g = {"layer1.weight": dh[0].t() @ enc_x, "layer1.bias": dh[0].sum(0)}
+    for i in range(L - 1):
+        delta = dh[1 + i]
+        gw = delta.t() @ h[i]
+        if i % skip_step == 0 and i > 0 and i != L - 1:      # cat(x, xyz): models.py:64-65
+            gw = torch.cat((gw, delta.t() @ enc_x), dim=1)
+        g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, delta.sum(0)
+    g["fc_feat.weight"], g["fc_feat.bias"] = dfeat.t() @ h[L - 1], dfeat.sum(0)
+    g["fc_alpha.weight"], g["fc_alpha.bias"] = dlast[:, 3:4].t() @ h[L - 1], dlast[:, 3].sum().reshape(1)
+    g["layers_dir.0.weight"] = torch.cat((dv.t() @ feat, dv.t() @ enc_d), dim=1)   # cat(feat, view): models.py:72
+    g["layers_dir.0.bias"] = dv.sum(0)
+    g["fc_rgb.weight"], g["fc_rgb.bias"] = dlast[:, :3].t() @ v, dlast[:, :3].sum(0)
+    return g
+
+
+class _MLPRays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mlp, names, origins, dirs, t, *params):
+        radiance, tape = forward_train(mlp, origins, dirs, t)
+        ctx.mlp, ctx.names, ctx.tape = mlp, names, tape
+        ctx.save_for_backward(origins, dirs, t, radiance)
+        return radiance
+
+    @staticmethod
+    def backward(ctx, grad):
+        origins, dirs, t, radiance = ctx.saved_tensors
+        g = backward(ctx.mlp, ctx.tape, radiance, grad, origins, dirs, t)
+        ctx.tape = None
+        return (None, None, None, None, None) + tuple(g[k] for k in ctx.names)
+
+
+def mlp_rays(module, origins, dirs, t):
+    """Differentiable FlexibleNeRFModel.forward over (R,S) ray samples; `module` is the nn.Module mirror
+    (nerfmeshes_amd.nerf.models.FlexibleNeRFModel) whose parameters receive the gradients."""
+    mlp = module.hip()          # re-packed on the device if an optimizer step changed the parameters
+    names = param_names(int(mlp.desc["num_layers"]))
+    params = dict(module.named_parameters())
+    return _MLPRays.apply(mlp, names, origins, dirs, t, *[params[k] for k in names])
+
+
+def perturb_intervals(t, rnd):
+    t, rnd = _dev32(t), _dev32(rnd)
+    out = torch.empty_like(t)
+    check(_lib.load().nm_perturb_intervals(_ptr(t), _ptr(rnd), t.shape[0], t.shape[1], _ptr(out), _stream()),
+          "nm_perturb_intervals")
+    return out
+
+
+def sample_pdf_rand(t, weights, u):
+    """SamplePDF.forward with per-ray u (R, num_fine) -- modules.py:224-228."""
+    t, weights, u = _dev32(t), _dev32(weights), _dev32(u)
+    rays, coarse = t.shape
+    out = torch.empty(rays, coarse + u.shape[1], dtype=torch.float32, device=t.device)
+    check(_lib.load().nm_sample_pdf_rand(_ptr(t), _ptr(weights), _ptr(u), rays, coarse, u.shape[1], _ptr(out), _stream()),
+          "nm_sample_pdf_rand")
+    return out
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, radiance, t, dirs, noise, thr, white_bg):
+        rays, samples = t.shape
+        tensors, out = hip_ops._alloc_bundle(rays, samples, radiance.device)
+        check(_lib.load().nm_composite_train(_ptr(radiance), _ptr(t), _ptr(dirs), _ptr(noise), rays, samples, float(thr),
+                                             int(white_bg), C.byref(out), _stream()), "nm_composite_train")
+        ctx.white_bg = bool(white_bg)
+        ctx.noise = noise
+        ctx.save_for_backward(radiance, t, dirs)
+        ctx.set_materialize_grads(False)
+        res = tuple(tensors[k] for k in hip_ops.BUNDLE_FIELDS)
+        ctx.mark_non_differentiable(tensors["mask_weights"], tensors["disp_map"])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_weights, g_mask, g_acc, g_disp):
+        radiance, t, dirs = ctx.saved_tensors
+        rays, samples = t.shape
+        keep = [None if g is None else _dev32(g) for g in (g_rgb, g_acc, g_depth, g_weights)]
+        grads = BundleGrads(*[_ptr(g) for g in keep])
+        out = torch.empty_like(radiance)
+        check(_lib.load().nm_composite_backward(_ptr(radiance), _ptr(t), _ptr(dirs), _ptr(ctx.noise), rays, samples,
+                                                int(ctx.white_bg), C.byref(grads), _ptr(out), _stream()),
+              "nm_composite_backward")
+        return out, None, None, None, None, None
+
+
+def composite(radiance, t, dirs, noise=None, attenuation_threshold=1e-5, white_background=False):
+    """Differentiable VolumeRenderer.forward in training mode -> dict of the six bundle fields."""
+    radiance = radiance if radiance.is_contiguous() else radiance.contiguous()
+    t, dirs = _dev32(t), _dev32(dirs, radiance.device)
+    noise = None if noise is None else _dev32(noise, radiance.device)
+    res = _Composite.apply(radiance, t, dirs, noise, attenuation_threshold, white_background)
+    return dict(zip(hip_ops.BUNDLE_FIELDS, res))

@@ -102,11 +102,13 @@ def positional_encoding(x, n_freq, include_input=True, log_sampling=True):
     return torch.cat(parts, dim=-1)
 
 
-def mlp_forward(w, spec: MLPSpec, points, directions=None):
-    """R3b.  (N,3),(N,3) -> (N,4) = [sigmoid rgb | raw sigma]."""
+def mlp_forward(w, spec: MLPSpec, points, directions=None, keep_graph=False):
+    """R3b.  (N,3),(N,3) -> (N,4) = [sigmoid rgb | raw sigma].  keep_graph: use the tensors as given (any
+    dtype, autograd graph intact) -- the gradient checks of the training path differentiate through this."""
     lin = torch.nn.functional.linear
-    w = {k: _t(v) for k, v in w.items()}
-    points = _t(points)
+    conv = (lambda x: x) if keep_graph else _t
+    w = {k: conv(v) for k, v in w.items()}
+    points = conv(points)
     enc = positional_encoding(points, spec.num_encoding_fn_xyz, spec.include_input_xyz, spec.log_sampling_xyz)
     h = lin(enc, w["layer1.weight"], w["layer1.bias"])          # no activation (models.py:62)
     for i in range(spec.num_layers - 1):
@@ -117,7 +119,7 @@ def mlp_forward(w, spec: MLPSpec, points, directions=None):
         out = lin(h, w["fc_out.weight"], w["fc_out.bias"])
         out[..., :3] = torch.sigmoid(out[..., :3])
         return out
-    view = positional_encoding(_t(directions), spec.num_encoding_fn_dir, spec.include_input_dir,
+    view = positional_encoding(conv(directions), spec.num_encoding_fn_dir, spec.include_input_dir,
                                spec.log_sampling_dir)
     feat = torch.relu(lin(h, w["fc_feat.weight"], w["fc_feat.bias"]))
     sigma = lin(h, w["fc_alpha.weight"], w["fc_alpha.bias"])
@@ -156,13 +158,14 @@ def exclusive_cumprod(x):
     return c
 
 
-def composite(radiance, t, directions, rs: RenderSpec):
-    """R4.  radiance (R,S,4), t (R,S), directions (R,3) -> dict of maps."""
+def composite(radiance, t, directions, rs: RenderSpec, noise=None):
+    """R4.  radiance (R,S,4), t (R,S), directions (R,3) -> dict of maps.  `noise` (R,S): the training-mode
+    radiance noise, already scaled by its std (modules.py:82-91); differentiable in `radiance`."""
     big = torch.tensor([1e10])
     dists = torch.cat((t[..., 1:] - t[..., :-1], big.expand(t[..., :1].shape)), dim=-1)
     dists = dists * directions[..., None, :].norm(p=2, dim=-1)
     rgb = radiance[..., :3]
-    sigma = torch.relu(radiance[..., 3] + 0.0)
+    sigma = torch.relu(radiance[..., 3] + (0.0 if noise is None else noise))
     alpha = 1.0 - torch.exp(-sigma * dists)
     trans = exclusive_cumprod(1.0 - alpha + 1e-10)
     mask = (trans > rs.attenuation_threshold).float()
@@ -173,21 +176,32 @@ def composite(radiance, t, directions, rs: RenderSpec):
     disp = 1.0 / torch.max(1e-10 * torch.ones_like(depth), depth / acc)
     disp[torch.isnan(disp)] = 0
     if not rs.training:
-        depth[acc < 1.0] = 0                                     # modules.py:108-109
+        depth = torch.where(acc < 1.0, torch.zeros_like(depth), depth)   # modules.py:108-109
     if rs.white_background:
         rgb_map = rgb_map + (1.0 - acc[..., None])
     return dict(rgb_map=rgb_map, depth_map=depth, weights=weights, mask_weights=mask,
                 acc_map=acc, disp_map=disp)
 
 
-def sample_pdf_intervals(t, weights, num_fine):
-    """R5, deterministic u.  t (R,Sc), weights (R,Sc) -> sorted (R, Sc+num_fine)."""
+def perturb_intervals(t, t_rand):
+    """R1 with cfg.perturb (modules.py:171-184): stratified samples, t_rand (R,S) = the torch.rand draw."""
+    mids = 0.5 * (t[..., 1:] + t[..., :-1])
+    upper = torch.cat((mids, t[..., -1:]), dim=-1)
+    lower = torch.cat((t[..., :1], mids), dim=-1)
+    return lower + (upper - lower) * t_rand
+
+
+def sample_pdf_intervals(t, weights, num_fine, u=None):
+    """R5.  t (R,Sc), weights (R,Sc) -> sorted (R, Sc+num_fine).  u=None: deterministic linspace;
+    u (R,num_fine): the torch.rand draw of the perturb branch (modules.py:224-228)."""
     bins = 0.5 * (t[..., 1:] + t[..., :-1])
     w = weights[..., 1:-1] + 1e-5
     pdf = w / torch.sum(w, dim=-1, keepdim=True)
     cdf = torch.cumsum(pdf, dim=-1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
-    u = torch.linspace(0.0, 1.0, steps=num_fine).expand(list(cdf.shape[:-1]) + [num_fine]).contiguous()
+    if u is None:
+        u = torch.linspace(0.0, 1.0, steps=num_fine).expand(list(cdf.shape[:-1]) + [num_fine])
+    u = u.contiguous()
     cdf = cdf.contiguous()
     idx = torch.searchsorted(cdf, u, right=True)
     lo = torch.max(torch.zeros_like(idx), idx - 1)

@@ -1,0 +1,249 @@
+"""Training path on the MI355X against torch autograd over the CPU oracle.
+
+The reference trains through torch autograd (model_nerf.py:88-151); the oracle's functions are the same torch ops,
+so `torch.autograd` over them in fp64 is the ground-truth gradient and in fp32 the reference's own noise floor.
+Tolerances are relative to each tensor's largest entry (fp32 sums over up to 1e4 samples in a different order)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import O, S
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
+    dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4),
+    dict(num_layers=3, hidden_size=128, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4),   # no skip layer
+]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nerfmeshes_amd import hip_ops
+    return hip_ops
+
+
+@pytest.fixture(scope="module")
+def T():
+    from nerfmeshes_amd import train_ops
+    return train_ops
+
+
+def _weights(kw, seed=5):
+    w = S.make_mlp_weights(seed, density_gain=30.0, density_bias=0.3, **kw)
+    return {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in w.items()}
+
+
+def _rays(rays, samples, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([[0.2, -0.1, 3.5]]) + 0.1 * torch.randn(rays, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.tensor([[0.0, 0.1, -1.0]]) + 0.3 * torch.randn(rays, 3, generator=g), dim=-1)
+    t = torch.sort(2.0 + 4.0 * torch.rand(rays, samples, generator=g), dim=-1).values
+    return o, d, t
+
+
+def _rel(got, ref):
+    ref = ref.detach().to(torch.float64).cpu()
+    got = got.detach().to(torch.float64).cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _oracle_grads(w, spec, o, d, t, grad_out, dtype):
+    wd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in w.items() if "frequency" not in k}
+    pts = O.ray_points(t.to(dtype), d.to(dtype), o.to(dtype)).reshape(-1, 3)
+    dirs = d.to(dtype)[:, None, :].expand(-1, t.shape[1], -1).reshape(-1, 3)
+    out = O.mlp_forward(wd, spec, pts, dirs, keep_graph=True)
+    (out * grad_out.to(dtype).reshape(-1, 4)).sum().backward()
+    return out.detach(), {k: v.grad for k, v in wd.items()}
+
+
+@pytest.mark.parametrize("kw", SHAPES, ids=["4x64", "8x256", "3x128"])
+def test_refresh_equals_create(ops, T, kw):
+    """nm_mlp_refresh (device gather from live tensors) == nm_mlp_create from the same values, bit for bit."""
+    a, b = _weights(kw, 5), _weights(kw, 6)
+    m_a, m_b = ops.HipMLP(a, kw, "cuda"), ops.HipMLP(b, kw, "cuda")
+    p = torch.randn(1000, 3).cuda()
+    before = m_a.sample_points(p, p).clone()
+    T.refresh(m_a, {k: v.cuda() for k, v in b.items()})
+    after = m_a.sample_points(p, p)
+    assert not torch.equal(before, after)
+    assert torch.equal(after, m_b.sample_points(p, p))
+
+
+@pytest.mark.parametrize("kw", SHAPES, ids=["4x64", "8x256", "3x128"])
+@pytest.mark.parametrize("rays,samples", [(37, 9), (128, 16)])
+def test_mlp_tape_and_backward_vs_autograd(ops, T, kw, rays, samples):
+    spec = O.MLPSpec(**kw)
+    w = _weights(kw)
+    mlp = ops.HipMLP(w, kw, "cuda")
+    o, d, t = _rays(rays, samples, rays)
+    g = torch.Generator().manual_seed(1)
+    grad_out = torch.randn(rays, samples, 4, generator=g)
+
+    rad, tape = T.forward_train(mlp, o.cuda(), d.cuda(), t.cuda())
+    assert torch.equal(rad, mlp.eval_rays(o.cuda(), d.cuda(), t.cuda())), "the taping kernel must not change the output"
+    ref32, g32 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float32)
+    ref64, g64 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float64)
+    assert _rel(rad.reshape(-1, 4), ref64) < max(2e-5, 4 * _rel(ref32, ref64))   # fp32 sin/cos of x * 2^9
+
+    # the tape rows are the network's activations (checked on the last trunk layer and the view layer)
+    n, L = rays * samples, kw["num_layers"]
+    assert tape["h"].shape == (L, n, kw["hidden_size"])
+    enc_x, enc_d = T.encode_samples(mlp, o.cuda(), d.cuda(), t.cuda())
+    pts = O.ray_points(t, d, o).reshape(-1, 3)
+    ref_enc = O.positional_encoding(pts, kw["num_encoding_fn_xyz"])
+    assert _rel(enc_x, ref_enc) < 1e-6
+    h0 = torch.nn.functional.linear(ref_enc, w["layer1.weight"], w["layer1.bias"])
+    assert _rel(tape["h"][0], h0) < 1e-5
+    assert float(tape["h"][1:].min()) >= 0.0 and float(tape["feat"].min()) >= 0.0 and float(tape["v"].min()) >= 0.0
+
+    got = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
+    worst = {}
+    for k, ref in g64.items():
+        assert got[k].shape == ref.shape, k
+        worst[k] = (_rel(got[k], ref), _rel(g32[k], ref))
+    bad = {k: v for k, v in worst.items() if v[0] > max(2e-4, 20 * v[1])}
+    assert not bad, f"gradient mismatch (ours, torch-fp32) relative to fp64 autograd: {bad}"
+
+
+@pytest.mark.parametrize("rays,samples,white", [(5, 7, False), (64, 64, False), (33, 192, True)])
+def test_composite_forward_backward_vs_autograd(ops, T, rays, samples, white):
+    g = torch.Generator().manual_seed(samples)
+    rad = torch.cat((torch.rand(rays, samples, 3, generator=g), 3.0 * torch.randn(rays, samples, 1, generator=g)), -1)
+    _, d, t = _rays(rays, samples, 3)
+    noise = torch.randn(rays, samples, generator=g)
+    G = dict(rgb_map=torch.randn(rays, 3, generator=g), acc_map=torch.randn(rays, generator=g),
+             depth_map=torch.randn(rays, generator=g), weights=torch.randn(rays, samples, generator=g))
+    rs = O.RenderSpec(num_coarse=samples, num_fine=0, white_background=white, training=True)
+
+    def loss_of(bundle, dtype):
+        return sum((bundle[k] * G[k].to(dtype)).sum() for k in G)
+
+    r64 = rad.double().requires_grad_(True)
+    b64 = O.composite(r64, t.double(), d.double(), rs, noise=noise.double())
+    loss_of(b64, torch.float64).backward()
+
+    r_gpu = rad.cuda().requires_grad_(True)
+    b = T.composite(r_gpu, t.cuda(), d.cuda(), noise.cuda(), rs.attenuation_threshold, white)
+    b32 = O.composite(rad, t, d, rs, noise=noise)
+    for k in ("rgb_map", "acc_map", "depth_map", "weights"):
+        assert _rel(b[k], b32[k]) < 2e-6, k
+    sum((b[k] * G[k].cuda()).sum() for k in G).backward()
+    assert _rel(r_gpu.grad, r64.grad) < 5e-5
+    # rgb_map-only loss (the reference's): the other upstream gradients are absent, not zero tensors
+    r2 = rad.cuda().requires_grad_(True)
+    (T.composite(r2, t.cuda(), d.cuda(), noise.cuda(), rs.attenuation_threshold, white)["rgb_map"] ** 2).sum().backward()
+    r64b = rad.double().requires_grad_(True)
+    (O.composite(r64b, t.double(), d.double(), rs, noise=noise.double())["rgb_map"] ** 2).sum().backward()
+    assert _rel(r2.grad, r64b.grad) < 5e-5
+
+
+def test_stochastic_samplers_match_the_oracle_given_the_draws(ops, T):
+    g = torch.Generator().manual_seed(9)
+    rays, nc, nf = 333, 64, 128
+    t = O.coarse_intervals(torch.tensor(2.0), torch.tensor(6.0), nc, rays).contiguous()
+    rnd = torch.rand(rays, nc, generator=g)
+    tp = T.perturb_intervals(t.cuda(), rnd.cuda())
+    ref = O.perturb_intervals(t, rnd)
+    assert torch.equal(tp.cpu(), ref)
+    weights = torch.rand(rays, nc, generator=g) ** 4
+    u = torch.rand(rays, nf, generator=g)
+    got = T.sample_pdf_rand(ref.cuda(), weights.cuda(), u.cuda()).cpu()
+    want = O.sample_pdf_intervals(ref, weights, nf, u=u)
+    assert got.shape == want.shape and bool((got[:, 1:] >= got[:, :-1]).all())
+    # same multiset of depths up to the round-off of (u - cdf) / denom in nearly empty bins
+    assert float((got - want).abs().max()) < 2e-3 and float((got - want).abs().median()) == 0.0
+
+
+def _model(cfg_kw, seed=0):
+    from nerfmeshes_amd import models
+    from nerfmeshes_amd.nerf import CfgNode
+    cfg = CfgNode(S.hparams(**cfg_kw))
+    torch.manual_seed(seed)
+    return models.NeRFModel(cfg).cuda()
+
+
+def test_end_to_end_loss_gradients_vs_oracle_autograd():
+    """NeRFModel.forward in train() mode, loss as training_step's (coarse + fine MSE), backward: gradients of all
+    54 parameter tensors against fp64 autograd through the oracle on the SAME sample depths."""
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    model = _model(dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw))
+    with torch.no_grad():     # a scene with visible structure: scale sigma
+        for net in (model.model_coarse, model.model_fine):
+            net.fc_alpha.weight.mul_(40.0)
+    model.train()
+    rays = 257
+    o, d, _ = _rays(rays, 2, 11)
+    target = torch.rand(rays, 3, generator=torch.Generator().manual_seed(2))
+    bounds = torch.tensor([2.0, 6.0])
+    coarse, fine = model((o[:1].cuda(), d.cuda(), bounds))
+    loss = torch.nn.functional.mse_loss(coarse.rgb_map, target.cuda()) + torch.nn.functional.mse_loss(fine.rgb_map, target.cuda())
+    loss.backward()
+
+    spec = O.MLPSpec(**kw)
+    rs = O.RenderSpec(num_coarse=16, num_fine=16, training=True)
+    total, grads = 0.0, {}
+    t_c = O.coarse_intervals(2.0, 6.0, 16, rays)
+    t_f = O.sample_pdf_intervals(t_c, coarse.weights.detach().cpu(), 16)
+    for name, net, t in (("model_coarse", model.model_coarse, t_c), ("model_fine", model.model_fine, t_f)):
+        wd = {k: v.detach().double().cpu().requires_grad_(True) for k, v in net.named_parameters()}
+        pts = O.ray_points(t.double(), d.double(), o[:1].double()).reshape(-1, 3)
+        dirs = d.double()[:, None, :].expand(-1, t.shape[1], -1).reshape(-1, 3)
+        rad = O.mlp_forward(wd, spec, pts, dirs, keep_graph=True).reshape(rays, -1, 4)
+        b = O.composite(rad, t.double(), d.double(), rs)
+        l = torch.nn.functional.mse_loss(b["rgb_map"], target.double())
+        l.backward()
+        total += float(l.detach())
+        grads[name] = {k: v.grad for k, v in wd.items()}
+    assert abs(float(loss) - total) < 1e-5 * max(1.0, total)
+    for name, net in (("model_coarse", model.model_coarse), ("model_fine", model.model_fine)):
+        for k, p in net.named_parameters():
+            assert p.grad is not None, (name, k)
+            assert _rel(p.grad, grads[name][k]) < 5e-4, (name, k, _rel(p.grad, grads[name][k]))
+
+
+def test_adam_steps_reduce_the_loss_and_eval_follows_the_new_weights():
+    """A few optimizer steps on one ray batch: the loss falls, and the inference path (nm_render_rays) sees the
+    updated parameters (device re-pack) -- it equals a model rebuilt from the new state_dict."""
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw)
+    model = _model(hp, seed=3)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    o, d, _ = _rays(512, 2, 4)
+    target = (0.5 + 0.5 * torch.sin(7.0 * d)).cuda()
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        c, f = model(batch)
+        loss = torch.nn.functional.mse_loss(c.rgb_map, target) + torch.nn.functional.mse_loss(f.rgb_map, target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.7 * losses[0], losses
+    model.eval()
+    with torch.no_grad():
+        got = model.query(batch).rgb_map
+    fresh = _model(hp, seed=99)
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh.query(batch).rgb_map
+    assert torch.equal(got, want)
+
+
+def test_perturb_and_noise_are_seeded_by_torch():
+    hp = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4, num_coarse=16,
+              num_fine=16, train_perturb=True, train_noise_std=0.2)
+    model = _model(hp, seed=1)
+    model.train()
+    o, d, _ = _rays(100, 2, 8)
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            outs.append(model(batch)[1].rgb_map.clone())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
