@@ -95,7 +95,7 @@ class BaseModel(_Base):
         results = self.get_model().forward(points, rays, **kwargs)
         return results[0] if isinstance(results, tuple) else results
 
-    # ---- training-side hooks kept for API compatibility (not accelerated; see DESIGN.md scope) ----
+    # ---- training-side hooks (model_base.py:150-187); NeRFModel implements training_step / validation_step ----
     def get_scheduler(self, optimizer):
         gamma, step_size = self.cfg.scheduler.options.gamma, self.cfg.scheduler.options.step_size
         return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda step: gamma ** (step / step_size))
@@ -109,7 +109,13 @@ class BaseModel(_Base):
         return [optimizer], [{"scheduler": scheduler, "interval": "step", "frequency": 1}]
 
     def training_step(self, ray_batch, batch_idx):
-        raise NotImplementedError("training (backward pass) is not part of the HIP hot path built so far")
+        raise NotImplementedError("training_step is implemented for NeRFModel; BuFF training needs the tree "
+                                  "maintenance rows (SURVEY.md 8(f) rank 3)")
+
+    def validation_epoch_end(self, outputs):
+        """model_base.py:75-103 without the pytorch3d chamfer branch: the mean of every logged value."""
+        log = {k: torch.stack([torch.as_tensor(o["log"][k]) for o in outputs]).mean() for k in outputs[0]["log"]}
+        return {"log": log, "val_loss": torch.stack([torch.as_tensor(o["val_loss"]) for o in outputs]).mean()}
 
     def check_early_stopping(self, rgb):
         exp = self.cfg.experiment

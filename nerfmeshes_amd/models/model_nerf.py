@@ -3,7 +3,9 @@ import torch
 
 from .. import hip_ops
 from ..nerf import RaySampleInterval, SamplePDF, models as nerf_models
+from ..data import DataBundle
 from ..nerf.modules import OutputBundle
+from ..nerf.nerf_helpers import cast_to_image
 from .model_base import BaseModel
 
 
@@ -85,6 +87,79 @@ class NeRFModel(BaseModel):
     def query(self, ray_batch):
         coarse, fine = self.forward(ray_batch)
         return fine if fine is not None else coarse
+
+    def _chunks(self, bundle, chunk):
+        """The reference's manual batching (model_nerf.py:93-112): slices of `chunk` rays; origins are shared
+        unless the rays are in NDC.  Tensors already in GPU memory stay there (no host round trip per chunk)."""
+        dev = self.device
+        origins, dirs, bounds = bundle.ray_origins.to(dev), bundle.ray_directions.to(dev), bundle.ray_bounds
+        targets = bundle.ray_targets.to(dev)
+        for i in range(0, targets.shape[0], chunk):
+            sl = slice(i, i + chunk)
+            yield (origins[sl] if self.cfg.dataset.use_ndc else origins, dirs[sl], bounds), targets[sl]
+
+    def _current_lr(self):
+        trainer = getattr(self, "trainer", None)
+        try:
+            return trainer.optimizers[0].param_groups[0]["lr"]
+        except (AttributeError, IndexError, TypeError):
+            return self.cfg.optimizer.lr
+
+    def training_step(self, ray_batch, batch_idx):
+        """model_nerf.py:88-151: loss = MSE(coarse) + MSE(fine) averaged over the chunks with the reference's
+        float `batch_count`; the returned loss carries the autograd graph of the HIP forward (train_ops)."""
+        bundle = DataBundle.deserialize(ray_batch).to_ray_batch()
+        chunk = self.cfg.nerf.train.chunksize
+        batch_count = bundle.ray_targets.shape[0] / chunk
+        coarse_loss, fine_loss = 0, 0
+        for rays, target in self._chunks(bundle, chunk):
+            coarse, fine = self.forward(rays)
+            coarse_loss += self.loss(coarse.rgb_map, target)
+            self.check_early_stopping(coarse.rgb_map)
+            if self.model_fine is not None:
+                fine_loss += self.loss(fine.rgb_map, target)
+                self.check_early_stopping(fine.rgb_map)
+        coarse_loss /= batch_count
+        log = {"train/coarse_loss": coarse_loss, "train/coarse_psnr": self.criterion_psnr(coarse_loss)}
+        loss = coarse_loss
+        if self.cfg.models.use_fine:
+            fine_loss /= batch_count
+            loss = loss + fine_loss
+            log.update({"train/fine_loss": fine_loss, "train/fine_psnr": self.criterion_psnr(fine_loss)})
+        return {"loss": loss, "log": {"train/loss": loss, **log, "train/lr": self._current_lr()}}
+
+    def validation_step(self, image_ray_batch, batch_idx):
+        """model_nerf.py:153-222: one whole image in validation chunks; images go to the logger if one is attached."""
+        bundle = DataBundle.deserialize(image_ray_batch).to_ray_batch()
+        chunk = self.cfg.nerf.validation.chunksize
+        batch_count = bundle.ray_targets.shape[0] / chunk
+        coarse_loss, fine_loss, rgb_c, rgb_f = 0, 0, [], []
+        for rays, target in self._chunks(bundle, chunk):
+            coarse, fine = self.forward(rays)
+            coarse_loss += self.loss(coarse.rgb_map, target)
+            rgb_c.append(coarse.rgb_map)
+            if self.model_fine is not None:
+                fine_loss += self.loss(fine.rgb_map, target)
+                rgb_f.append(fine.rgb_map)
+        coarse_loss /= batch_count
+        loss = coarse_loss
+        log = {"validation/coarse_loss": coarse_loss, "validation/coarse_psnr": self.criterion_psnr(coarse_loss)}
+        images = {"validation/rgb_coarse/": torch.cat(rgb_c, 0)}
+        if self.model_fine is not None:
+            fine_loss /= batch_count
+            loss = loss + fine_loss
+            log.update({"validation/fine_loss": fine_loss, "validation/fine_psnr": self.criterion_psnr(fine_loss)})
+            images["validation/rgb_fine/"] = torch.cat(rgb_f, 0)
+        experiment = getattr(getattr(self, "logger", None), "experiment", None)
+        if experiment is not None and bundle.hwf is not None:
+            for tag, rgb in images.items():
+                experiment.add_image(tag + str(batch_idx), cast_to_image(rgb.view(bundle.hwf[0], bundle.hwf[1], 3)),
+                                     self.global_step)
+            if bundle.ray_targets is not None:
+                experiment.add_image("validation/img_target/" + str(batch_idx),
+                                     cast_to_image(bundle.ray_targets.view(bundle.hwf[0], bundle.hwf[1], 3)),
+                                     self.global_step)
+        return {"val_loss": loss, "log": {"validation/loss": loss, **log}}
 
     # names used by BASELINE.json's north_star (upstream krrish94/nerf-pytorch); absent in this reference
     run_iter = forward

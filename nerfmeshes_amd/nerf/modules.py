@@ -37,11 +37,12 @@ class PositionalEncoding(torch.nn.Module):
         return 6 * self.num_encoding_functions + (3 if self.include_input else 0)
 
     def forward(self, x):
-        raise NotImplementedError("PositionalEncoding is fused into the HIP MLP kernel (FlexibleNeRFModel.forward)")
+        raise NotImplementedError("PositionalEncoding is fused into the HIP MLP kernels (FlexibleNeRFModel.forward; "
+                                  "train_ops.encode_samples returns the rows the weight gradients need)")
 
 
 class VolumeRenderer(torch.nn.Module):
-    """modules.py:50-121 -> nm_composite."""
+    """modules.py:50-121 -> nm_composite (no noise, no autograd) / train_ops.composite (noise, differentiable)."""
 
     def __init__(self, train_radiance_field_noise_std=0.0, val_radiance_field_noise_std=0.0, white_background=False,
                  attenuation_threshold=1e-3):
@@ -53,9 +54,16 @@ class VolumeRenderer(torch.nn.Module):
         self.register_buffer("one_e_10", torch.tensor([1e10]))
 
     def forward(self, radiance_field, depth_values, ray_directions):
-        noise = self.train_radiance_field_noise_std if self.training else self.val_radiance_field_noise_std
-        if noise > 0.0:
-            raise NotImplementedError("radiance-field noise (training) is not implemented on the HIP path")
+        std = self.train_radiance_field_noise_std if self.training else self.val_radiance_field_noise_std
+        if std > 0.0 or (torch.is_grad_enabled() and radiance_field.requires_grad):
+            from .. import train_ops
+            sigma = radiance_field[..., 3]
+            noise = torch.randn(sigma.shape, dtype=sigma.dtype, device=sigma.device) * std if std > 0.0 else None
+            out = train_ops.composite(radiance_field, depth_values, ray_directions, noise, self.attenuation_threshold,
+                                      self.white_background)
+            if not self.training:                                    # modules.py:108-109
+                out["depth_map"] = torch.where(out["acc_map"] < 1.0, torch.zeros_like(out["depth_map"]), out["depth_map"])
+            return OutputBundle(**out)
         out = hip_ops.composite(radiance_field, depth_values, ray_directions, self.attenuation_threshold,
                                 self.white_background, self.training)
         return OutputBundle(**out)
@@ -70,9 +78,11 @@ class RaySampleInterval(torch.nn.Module):
         self.register_buffer("point_intervals", torch.linspace(0.0, 1.0, count)[None, :], persistent=False)
 
     def forward(self, cfg, ray_count, near, far):
-        if cfg.perturb:
-            raise NotImplementedError("stratified jitter (perturb) is not implemented on the HIP path")
-        return hip_ops.coarse_intervals(self.point_intervals.reshape(-1), near, far, ray_count, bool(cfg.lindisp))
+        t = hip_ops.coarse_intervals(self.point_intervals.reshape(-1), near, far, ray_count, bool(cfg.lindisp))
+        if cfg.perturb:                                              # modules.py:171-184, torch's random draw
+            from .. import train_ops
+            t = train_ops.perturb_intervals(t, torch.rand(t.shape, dtype=t.dtype, device=t.device))
+        return t
 
 
 class SamplePDF(torch.nn.Module):
@@ -84,6 +94,9 @@ class SamplePDF(torch.nn.Module):
         self.register_buffer("u", torch.linspace(0.0, 1.0, steps=num_samples))
 
     def forward(self, point_interval, weights, perturb):
-        if perturb != 0.0:
-            raise NotImplementedError("random u (perturb) is not implemented on the HIP path")
+        if perturb != 0.0:                                           # det = (perturb == 0.0), modules.py:201
+            from .. import train_ops
+            u = torch.rand(point_interval.shape[0], self.num_samples, dtype=point_interval.dtype,
+                           device=point_interval.device)
+            return train_ops.sample_pdf_rand(point_interval, weights.detach(), u)
         return hip_ops.sample_pdf(point_interval, weights, self.u)

@@ -84,3 +84,25 @@ def test_density_grid_sharded_two_ranks_equals_single():
     ref = (torch.arange(7 * 3 * 5, dtype=torch.float32) * 2.0).view(7, 3, 5).numpy()
     for grid in res:
         assert np.array_equal(grid, ref)
+
+
+def _grad_job(rank, world):
+    torch.manual_seed(0)                                        # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    unused = torch.nn.Parameter(torch.zeros(4))                 # a parameter without a gradient on rank 0
+    x = torch.arange(20, dtype=torch.float32).reshape(4, 5) * (rank + 1) / 10.0
+    loss = net(x).pow(2).mean() + (unused.sum() if rank == 1 else 0.0)
+    loss.backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    nd.all_reduce_gradients(list(net.parameters()) + [unused], bucket_bytes=64)    # several buckets
+    return [g.numpy() for g in local], [p.grad.numpy() for p in net.parameters()], unused.grad.numpy()
+
+
+def test_gradient_all_reduce_two_ranks_is_the_mean():
+    res = _run(_grad_job)
+    for k in range(4):
+        mean = 0.5 * (res[0][0][k] + res[1][0][k])
+        for r in range(2):
+            np.testing.assert_allclose(res[r][1][k], mean, rtol=1e-6, atol=1e-7)
+    for r in range(2):
+        np.testing.assert_allclose(res[r][2], np.full(4, 0.5, dtype=np.float32))

@@ -196,7 +196,7 @@ def test_end_to_end_loss_gradients_vs_oracle_autograd():
         l.backward()
         total += float(l.detach())
         grads[name] = {k: v.grad for k, v in wd.items()}
-    assert abs(float(loss) - total) < 1e-5 * max(1.0, total)
+    assert abs(float(loss.detach()) - total) < 1e-5 * max(1.0, total)
     for name, net in (("model_coarse", model.model_coarse), ("model_fine", model.model_fine)):
         for k, p in net.named_parameters():
             assert p.grad is not None, (name, k)
@@ -247,3 +247,22 @@ def test_perturb_and_noise_are_seeded_by_torch():
         with torch.no_grad():
             outs.append(model(batch)[1].rgb_map.clone())
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
+def test_training_step_api_and_driver(tmp_path):
+    """training_step / configure_optimizers / DataBundle through the driver loop (nerfmeshes_amd.train_nerf): a
+    4x64 student fitted for 80 iterations to renders of the seeded scene: the training loss falls by > 40 %, the
+    held-out view does not get worse (the 8x256 student of the default command line goes from 8 dB to 19 dB in 300
+    iterations, profiles/r01_train_bench.json), and the checkpoint loads back through the reference's entry point."""
+    from nerfmeshes_amd import models, train_nerf
+    ckpt = tmp_path / "default" / "version_0" / "checkpoints" / "last.ckpt"
+    losses, before, after = train_nerf.main(["--iters", "80", "--views", "4", "--size", "48", "--hidden-size", "64",
+                                             "--num-layers", "4", "--rays", "1024", "--lr", "2e-3", "--save", str(ckpt)])
+    assert len(losses) == 80 and all(np.isfinite(losses))
+    assert np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    assert np.isfinite(before) and np.isfinite(after) and after > before - 0.5, (before, after)
+    model = models.NeRFModel.load_from_checkpoint(str(ckpt)).cuda().eval()
+    o, d, _ = _rays(64, 2, 5)
+    with torch.no_grad():
+        out = model.query((o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0])))
+    assert out.rgb_map.shape == (64, 3) and bool(torch.isfinite(out.rgb_map).all())
