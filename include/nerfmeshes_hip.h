@@ -237,6 +237,16 @@ int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origin
                       const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
                       int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream);
 
+/* TreeSampling.ray_batch_integration (src/nerf/tree.py:177-206), training-time tree maintenance: the samples of
+ * the rays that hit the tree -- d_idx / d_weights / d_mask_weights, `count` elements each (= indices[mask],
+ * weights[mask], mask_weights[mask] flattened) -- update the running voxel weights d_memm (nvox,) in place:
+ * memm[v] += (sum_w[v] / sum_mask[v] - memm[v]) / counter wherever sum_mask[v] > 0.  `counter` is the tree's
+ * 1-based integration counter (the caller increments it).  Workspace: nm_tree_workspace_bytes(nvox). */
+int64_t nm_tree_workspace_bytes(int32_t nvox);
+int nm_tree_integrate(const int64_t* d_idx, const float* d_weights, const float* d_mask_weights, int64_t count,
+                      int32_t nvox, int32_t counter, float* d_memm, void* d_workspace, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Marching cubes: skimage.measure.marching_cubes(volume, level) as called at src/mesh_nerf.py:79
  * (third-party scikit-image 0.17.2, Lewiner MC33, defaults: step_size=1, gradient_direction='descent',

@@ -158,9 +158,57 @@ __global__ __launch_bounds__(256) void buff_intersect_kernel(const float* __rest
     }
 }
 
+// ---- training-time weight integration (tree.py:177-206) ------------------------------------------------------
+// acc[v] = sum of the sample weights that fell into voxel v over the whole ray batch, freq[v] = how many of them
+// were still visible (mask_weights); the reference materialises two dense (R, N) scatter targets per step, here
+// every sample adds into two length-N fp64 accumulators (native fp64 atomics; the fp64 sum rounded to fp32 is
+// order-independent in practice), then memm[v] += (acc / freq - memm[v]) / counter where freq > 0.
+__global__ void tree_scatter_kernel(const int64_t* __restrict__ idx, const float* __restrict__ w,
+                                    const float* __restrict__ mw, int64_t n, int nvox, double* __restrict__ acc,
+                                    double* __restrict__ freq) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t v = idx[i];
+    if (v < 0 || v >= nvox) return;
+    const float wi = w[i], mi = mw[i];
+    if (wi != 0.0f) atomicAdd(&acc[v], (double)wi);
+    if (mi != 0.0f) atomicAdd(&freq[v], (double)mi);
+}
+
+__global__ void tree_update_kernel(const double* __restrict__ acc, const double* __restrict__ freq,
+                                   float* __restrict__ memm, int nvox, float counter) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const float f = (float)freq[v];
+    if (f > 0.0f) {
+        const float mean = (float)acc[v] / f;
+        const float m = memm[v];
+        memm[v] = m + (mean - m) / counter;
+    }
+}
+
 }  // namespace nm
 
 using namespace nm;
+
+extern "C" int64_t nm_tree_workspace_bytes(int32_t nvox) { return nvox > 0 ? (int64_t)nvox * 16 : 0; }
+
+extern "C" int nm_tree_integrate(const int64_t* d_idx, const float* d_weights, const float* d_mask_weights, int64_t count,
+                                 int32_t nvox, int32_t counter, float* d_memm, void* d_workspace, void* stream_) {
+    NM_REQUIRE(d_idx && d_weights && d_mask_weights && d_memm && d_workspace, "bad argument");
+    NM_REQUIRE(nvox > 0 && counter >= 1 && count >= 0, "tree_integrate: bad sizes");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double* acc = static_cast<double*>(d_workspace);
+    double* freq = acc + nvox;
+    NM_HIP_CHECK(hipMemsetAsync(d_workspace, 0, (size_t)nvox * 16, stream));
+    if (count > 0)
+        hipLaunchKernelGGL(tree_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, d_idx,
+                           d_weights, d_mask_weights, count, nvox, acc, freq);
+    hipLaunchKernelGGL(tree_update_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, stream, acc, freq, d_memm,
+                       nvox, (float)counter);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
                                  const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,

@@ -242,6 +242,24 @@ def buff_intersect(voxels, origins, dirs, near, far, samples):
     return z, idx, mask.bool()
 
 
+def tree_integrate(memm, counter, indices, weights, mask_weights):
+    """TreeSampling.ray_batch_integration's arithmetic (nm_tree_integrate): updates `memm` (N,) in place from the
+    (K,S) voxel ids / weights / visibility masks of the rays that hit the tree."""
+    lib = _lib.load()
+    memm = memm if (memm.is_cuda and memm.dtype == torch.float32 and memm.is_contiguous()) else None
+    if memm is None:
+        raise _lib.HipLibraryError("tree_integrate: memm must be a contiguous fp32 GPU tensor (updated in place)")
+    dev = memm.device
+    idx = indices.to(device=dev, dtype=torch.int64).contiguous()
+    w, mw = _dev32(weights, dev, "weights"), _dev32(mask_weights, dev, "mask_weights")
+    if not (idx.numel() == w.numel() == mw.numel()):
+        raise ValueError("tree_integrate: indices / weights / mask_weights differ in size")
+    ws = torch.empty(int(lib.nm_tree_workspace_bytes(memm.numel())), dtype=torch.uint8, device=dev)
+    check(lib.nm_tree_integrate(_ptr(idx), _ptr(w), _ptr(mw), idx.numel(), memm.numel(), int(counter), _ptr(memm),
+                                _ptr(ws), _stream()), "nm_tree_integrate")
+    return memm
+
+
 def marching_cubes(volume, level):
     """skimage.measure.marching_cubes(volume, level) on the GPU (nm_mc_count + nm_mc_emit).
     volume: (n0,n1,n2) fp32 CUDA tensor.  Returns (verts (V,3) f32, faces (F,3) i32, normals (V,3) f32,

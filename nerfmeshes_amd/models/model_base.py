@@ -109,8 +109,7 @@ class BaseModel(_Base):
         return [optimizer], [{"scheduler": scheduler, "interval": "step", "frequency": 1}]
 
     def training_step(self, ray_batch, batch_idx):
-        raise NotImplementedError("training_step is implemented for NeRFModel; BuFF training needs the tree "
-                                  "maintenance rows (SURVEY.md 8(f) rank 3)")
+        raise NotImplementedError
 
     def validation_epoch_end(self, outputs):
         """model_base.py:75-103 without the pytorch3d chamfer branch: the mean of every logged value."""

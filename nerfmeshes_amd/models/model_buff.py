@@ -1,6 +1,8 @@
 """BuFFModel: single network + voxel-tree sampling (mirror of /root/reference/src/models/model_buff.py:12-73,166-170)."""
 import torch
 
+from .. import train_ops
+from ..data import DataBundle
 from ..nerf import RaySampleInterval, TreeSampling, models as nerf_models
 from .model_base import BaseModel
 
@@ -25,15 +27,36 @@ class BuFFModel(BaseModel):
         intervals, indices, mask = self.tree.batch_ray_voxel_intersect(ray_origins, ray_directions, near, far,
                                                                        samples_count=nerf_cfg.num_coarse)
         intervals[~mask] = uniform[~mask]                         # rays that miss every voxel (model_buff.py:53)
-        radiance = self.model.hip().eval_rays(ray_origins, ray_directions, intervals)
+        if self.model.needs_grad():                               # training: differentiable kernels (train_ops)
+            radiance = train_ops.mlp_rays(self.model, ray_origins, ray_directions, intervals)
+        else:
+            radiance = self.model.hip().eval_rays(ray_origins, ray_directions, intervals)
         bundle = self.volume_renderer(radiance, intervals, ray_directions)
-        if self.training:
-            self.tree.ray_batch_integration(self.global_step, indices[mask], bundle.weights[mask],
-                                            bundle.mask_weights[mask])
+        if self.training:                                         # model_buff.py:66-68
+            self.tree.ray_batch_integration(self.global_step, indices[mask], bundle.weights[mask].detach(),
+                                            bundle.mask_weights[mask].detach())
         return bundle
 
     def query(self, ray_batch):
         return self.forward(ray_batch)
+
+    def training_step(self, ray_batch, batch_idx):
+        """model_buff.py:79-124 without the TensorBoard loggers: one forward over the whole ray batch, MSE loss,
+        tree consolidation on its schedule."""
+        bundle = DataBundle.deserialize(ray_batch).to_ray_batch()
+        dev = self.model.layer1.weight.device
+        out = self.forward((bundle.ray_origins, bundle.ray_directions, bundle.ray_bounds))
+        self.check_early_stopping(out.rgb_map)
+        loss = self.loss(out.rgb_map, bundle.ray_targets.to(dev))
+        log = {"train/loss": loss, "train/psnr": self.criterion_psnr(loss)}
+        if self.tree.ticked(self.global_step):
+            self.tree.consolidate()
+        trainer = getattr(self, "trainer", None)
+        try:
+            lr = trainer.optimizers[0].param_groups[0]["lr"]
+        except (AttributeError, IndexError, TypeError):
+            lr = self.cfg.optimizer.lr
+        return {"loss": loss, "log": {**log, "train/lr": lr}}
 
     def on_save_checkpoint(self, checkpoint):
         checkpoint["tree"] = self.tree.serialize()

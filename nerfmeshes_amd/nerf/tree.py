@@ -5,8 +5,10 @@
 `nerf.tree.Node` importable -- see nerfmeshes_amd.compat).  The inference hot spot,
 `batch_ray_voxel_intersect` (tree.py:215-343, deterministic branch), runs as one gfx950 kernel with one
 wavefront per ray and the voxel AABBs staged in LDS (nm_buff_intersect) instead of the reference's
-dense (R, N, 3) temporaries.  Training-time tree maintenance (`ray_batch_integration`, the weighted
-`consolidate`) is host-side bookkeeping outside this round's scope and raises.
+dense (R, N, 3) temporaries.  Training-time tree maintenance: `ray_batch_integration`
+(tree.py:177-206) accumulates on the GPU (nm_tree_integrate, two length-N accumulators instead of two dense
+(R, N) scatter targets); `consolidate` (tree.py:127-175) is host-side bookkeeping over the node graph, as in the
+reference.
 """
 import torch
 
@@ -65,15 +67,48 @@ class TreeSampling:
         return False
 
     def consolidate(self, split=False):
+        """tree.py:127-175.  With accumulated weights: drop the voxels whose weight is <= tree.eps, then subdivide
+        the survivors -- shallow nodes first, heavier first among equals -- for as long as the projected voxel count
+        stays under tree.max_voxel_count; the rest are kept whole.  Always: rebuild the (N,2,3) voxel tensor, zero the
+        weights, restart the integration counter."""
         if self.memm is not None:
-            raise NotImplementedError("weighted tree consolidation (BuFF training) is outside the HIP inference path")
+            tree = self.config.tree
+            memm = self.memm.detach().cpu()
+            print(f"Min memm {memm.min()}\nMax memm {memm.max()}\nMean memm {memm.mean()}\nMedian memm {memm.median()}")
+            print(f"Threshold {tree.eps}")
+            keep = torch.nonzero(memm > tree.eps).reshape(-1).tolist()
+            lightness = (1.0 - memm[memm > tree.eps]).tolist()          # same order as `keep`
+            print(f"From {memm.shape[0]} voxels with {memm.shape[0] - len(keep)} filtered to current {len(keep)}")
+            survivors = [self.root.children[i] for i in keep]
+            order = sorted(range(len(survivors)), key=lambda j: (survivors[j].depth, lightness[j]))   # stable
+            growth = tree.subdivision_inner_count ** 3 - 1
+            children = []
+            for position, j in enumerate(order):
+                node = survivors[j]
+                projected = len(children) + growth + len(keep) - position
+                if projected < tree.max_voxel_count:
+                    node.subdivide()
+                    children.extend(node.children if node.children else [node])
+                else:
+                    children.append(node)
+            print(f"Now {len(children)} voxels")
+            self.root.children = children
         voxels = [torch.stack(node.bounds, 0) for node in self.root.children]
+        if not voxels:
+            print(f"The chosen threshold {self.config.tree.eps} was set too high!")
         self.voxels = torch.stack(voxels, 0).to(self.device)          # (N, 2, 3) min / max corners
         self.memm = torch.zeros(self.voxels.shape[0]).to(self.device)
         self.counter = 1
 
     def ray_batch_integration(self, step, ray_voxel_indices, ray_batch_weights, ray_batch_weights_mask):
-        raise NotImplementedError("BuFF training-time weight integration is outside the HIP inference path")
+        """tree.py:177-206: running mean of the per-voxel sample weights of this ray batch (rays that hit the tree)."""
+        offset = self.config.tree.step_size_integration_offset
+        if step < offset:
+            return
+        if step == offset:
+            print(f"Began ray batch integration... Step:{step}")
+        hip_ops.tree_integrate(self.memm, self.counter, ray_voxel_indices, ray_batch_weights, ray_batch_weights_mask)
+        self.counter += 1
 
     def batch_ray_voxel_intersect(self, origins, dirs, near, far, samples_count=64):
         """(z_vals (R,S) f32, voxel indices (R,S) i64, ray_mask (R,) bool) -- tree.py:215-343."""

@@ -397,3 +397,15 @@ def buff_intersect(voxels, origins, dirs, near, far, samples_count):
     vox = order.indices.gather(-1, start.indices.gather(-1, bucket))
     z, zorder = torch.sort(z, dim=-1, stable=True)
     return z, vox.gather(-1, zorder), ray_mask
+
+
+def buff_integrate(memm, counter, indices, weights, mask_weights):
+    """(f)-3: TreeSampling.ray_batch_integration (tree.py:177-206): returns the updated voxel weights.
+    indices (K,S) int64, weights / mask_weights (K,S): the rays that hit the tree."""
+    rays, n = weights.shape[0], memm.shape[0]
+    acc = torch.zeros(rays, n).scatter_add(-1, indices, weights).sum(0)
+    freq = torch.zeros(rays, n).scatter_add(-1, indices, mask_weights).sum(0)
+    seen = freq > 0
+    out = memm.clone()
+    out[seen] += (acc[seen] / freq[seen] - out[seen]) / counter
+    return out

@@ -212,6 +212,44 @@ def case_buff(name):
     print(name, "hit rays", int(mask.sum()), "/", n, "acc", float(bundle.acc_map.mean()))
 
 
+def case_buff_tree(name):
+    """(f)-3: the reference's training-time tree maintenance -- three ray_batch_integration steps on the fresh
+    12^3 tree, then two consolidate() rounds (filter by tree.eps, subdivide under tree.max_voxel_count)."""
+    import contextlib, io
+    nerf, models = ref_import.load()
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2,
+                   dataset_type="colmap")
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.BuFFModel(hp)
+    tree = m.tree
+    g = torch.Generator().manual_seed(33)
+    n = tree.voxels.shape[0]
+    out = dict(voxels0=tree.voxels.numpy())
+    rays, S_ = 96, 192
+    hot = torch.randperm(n, generator=g)[:140]                       # the voxels the "scene" occupies
+    for k in range(3):
+        # every ray walks through a few of the occupied voxels in runs, as batch_ray_voxel_intersect reports them
+        pick = hot[torch.randint(0, hot.numel(), (rays, 12), generator=g)]
+        idx = pick.repeat_interleave(16, dim=1)
+        w = torch.rand(rays, S_, generator=g) ** 6 * 0.3
+        mw = (torch.rand(rays, S_, generator=g) > 0.35).float()
+        with contextlib.redirect_stdout(io.StringIO()):
+            tree.ray_batch_integration(k, idx, w, mw)
+        out.update({f"idx{k}": idx.numpy(), f"w{k}": w.numpy(), f"mw{k}": mw.numpy(), f"memm{k}": tree.memm.numpy().copy()})
+    out["counter"] = tree.counter
+    for k in range(2):
+        with contextlib.redirect_stdout(io.StringIO()):
+            tree.consolidate()
+        out[f"voxels_after{k + 1}"] = tree.voxels.numpy()
+        if k == 0:   # weights for the second round: every other voxel of the refined set is occupied
+            memm = (torch.rand(tree.voxels.shape[0], generator=g) * (torch.arange(tree.voxels.shape[0]) % 2 == 0)).float()
+            tree.memm = memm.clone()
+            out["memm_round2"] = memm.numpy()
+    out.update(eps=hp["tree.eps"], max_voxel_count=hp["tree.max_voxel_count"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, [out[f"voxels_after{k}"].shape[0] for k in (1, 2)], "voxels after the two rounds")
+
+
 def case_obj(name):
     """(f)-1: the reference's OBJ text writer (nerf_helpers.py:86-111) on a tiny mesh."""
     import contextlib, io
@@ -233,7 +271,10 @@ if __name__ == "__main__":
         case_obj("export_obj")
     elif "--buff" in sys.argv:
         case_buff("buff_fern")
+    elif "--buff-tree" in sys.argv:
+        case_buff_tree("buff_tree")
     else:
         main()
         case_buff("buff_fern")
+        case_buff_tree("buff_tree")
         case_obj("export_obj")

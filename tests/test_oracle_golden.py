@@ -151,3 +151,30 @@ def test_export_obj_text_matches_reference(tmp_path):
                torch.from_numpy(g["normals"]), str(out))
     ref = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "export_obj.obj")).read()
     assert out.read_text() == ref
+
+
+def test_buff_tree_maintenance_matches_reference(capsys):
+    """(f)-3: oracle integration == the reference's memm after each step (same torch ops: exact); the host-side
+    consolidate() of the product mirror reproduces the reference's voxel sets over two refinement rounds."""
+    from nerfmeshes_amd.nerf import CfgNode, TreeSampling
+    g = load_golden("buff_tree")
+    memm = torch.zeros(g["voxels0"].shape[0])
+    for k in range(3):
+        memm = O.buff_integrate(memm, k + 1, torch.from_numpy(g[f"idx{k}"]), torch.from_numpy(g[f"w{k}"]),
+                                torch.from_numpy(g[f"mw{k}"]))
+        assert torch.equal(memm, torch.from_numpy(g[f"memm{k}"])), k
+    assert int(g["counter"]) == 4
+    from nerfmeshes_amd.models.model_helpers import nest_dict
+    cfg = CfgNode(nest_dict(S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2,
+                                      dataset_type="colmap"), sep="."))
+    tree = TreeSampling(cfg, "cpu")
+    assert np.array_equal(tree.voxels.numpy(), g["voxels0"])
+    tree.memm = memm.clone()
+    tree.consolidate()
+    assert np.array_equal(tree.voxels.numpy(), g["voxels_after1"])
+    assert tree.counter == 1 and float(tree.memm.abs().sum()) == 0.0
+    tree.memm = torch.from_numpy(g["memm_round2"]).clone()
+    tree.consolidate()
+    assert np.array_equal(tree.voxels.numpy(), g["voxels_after2"])
+    assert tree.voxels.shape[0] < int(g["max_voxel_count"])
+    capsys.readouterr()
