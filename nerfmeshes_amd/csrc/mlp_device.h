@@ -45,11 +45,18 @@ __device__ __forceinline__ void stream_to_lds(const char* src, char* dst, int by
 // their use, and the two waves of a SIMD, released together by the barrier, then expose the LDS latency
 // together every 8 MFMAs), one barrier.  (The cursor is SGPR arithmetic on purpose: a chunk table fetched
 // with s_load costs 3 % -- its s_waitcnt lgkmcnt(0) also drains the in-flight ds_reads.)
-template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE, bool SPREAD = false, int ABL = 0>
+//
+// STORE (training): b1 -- the previous layer's activation / delta, live in registers for this whole stage anyway --
+// is written to `store_row` (this lane's row-major position, tape layout) a few tiles per chunk instead of as one
+// 16-instruction burst before the stage: the bursts of the 8 waves of a workgroup (128 KB) outrun the HBM write
+// bandwidth and the next barrier's s_waitcnt vmcnt(0) -- gfx9 counts stores and loads together -- waits for them
+// (10 % of the delta kernel); spread out, each store has a chunk's worth of MFMAs (1.7 us) to retire.
+template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, bool PIPE, bool SPREAD = false, int ABL = 0,
+          bool STORE = false>
 __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[KS1],
                                            const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
                                            const char* tail_src, int tail_bytes, char* lds, int& par,
-                                           int wave, int lane) {
+                                           int wave, int lane, float* store_row = nullptr) {
     constexpr int KS = KS1 + KS2;
     constexpr int NCH = (KS + KCH - 1) / KCH;
     constexpr int VW = NT >= 4 ? 4 : NT;  // A operands fetched per LDS read
@@ -75,6 +82,19 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[K
         const int next_units = (next_bytes + 1023) >> 10;
         int next_u = wave;
         if constexpr (!SPREAD && !(ABL & 4)) stream_to_lds<NW>(next_src, next_slot, next_bytes, wave, lane);
+        if constexpr (STORE) {
+            constexpr int TILES = KS1 / 4, PER_CHUNK = (TILES + NCH - 1) / NCH;
+            if (store_row) {
+#pragma unroll
+                for (int q = 0; q < PER_CHUNK; ++q) {
+                    const int nt = c * PER_CHUNK + q;
+                    if (nt < TILES) {
+                        const f32x4 v4 = {b1[4 * nt], b1[4 * nt + 1], b1[4 * nt + 2], b1[4 * nt + 3]};
+                        *reinterpret_cast<f32x4*>(store_row + 16 * nt) = v4;
+                    }
+                }
+            }
+        }
         const char* buf = lds + par * LDSBUF + lane * (VW * 4);
         avec a_next[NB];
         if constexpr (PIPE) {
@@ -282,7 +302,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         gw += N::EX * N::STEP;
         acc_to_operand<N::NT, false>(acc, in);
         const int64_t tile = it * NW + wave;
-        if constexpr (TAPE) store_rows<N::NT>(args.tape_h, H, sample, valid, in, g);
+        // TAPE: every trunk activation is written while the NEXT stage consumes it (gemm_stage STORE): tape_h[i] during
+        // trunk stage i, relu(fc_feat) during the view stage
+        float* tape_row = (TAPE && valid) ? args.tape_h + sample * H + 4 * g : nullptr;
 
         // ---- layers_xyz[0 .. L-2], then (full evaluation only) fc_feat as iteration L-1 (models.py:63-70)
         float sigma = 0.0f;
@@ -300,7 +322,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
                 if (skip) tbytes = N::L1_FIRST;               // the skip layer's encoding columns follow
                 else if (is_feat) tbytes = N::DIR_FIRST;      // view layer follows
                 else if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
-                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane);
+                gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL, TAPE>(
+                    acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane,
+                    tape_row ? tape_row + (int64_t)i * args.n * H : nullptr);
                 gw += N::KH * N::STEP;
             }
             if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
@@ -318,8 +342,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
             }
             acc_to_operand<N::NT, true>(acc, in);
             if constexpr (TAPE) {
-                float* rows = is_feat ? args.tape_feat : args.tape_h + (int64_t)(1 + i) * args.n * H;
-                store_rows<N::NT>(rows, H, sample, valid, in, g);
                 if (tile < args.tiles) args.mask_h[((int64_t)i * args.tiles + tile) * 64 + lane] = positive_mask(in);
             }
         }
@@ -337,8 +359,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         load_bias<N::NTD>(accd, bias_src + H * (1 + num_layers), g);
         float encd[N::ED];
         encode<FD, N::ED, ABL>(encd, d, args.bands_dir, g);
-        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(accd, in, encd, gw, args.wstream,
-                                                                    has_next ? N::L1_FIRST : 0, lds, par, wave, lane);
+        gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL, TAPE>(
+            accd, in, encd, gw, args.wstream, has_next ? N::L1_FIRST : 0, lds, par, wave, lane,
+            (TAPE && valid) ? args.tape_feat + sample * H + 4 * g : nullptr);
         gw = args.wstream;
         acc_to_operand<N::NTD, true>(accd, v);
         if constexpr (TAPE) {
