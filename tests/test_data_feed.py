@@ -1,0 +1,62 @@
+"""Host-side data feed: DataBundle round trips and the per-image `.data` ray cache
+(datasets.py:136-283) -- CPU only."""
+import torch
+
+from nerfmeshes_amd import synthetic as S
+from nerfmeshes_amd.data import CachedRayDataset, DataBundle, DatasetType
+from nerfmeshes_amd.models.model_helpers import nest_dict
+from nerfmeshes_amd.nerf import CfgNode
+
+
+def _cfg(tmp_path, rays=64):
+    flat = S.hparams()
+    flat.update({"dataset.caching.cache_dir": str(tmp_path / "cache"), "nerf.train.num_random_rays": rays})
+    return CfgNode(nest_dict(flat, sep="."))
+
+
+def _view(h, w, k):
+    g = torch.Generator().manual_seed(k)
+    dirs = torch.randn(h, w, 3, generator=g)
+    return DataBundle(ray_origins=torch.tensor([0.0, 1.0, float(k)]), ray_directions=dirs, ray_targets=dirs * 0.5 + 0.25,
+                      ray_bounds=torch.tensor([2.0, 6.0]), size=1, hwf=(h, w, 55.5))
+
+
+def test_databundle_round_trip_and_ray_batch_shapes():
+    b = _view(6, 9, 0)
+    d = b.serialize(["ray_origins", "ray_directions", "ray_targets", "ray_bounds", "target_depth", "size", "hwf"])
+    assert set(d) == {"ray_origins", "ray_directions", "ray_targets", "ray_bounds", "size", "hwf"}     # None is dropped
+    loader_batch = {k: (v[None] if isinstance(v, torch.Tensor) else v) for k, v in d.items()}          # DataLoader batch dim
+    rb = DataBundle.deserialize(loader_batch).to("cpu").to_ray_batch()
+    assert rb.ray_origins.shape == (1, 3) and rb.ray_directions.shape == (54, 3) and rb.ray_bounds.shape == (2,)
+    assert rb.ray_targets.shape == (54, 3) and rb.target_depth is None
+    o, t = rb["ray_origins", "ray_targets"]
+    assert o is rb.ray_origins and t is rb.ray_targets
+
+
+def test_ray_cache_files_and_random_sampling(tmp_path):
+    cfg = _cfg(tmp_path)
+    writer = CachedRayDataset(cfg, DatasetType.TRAIN)
+    assert len(writer) == 0
+    for k in range(3):
+        writer.write_view(_view(10, 14, k), k)
+    files = sorted(p.name for p in (tmp_path / "cache" / "train").iterdir())
+    assert files == ["0000.data", "0001.data", "0002.data"]
+    raw = torch.load(tmp_path / "cache" / "train" / "0001.data", weights_only=False)      # a plain dict, as the reference writes
+    assert isinstance(raw, dict) and raw["ray_directions"].shape == (10, 14, 3) and tuple(raw["hwf"]) == (10, 14, 55.5)
+
+    train = CachedRayDataset(cfg, DatasetType.TRAIN)
+    assert len(train) == 3 and train.coords.shape == (140, 2)
+    assert int(train.coords[:, 0].max()) == 9 and int(train.coords[:, 1].max()) == 13
+    torch.manual_seed(0)
+    item = train[2]
+    assert item["ray_directions"].shape == (64, 3) and item["ray_targets"].shape == (64, 3)
+    assert torch.equal(item["ray_targets"], item["ray_directions"] * 0.5 + 0.25)           # pixels stay paired
+    assert torch.equal(item["ray_origins"], torch.tensor([0.0, 1.0, 2.0]))                # shared origin untouched
+    flat = raw_dirs = torch.load(tmp_path / "cache" / "train" / "0002.data", weights_only=False)["ray_directions"].reshape(-1, 3)
+    assert all(bool((flat == row).all(-1).any()) for row in item["ray_directions"][:8])    # drawn from that image
+    assert raw_dirs is flat
+
+    for k in range(2):
+        CachedRayDataset(cfg, DatasetType.VALIDATION).write_view(_view(10, 14, 10 + k), k)
+    val = CachedRayDataset(cfg, DatasetType.VALIDATION)
+    assert len(val) == 2 and val[0]["ray_directions"].shape == (10, 14, 3)                # whole image, no sampling
