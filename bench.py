@@ -67,6 +67,41 @@ def cpu_baseline(weights, rays_o, rays_d, budget_s=16.0, chunk=2048):
     return done / dt, done, dt, torch.cat(outs, 0), O
 
 
+def train_probe(dev, dirs, origin, rays=2048, iters=10):
+    """Secondary figure: one optimizer iteration of the same 8x256 coarse+fine model on a
+    2048-ray batch -- forward in train mode (perturb + noise), MSE(coarse)+MSE(fine), HIP backward, Adam."""
+    from nerfmeshes_amd import models
+    from nerfmeshes_amd.nerf import CfgNode
+    torch.manual_seed(0)
+    model = models.NeRFModel(CfgNode(S.hparams(train_perturb=True, train_noise_std=0.2))).to(dev)
+    with torch.no_grad():
+        for net in (model.model_coarse, model.model_fine):
+            net.fc_alpha.weight.mul_(30.0)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    pick = torch.randperm(dirs.shape[0], generator=torch.Generator().manual_seed(1))[:rays].to(dev)
+    batch = (origin.reshape(1, 3), dirs[pick].contiguous(), torch.tensor([2.0, 6.0]))
+    target = torch.rand(rays, 3, device=dev)
+
+    def iteration():
+        opt.zero_grad(set_to_none=True)
+        c, f = model(batch)
+        loss = torch.nn.functional.mse_loss(c.rgb_map, target) + torch.nn.functional.mse_loss(f.rgb_map, target)
+        loss.backward()
+        opt.step()
+
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"value": rays / ms * 1e3, "unit": "rays/s", "ms_per_iteration": ms, "rays_per_iteration": rays,
+            "workload": "training step: 8x256 coarse+fine, 64+128 samples, perturb + noise, Adam (forward + HIP backward + step)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=65536, help="rays per nm_render_rays call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-probe", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +222,12 @@ def main():
                          "max_abs_drgb": float((got - ref_rgb).abs().max()),
                          "psnr_hip_vs_ref_db": float(O.mse2psnr(torch.nn.functional.mse_loss(got, ref_rgb))),
                          "rays": n}
+    if rank == 0 and world == 1 and not args.no_train_probe:
+        try:
+            o, d = views[0]
+            out["train"] = train_probe(dev, d, o)
+        except Exception as e:  # the headline line must not depend on the secondary figure
+            out["train"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -1,7 +1,9 @@
 /* Language-neutral use of the C ABI (include/nerfmeshes_hip.h): no Python, no torch.
  * Builds a 4x64 FlexibleNeRFModel from weights read from a raw fp32 file, evaluates n points with
- * nm_mlp_sample_points and writes the (n,4) result to a raw fp32 file.  The pytest driver
- * (tests/test_gpu_cabi_c.py) generates the inputs and checks the output against the CPU oracle.
+ * nm_mlp_sample_points and writes the (n,4) result to a raw fp32 file; then runs the training entry points
+ * (nm_mlp_forward_train + nm_mlp_backward with dL/d(radiance) = 1) on the same points as one-sample rays and appends
+ * the radiance again, delta at layer1's output (n,H) and the head deltas (n,4).  The pytest driver
+ * (tests/test_gpu_cabi_c.py) generates the inputs and checks everything against the CPU oracle.
  *
  *   gcc -D__HIP_PLATFORM_AMD__ tests/cabi_smoke.c -Iinclude -I/opt/rocm/include -Lnerfmeshes_amd/csrc -lnerfmeshes_hip \
  *       -L/opt/rocm/lib -lamdhip64 -o cabi_smoke
@@ -62,6 +64,31 @@ int main(int argc, char** argv) {
     float* out = (float*)malloc((size_t)n * 16);
     if (hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "copy back failed\n"); return 6; }
     f = fopen(argv[4], "wb");
+    fwrite(out, sizeof(float), (size_t)n * 4, f);
+
+    /* ---- training ABI: every point is a one-sample ray (origin = point, t = 0) */
+    const size_t tiles = ((size_t)n + 15) / 16;
+    nm_mlp_tape tape;
+    nm_mlp_deltas dl;
+    float *d_t, *d_grad, *d_rad2;
+    hipMalloc((void**)&tape.d_h, (size_t)L * n * H * 4); hipMalloc((void**)&tape.d_feat, (size_t)n * H * 4);
+    hipMalloc((void**)&tape.d_v, (size_t)n * (H / 2) * 4);
+    hipMalloc((void**)&tape.d_mask_h, (size_t)L * tiles * 64 * 8); hipMalloc((void**)&tape.d_mask_v, tiles * 64 * 8);
+    hipMalloc((void**)&dl.d_h, (size_t)L * n * H * 4); hipMalloc((void**)&dl.d_feat, (size_t)n * H * 4);
+    hipMalloc((void**)&dl.d_v, (size_t)n * (H / 2) * 4); hipMalloc((void**)&dl.d_last, (size_t)n * 16);
+    hipMalloc((void**)&d_t, (size_t)n * 4); hipMalloc((void**)&d_grad, (size_t)n * 16); hipMalloc((void**)&d_rad2, (size_t)n * 16);
+    hipMemset(d_t, 0, (size_t)n * 4);
+    float* ones = (float*)malloc((size_t)n * 16);
+    for (long i = 0; i < 4 * n; ++i) ones[i] = 1.0f;
+    hipMemcpy(d_grad, ones, (size_t)n * 16, hipMemcpyHostToDevice);
+    if (nm_mlp_forward_train(mlp, d_pts, 1, d_dirs, d_t, n, 1, &tape, d_rad2, NULL)) { fprintf(stderr, "forward_train: %s\n", nm_last_error()); return 7; }
+    if (nm_mlp_backward(mlp, n, &tape, d_rad2, d_grad, &dl, NULL)) { fprintf(stderr, "backward: %s\n", nm_last_error()); return 8; }
+    float* buf = (float*)malloc((size_t)n * H * 4);
+    if (hipMemcpy(out, d_rad2, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+    fwrite(out, sizeof(float), (size_t)n * 4, f);
+    if (hipMemcpy(buf, dl.d_h, (size_t)n * H * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+    fwrite(buf, sizeof(float), (size_t)n * H, f);
+    if (hipMemcpy(out, dl.d_last, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return 9;
     fwrite(out, sizeof(float), (size_t)n * 4, f);
     fclose(f);
     printf("abi %d flops/sample %lld ok\n", nm_abi_version(), (long long)nm_mlp_flops_per_sample(mlp, 0));

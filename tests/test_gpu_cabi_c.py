@@ -42,7 +42,18 @@ def test_c_program_through_the_c_abi(tmp_path):
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     assert "abi 1" in res.stdout
-    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(n, 4)
+    blob = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    assert blob.size == n * (4 + 4 + 64 + 4)
+    got, taped, d_h0, d_last = np.split(blob, [4 * n, 8 * n, 8 * n + 64 * n])
+    got, taped, d_h0, d_last = got.reshape(n, 4), taped.reshape(n, 4), d_h0.reshape(n, 64), d_last.reshape(n, 4)
+    assert np.array_equal(got, taped), "nm_mlp_forward_train must reproduce nm_mlp_sample_points"
     ref = O.mlp_forward(w, O.MLPSpec(**kw), pts, dirs).numpy()
     assert np.abs(got[:, :3] - ref[:, :3]).max() < 2e-5
     assert np.abs(got[:, 3] - ref[:, 3]).max() < 2e-5 * (np.abs(ref[:, 3]).max() + 1)
+    # training ABI from C: bias gradients are the column sums of the deltas it wrote (dL/d radiance = 1)
+    w64 = {k: torch.as_tensor(v, dtype=torch.float64).requires_grad_(True) for k, v in w.items()}
+    O.mlp_forward(w64, O.MLPSpec(**kw), torch.from_numpy(pts).double(), torch.from_numpy(dirs).double(), keep_graph=True).sum().backward()
+    for name, ours in (("layer1.bias", d_h0.astype(np.float64).sum(0)), ("fc_rgb.bias", d_last[:, :3].astype(np.float64).sum(0)),
+                       ("fc_alpha.bias", d_last[:, 3:].astype(np.float64).sum(0))):
+        ref_g = w64[name].grad.numpy()
+        assert np.abs(ours - ref_g).max() <= 2e-4 * np.abs(ref_g).max(), name

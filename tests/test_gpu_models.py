@@ -276,7 +276,7 @@ def test_buff_tree_integration_and_training_step(pkg):
         out = model.training_step(batch, step)
         out["loss"].backward()
         opt.step()
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
     assert losses[-1] < 0.8 * losses[0], losses
     assert model.tree.counter == 21 and float(model.tree.memm.max()) > 0.0
     before = model.tree.voxels.shape[0]
