@@ -271,15 +271,18 @@ def marching_cubes(volume, level):
         raise ValueError("Input array must be at least 2x2x2.")
     vol = _dev32(volume, name="volume")
     level = float(level)
-    lo, hi = (float(v) for v in torch.aminmax(vol))
-    if level < lo or level > hi:
-        raise ValueError("Surface level must be within volume data range.")
     n0, n1, n2 = vol.shape
     dev = vol.device
     ws = torch.empty(int(lib.nm_mc_workspace_bytes(n0, n1, n2)), dtype=torch.uint8, device=dev)
     nv, nf = C.c_int64(), C.c_int64()
     check(lib.nm_mc_count(_ptr(vol), n0, n1, n2, level, _ptr(ws), C.byref(nv), C.byref(nf), _stream()), "nm_mc_count")
     if nv.value == 0:
+        # skimage checks the level against the data range first (ValueError) and only then finds no surface
+        # (RuntimeError).  A level outside [min, max] cannot produce a vertex, so the 442 MB min/max pass is only
+        # paid on this error path instead of on every call.
+        lo, hi = (float(v) for v in torch.aminmax(vol))
+        if level < lo or level > hi:
+            raise ValueError("Surface level must be within volume data range.")
         raise RuntimeError("No surface found at the given iso value.")
     verts = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)
     normals = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)

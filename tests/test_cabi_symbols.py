@@ -25,10 +25,9 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_no_cpu_fallback_in_product():
-    """The product package must not import / execute anything under oracle/."""
-    pkg = os.path.join(ROOT, "nerfmeshes_amd")
+    """The product package (and the helper scripts outside tests/) must not import / execute anything under oracle/."""
     bad = re.compile(r"^\s*(from\s+\.*oracle\b|import\s+oracle\b)|import_module\([\"']oracle|oracle/_ref|oracle\.", re.M)
-    for dirpath, _, files in os.walk(pkg):
+    for dirpath, _, files in list(os.walk(os.path.join(ROOT, "nerfmeshes_amd"))) + list(os.walk(os.path.join(ROOT, "scripts"))):
         for f in files:
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()

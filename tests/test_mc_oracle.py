@@ -39,7 +39,7 @@ def test_oracle_matches_skimage_golden_set():
 
 @pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="scikit-image black box not present")
 def test_oracle_live_fuzz_against_skimage():
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import fuzz_mc
     try:
         cases = fuzz_mc.gen_cases(np.random.default_rng(int(os.environ.get("NM_FUZZ_SEED", "777"))), 120)[-400:]

@@ -1,5 +1,5 @@
 import os, sys, json, torch, ctypes as C
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nerfmeshes_amd import hip_ops, synthetic as S, train_ops as T, _lib
 from nerfmeshes_amd._lib import MlpDeltas, MlpTape
 kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)

@@ -2,10 +2,10 @@
 Times the density-grid query (fused MLP, density-only) and marching cubes (count + emit), checks the mesh
 bitwise against the CPU oracle on the SAME grid, and times the CPU legs on a bounded sample.
 
-    python scripts/bench_mesh.py [--res 480] [--no-oracle]
+    python tests/tools/bench_mesh.py [--res 480] [--no-oracle]
 """
 import argparse, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nerfmeshes_amd import hip_ops, synthetic as S

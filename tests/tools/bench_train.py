@@ -4,7 +4,7 @@ MSE(coarse) + MSE(fine) -> backward -> Adam step.  Prints one JSON object with t
 breakdown (HIP events on torch's stream) and -- bounded -- the same iteration through torch autograd over the
 CPU oracle on the host cores.
 
-    python scripts/bench_train.py [--rays 2048] [--iters 20] [--cpu-rays 256]
+    python tests/tools/bench_train.py [--rays 2048] [--iters 20] [--cpu-rays 256]
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from nerfmeshes_amd import models, synthetic as S, train_ops as T  # noqa: E402
 from nerfmeshes_amd.nerf import CfgNode  # noqa: E402
@@ -112,7 +112,7 @@ def main():
     }
     # ---- the same iteration through torch autograd over the CPU oracle (bounded)
     if args.cpu_rays > 0:
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
         from oracle import nerf_oracle as O
         spec = O.MLPSpec()
         rs = O.RenderSpec(training=True)

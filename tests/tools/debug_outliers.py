@@ -1,6 +1,6 @@
 """Find the rays where HIP and oracle renders differ most and explain why (debug aid, GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from nerfmeshes_amd import hip_ops as ops, synthetic as S
 from oracle import nerf_oracle as O

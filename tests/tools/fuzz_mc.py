@@ -1,7 +1,7 @@
 """Black-box fuzz of the C oracle against the compiled scikit-image module (build container only)."""
 import os, subprocess, sys, tempfile
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import mc_oracle
 
