@@ -10,8 +10,9 @@
 //                 An edge vertex is created by the first cube in scan order that contains the edge; every
 //                 tiling of a cube uses exactly its sign-changing edges, so ownership is a pure function of
 //                 the edge position ("no earlier cube contains it").
-//                 Sign patterns are computed by every lane (phase A); the ~1 % of cubes the surface cuts go
-//                 through an LDS queue so the MC33 tests run densely (phase B).  Per-cube state: ONE byte.
+//                 Sign patterns are computed by every lane (phase A, brick-shaped workgroups marching in z); the ~1 %
+//                 of cubes the surface cuts go through an LDS queue so the MC33 tests run densely (phase B).
+//                 Per-cube state: ONE byte.
 //   2. scan       exclusive prefix sums of (created vertices, triangles, active cubes) over 1024-cube tiles in
 //                 scan order (1024-tile groups scanned in parallel, then the group totals).
 //   3. compact    active cubes -> list (cube id, vertex base, triangle base), still in scan order.
@@ -25,6 +26,8 @@
 //                 max of the cubes' value ranges, normalises in fp64.
 // HBM-bound integer/byte work: 4 B/voxel streamed once for classification is the algorithmic traffic
 // (442 MB at 480^3); the other passes touch only the ~1 % of cubes that are active.
+#include <math.h>
+
 #include "nm_internal.h"
 #include "mc_luts.h"
 
@@ -57,18 +60,34 @@ __device__ __forceinline__ void load_cube(const float* __restrict__ vol, const M
     c.v[6] = (double)p[s0 + s1 + 1] - iso; c.v[7] = (double)p[s0 + s1] - iso;
 }
 
+// c.v[i] for a run-time i as a select chain over REGISTER copies.  The empty asm makes each copy an opaque value:
+// without it the compiler rewrites select(load, load) as load(select(address, address)), keeps the cube in scratch
+// memory to index it, and every kernel that runs the MC33 tests pays for scratch (mc_vertex_attributes: 305 -> 84 us).
+__device__ __forceinline__ double pick(const Cube& c, int i) {
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = c.v[k];
+        asm("" : "+v"(a[k]));
+    }
+    double r = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = i == k ? a[k] : r;
+    return r;
+}
+
+// Lewiner's test_face.  All six faces' (A, A*C - B*D) are formed from statically indexed corners and the requested one
+// is selected afterwards: a switch over the corners (or a select chain over c.v[]) is turned into an indexed load by
+// the compiler, which moves the cube -- and every kernel that runs the MC33 tests -- to scratch memory.
 __device__ __forceinline__ bool test_face(const Cube& c, int face) {
     const double* v = c.v;
-    double A, B, C, D;
-    switch (face < 0 ? -face : face) {
-        case 1: A = v[0]; B = v[4]; C = v[5]; D = v[1]; break;
-        case 2: A = v[1]; B = v[5]; C = v[6]; D = v[2]; break;
-        case 3: A = v[2]; B = v[6]; C = v[7]; D = v[3]; break;
-        case 4: A = v[3]; B = v[7]; C = v[4]; D = v[0]; break;
-        case 5: A = v[0]; B = v[3]; C = v[2]; D = v[1]; break;
-        default: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
-    }
-    const double acbd = A * C - B * D;
+    const int f = face < 0 ? -face : face;
+    double A = v[4], acbd = v[4] * v[6] - v[7] * v[5];                       // face 6 (and anything else)
+    if (f == 1) { A = v[0]; acbd = v[0] * v[5] - v[4] * v[1]; }
+    if (f == 2) { A = v[1]; acbd = v[1] * v[6] - v[5] * v[2]; }
+    if (f == 3) { A = v[2]; acbd = v[2] * v[7] - v[6] * v[3]; }
+    if (f == 4) { A = v[3]; acbd = v[3] * v[4] - v[7] * v[0]; }
+    if (f == 5) { A = v[0]; acbd = v[0] * v[2] - v[3] * v[1]; }
     if (acbd > -SK_EPS && acbd < SK_EPS) return face >= 0;
     return face * A * acbd >= 0;
 }
@@ -79,7 +98,7 @@ __device__ __constant__ signed char MC_INTERIOR_EDGES[12][8] = {
     {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2}, {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0},
     {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
 
-__device__ bool test_interior(const Cube& c, int kase, int cfg, int subcfg, int s) {
+__device__ __forceinline__ bool test_interior(const Cube& c, int kase, int cfg, int subcfg, int s) {   // inlined: a call would pin the cube in scratch
     const double* v = c.v;
     double t, At = 0, Bt, Ct, Dt;
     if (kase == 4 || kase == 10) {
@@ -98,10 +117,12 @@ __device__ bool test_interior(const Cube& c, int kase, int cfg, int subcfg, int 
         else if (kase == 12) edge = lut(MC_TEST12_OFF + cfg * MC_TEST12_ROW + 3);
         else edge = lut(MC_TILING13_5_1_OFF + (cfg * MC_TILING13_5_1_SUB + subcfg) * MC_TILING13_5_1_ROW);
         const signed char* e = MC_INTERIOR_EDGES[edge];
-        t = v[e[0]] / (v[e[0]] - v[e[1]] + SK_EPS);
-        Bt = v[e[2]] + (v[e[3]] - v[e[2]]) * t;
-        Ct = v[e[4]] + (v[e[5]] - v[e[4]]) * t;
-        Dt = v[e[6]] + (v[e[7]] - v[e[6]]) * t;
+        const double p0 = pick(c, e[0]), p1 = pick(c, e[1]), p2 = pick(c, e[2]), p3 = pick(c, e[3]);
+        const double p4 = pick(c, e[4]), p5 = pick(c, e[5]), p6 = pick(c, e[6]), p7 = pick(c, e[7]);
+        t = p0 / (p0 - p1 + SK_EPS);
+        Bt = p2 + (p3 - p2) * t;
+        Ct = p4 + (p5 - p4) * t;
+        Dt = p6 + (p7 - p6) * t;
     }
     const int test = (At >= 0 ? 1 : 0) + (Bt >= 0 ? 2 : 0) + (Ct >= 0 ? 4 : 0) + (Dt >= 0 ? 8 : 0);
     switch (test) {
@@ -118,7 +139,7 @@ __device__ bool test_interior(const Cube& c, int kase, int cfg, int subcfg, int 
 #define MC_T2(NAME, cfg, k) lut(MC_##NAME##_OFF + (cfg) * MC_##NAME##_ROW + (k))
 
 // Lewiner's process_cube: -> tiling row offset in MC_LUT and triangle count (0 = empty cube)
-__device__ void select_tiling(const Cube& c, int index, int& offset, int& nt) {
+__device__ __forceinline__ void select_tiling(const Cube& c, int index, int& offset, int& nt) {
     const int kase = lut(MC_CASES_OFF + 2 * index), cfg = lut(MC_CASES_OFF + 2 * index + 1);
     offset = 0; nt = 0;
     int sub = 0;
@@ -288,85 +309,134 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 }
 
 // ---- pass 1: classify ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(MC_BLOCK) void mc_classify(const float* __restrict__ vol, McDims d, double iso,
-                                                        uint32_t* __restrict__ codes4, uint4* __restrict__ tile_sums) {
-    __shared__ uint32_t s_v[MC_BLOCK / 64], s_t[MC_BLOCK / 64], s_a[MC_BLOCK / 64];
-    __shared__ uint32_t s_code[MC_BLOCK];            // the tile's 1024 code bytes
-    __shared__ uint32_t s_queue[MC_TILE];            // active cubes of the tile: local id | corner pattern << 16
+// Brick-shaped workgroups: 32 x-groups (4 cubes each) x 8 y x MC_ZRUN z.  A thread walks MC_ZRUN cubes up the z axis
+// and keeps the sign bits of the plane below in registers, so every voxel row is fetched by two cube rows of the SAME
+// workgroup (L1 hits) instead of four rows spread over tiles that run on different XCDs -- the scan-order tiling
+// of the first version re-read the volume ~3x across L2s and ran at 0.7 TB/s.
+constexpr int MC_ZRUN = 8;
+constexpr int MC_BRICK_CUBES = MC_BLOCK * MC_ITEMS * MC_ZRUN;       // 8192
+
+struct __attribute__((packed)) McWord { uint32_t v; };              // 4 code bytes at any byte offset
+
+// sign bits of the 5 voxels row[x0 .. x0+4]; FAST: all five exist (one 16-byte + one 4-byte load, branch-free so that
+// the caller's 18 row fetches are all issued before the first use); otherwise voxels past the row end read as 0.
+// `thr` is the largest float <= iso: (double)v > iso  <=>  v > thr exactly, without 180 fp64 conversions per thread.
+template <bool FAST>
+__device__ __forceinline__ unsigned row_bits(const float* __restrict__ row, int x0, int n2, float thr) {
+    unsigned bits = 0;
+    if constexpr (FAST) {
+        struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+        const F4 q = *reinterpret_cast<const F4*>(row + x0);
+        const float last = row[x0 + 4];
+        bits = (q.v[0] > thr ? 1u : 0u) | (q.v[1] > thr ? 2u : 0u) | (q.v[2] > thr ? 4u : 0u) | (q.v[3] > thr ? 8u : 0u) |
+               (last > thr ? 16u : 0u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (x0 + k < n2) bits |= (row[x0 + k] > thr) ? (1u << k) : 0u;
+    }
+    return bits;
+}
+
+template <int BX>   // x-groups per workgroup (BX * 16 bytes contiguous per voxel row); MC_BLOCK / BX cube rows in y
+__global__ __launch_bounds__(MC_BLOCK) void mc_classify(const float* __restrict__ vol, McDims d, double iso, float thr,
+                                                        uint8_t* __restrict__ codes) {
+    constexpr int BY = MC_BLOCK / BX;
+    __shared__ uint32_t s_queue[MC_BRICK_CUBES];     // cut cubes of the brick: local id | corner pattern << 16
     __shared__ uint32_t s_count;
-    uint32_t nv = 0, ntri = 0, nact = 0;
-    const int64_t tile_base = (int64_t)blockIdx.x * MC_TILE;
-    const int64_t first = tile_base + (int64_t)threadIdx.x * MC_ITEMS;
-    s_code[threadIdx.x] = 0;
+    const int tx = threadIdx.x % BX, ty = threadIdx.x / BX;
+    const int x0 = (blockIdx.x * BX + tx) * MC_ITEMS, y = blockIdx.y * BY + ty, z0 = blockIdx.z * MC_ZRUN;
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    // ---- phase A (uniform, every lane busy): corner sign patterns; surface cubes go to an LDS queue.
-    // Only ~1 % of the cubes are cut by the surface, but 84 % of the 256-cube wavefronts contain at least one:
-    // running the MC33 tests in place would serialise almost every wave on a handful of lanes.
-    if (first < d.cubes) {
-        int z, y, x;
-        cube_coords(d, first, z, y, x);
-        int idx4[MC_ITEMS];
-        const bool same_row = x + MC_ITEMS <= d.c2 && first + MC_ITEMS <= d.cubes;
-        if (same_row) {
-            // the 4 cubes share 4 voxel rows of 5 voxels: one 16-byte + one 4-byte load per row
-            struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
-            const int64_t s1 = d.n2, s0 = (int64_t)d.n1 * d.n2;
-            const float* p = vol + (int64_t)z * s0 + (int64_t)y * s1 + x;
-            const float* rows[4] = {p, p + s1, p + s0, p + s0 + s1};
-            unsigned bits[4];
+    // ---- phase A (uniform): sign patterns, zeroed code bytes, cut cubes into the LDS queue
+    if (x0 < d.c2 && y < d.c1) {
+        const int64_t s1 = d.n2, s0 = (int64_t)d.n1 * d.n2;
+        const float* base = vol + (int64_t)y * s1;
+        // all 2 x (MC_ZRUN + 1) row fetches are issued before the first use: a workgroup lives for one memory round
+        // trip instead of MC_ZRUN of them (planes past the volume are clamped and never used)
+        unsigned bits_a[MC_ZRUN + 1], bits_b[MC_ZRUN + 1];
+        if (x0 + 4 < d.n2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const F4 q = *reinterpret_cast<const F4*>(rows[r]);
-                const float last = rows[r][4];
-                bits[r] = ((double)q.v[0] > iso ? 1u : 0u) | ((double)q.v[1] > iso ? 2u : 0u) | ((double)q.v[2] > iso ? 4u : 0u) |
-                          ((double)q.v[3] > iso ? 8u : 0u) | ((double)last > iso ? 16u : 0u);
+            for (int l = 0; l <= MC_ZRUN; ++l) {
+                const int zz = z0 + l < d.n0 ? z0 + l : d.n0 - 1;
+                bits_a[l] = row_bits<true>(base + (int64_t)zz * s0, x0, d.n2, thr);
+                bits_b[l] = row_bits<true>(base + (int64_t)zz * s0 + s1, x0, d.n2, thr);
             }
+        } else {   // the last x-group of a row
 #pragma unroll
-            for (int k = 0; k < MC_ITEMS; ++k) {
-                const unsigned a = bits[0] >> k, b = bits[1] >> k, c = bits[2] >> k, e = bits[3] >> k;
-                idx4[k] = (int)((a & 1u) | ((a >> 1 & 1u) << 1) | ((b >> 1 & 1u) << 2) | ((b & 1u) << 3) |
-                                ((c & 1u) << 4) | ((c >> 1 & 1u) << 5) | ((e >> 1 & 1u) << 6) | ((e & 1u) << 7));
+            for (int l = 0; l <= MC_ZRUN; ++l) {
+                const int zz = z0 + l < d.n0 ? z0 + l : d.n0 - 1;
+                bits_a[l] = row_bits<false>(base + (int64_t)zz * s0, x0, d.n2, thr);
+                bits_b[l] = row_bits<false>(base + (int64_t)zz * s0 + s1, x0, d.n2, thr);
             }
         }
+        const int valid = d.c2 - x0 < MC_ITEMS ? d.c2 - x0 : MC_ITEMS;
 #pragma unroll
-        for (int it = 0; it < MC_ITEMS; ++it) {
-            if (first + it < d.cubes) {
-                const int index = same_row ? idx4[it] : cube_index(vol, d, z, y, x, iso);
-                if (index != 0 && index != 255)
-                    s_queue[atomicAdd(&s_count, 1u)] = (uint32_t)(threadIdx.x * MC_ITEMS + it) | ((uint32_t)index << 16);
-                next_cube(d, z, y, x);
+        for (int l = 0; l < MC_ZRUN; ++l) {
+            const int z = z0 + l;
+            if (z < d.c0) {
+                uint8_t* dst = codes + ((int64_t)z * d.c1 + y) * d.c2 + x0;
+                if (valid == MC_ITEMS) reinterpret_cast<McWord*>(dst)->v = 0u;
+                else for (int k = 0; k < valid; ++k) dst[k] = 0;
+#pragma unroll
+                for (int k = 0; k < MC_ITEMS; ++k) {
+                    const unsigned a = bits_a[l] >> k, b = bits_b[l] >> k, c = bits_a[l + 1] >> k, e = bits_b[l + 1] >> k;
+                    const unsigned index = (a & 1u) | ((a >> 1 & 1u) << 1) | ((b >> 1 & 1u) << 2) | ((b & 1u) << 3) |
+                                           ((c & 1u) << 4) | ((c >> 1 & 1u) << 5) | ((e >> 1 & 1u) << 6) | ((e & 1u) << 7);
+                    if (k < valid && index != 0u && index != 255u)
+                        s_queue[atomicAdd(&s_count, 1u)] = (uint32_t)((threadIdx.x * MC_ZRUN + l) * MC_ITEMS + k) | (index << 16);
+                }
             }
         }
     }
-    __syncthreads();
+    __syncthreads();   // also orders the zero stores above before the code bytes below (s_waitcnt vmcnt(0) + s_barrier)
     // ---- phase B (dense): MC33 face / interior tests and the created-vertex count of the queued cubes
     const uint32_t queued = s_count;
     for (uint32_t q = threadIdx.x; q < queued; q += MC_BLOCK) {
         const uint32_t ent = s_queue[q];
         const int local = (int)(ent & 0xffffu), index = (int)(ent >> 16);
-        int z, y, x;
-        cube_coords(d, tile_base + local, z, y, x);
+        const int k = local % MC_ITEMS, l = (local / MC_ITEMS) % MC_ZRUN, t = local / (MC_ITEMS * MC_ZRUN);
+        const int x = (blockIdx.x * BX + t % BX) * MC_ITEMS + k, yy = blockIdx.y * BY + t / BX, z = z0 + l;
         Cube c;
-        load_cube(vol, d, z, y, x, iso, c);
+        load_cube(vol, d, z, yy, x, iso, c);
         int off, nt;
         select_tiling(c, index, off, nt);
-        const int created = count_created(off, nt, z, y, x);
-        atomicOr(&s_code[local >> 2], pack_code(nt, created) << (8 * (local & 3)));
-        nv += created; ntri += nt; nact += nt > 0 ? 1 : 0;
+        if (nt > 0) codes[((int64_t)z * d.c1 + yy) * d.c2 + x] = (uint8_t)pack_code(nt, count_created(off, nt, z, yy, x));
     }
-    __syncthreads();
-    const uint32_t word = s_code[threadIdx.x];
-    const int64_t w = (int64_t)blockIdx.x * MC_BLOCK + threadIdx.x;     // code dword of this thread
-    if (w * MC_ITEMS < ((d.cubes + 3) & ~int64_t(3))) codes4[w] = word;
+}
+
+// per-tile (1024 cubes in scan order) sums of created vertices / triangles / active cubes, from the code bytes:
+// one wavefront per tile, 16 cubes (one 16-byte load) per lane -- a workgroup per tile is dispatch-bound (91 us)
+__device__ __forceinline__ uint4 load_codes16(const McDims& d, const uint32_t* __restrict__ codes4, int64_t first) {
+    if (first >= d.cubes) return make_uint4(0, 0, 0, 0);
+    uint4 w = *reinterpret_cast<const uint4*>(codes4 + (first >> 2));      // the buffer is padded by 4 KiB
+    const int64_t left = d.cubes - first;                                  // cubes from `first` to the end
+    uint32_t* p = &w.x;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t have = left - 4 * q;
+        if (have <= 0) p[q] = 0u;
+        else if (have < 4) p[q] &= (1u << (8 * (int)have)) - 1u;
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(256) void mc_tile_sums(McDims d, const uint32_t* __restrict__ codes4, int64_t tiles,
+                                                    uint4* __restrict__ tile_sums) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles) return;
+    const uint4 w = load_codes16(d, codes4, tile * MC_TILE + lane * 16);
+    uint32_t nv = 0, ntri = 0, nact = 0;
+    const uint32_t* p = &w.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t c = p[q] >> (8 * it);
+            nv += code_created(c); ntri += code_nt(c); nact += code_nt(c) ? 1 : 0;
+        }
     for (int o = 32; o > 0; o >>= 1) { nv += __shfl_xor(nv, o); ntri += __shfl_xor(ntri, o); nact += __shfl_xor(nact, o); }
-    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = nv; s_t[threadIdx.x >> 6] = ntri; s_a[threadIdx.x >> 6] = nact; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t a = 0, b = 0, c = 0;
-        for (int q = 0; q < MC_BLOCK / 64; ++q) { a += s_v[q]; b += s_t[q]; c += s_a[q]; }
-        tile_sums[blockIdx.x] = make_uint4(a, b, c, 0);
-    }
+    if (lane == 0) tile_sums[tile] = make_uint4(nv, ntri, nact, 0);
 }
 
 // ---- pass 2: exclusive scan of the per-tile sums: 1024-tile groups in parallel, then the group totals ------
@@ -435,19 +505,24 @@ struct McActive {      // one entry per cube that emits triangles, in scan order
 };
 
 // ---- pass 3a: compact the active cubes (scan order) with their vertex / triangle bases -----------------------
-__global__ __launch_bounds__(MC_BLOCK) void mc_compact(McDims d, const uint32_t* __restrict__ codes4,
-                                                       const uint4* __restrict__ tile_prefix,
-                                                       const uint4* __restrict__ group_prefix, McActive* __restrict__ list) {
-    __shared__ uint32_t s_w[3][MC_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t first = (int64_t)blockIdx.x * MC_TILE + (int64_t)threadIdx.x * MC_ITEMS;
-    const uint32_t word = first < d.cubes ? codes4[(int64_t)blockIdx.x * MC_BLOCK + threadIdx.x] : 0u;
+// one wavefront per tile, 16 cubes per lane, wave-level exclusive scan
+__global__ __launch_bounds__(256) void mc_compact(McDims d, const uint32_t* __restrict__ codes4, int64_t tiles,
+                                                  const uint4* __restrict__ tile_prefix,
+                                                  const uint4* __restrict__ group_prefix, McActive* __restrict__ list) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles) return;
+    const int64_t first = tile * MC_TILE + lane * 16;
+    const uint4 w = load_codes16(d, codes4, first);
+    const uint32_t* p = &w.x;
     uint32_t own[3] = {0, 0, 0};
 #pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        const uint32_t c = word >> (8 * it);
-        own[0] += code_created(c); own[1] += code_nt(c); own[2] += code_nt(c) ? 1 : 0;
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t c = p[q] >> (8 * it);
+            own[0] += code_created(c); own[1] += code_nt(c); own[2] += code_nt(c) ? 1 : 0;
+        }
     uint32_t inc[3] = {own[0], own[1], own[2]};
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -455,22 +530,20 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_compact(McDims d, const uint32_t*
             const uint32_t pv = __shfl_up(inc[k], o);
             if (lane >= o) inc[k] += pv;
         }
-    if (lane == 63) { s_w[0][wave] = inc[0]; s_w[1][wave] = inc[1]; s_w[2][wave] = inc[2]; }
-    __syncthreads();
-    if (word == 0) return;
-    const uint4 tp = tile_prefix[blockIdx.x], gp = group_prefix[blockIdx.x >> 10];
+    if (own[2] == 0) return;
+    const uint4 tp = tile_prefix[tile], gp = group_prefix[tile >> 10];
     uint32_t pre[3] = {gp.x + tp.x + inc[0] - own[0], gp.y + tp.y + inc[1] - own[1], gp.z + tp.z + inc[2] - own[2]};
-    for (int q = 0; q < MC_BLOCK / 64; ++q)
-        if (q < wave) { pre[0] += s_w[0][q]; pre[1] += s_w[1][q]; pre[2] += s_w[2][q]; }
 #pragma unroll
-    for (int it = 0; it < MC_ITEMS; ++it) {
-        const uint32_t c = word >> (8 * it);
-        if (code_nt(c)) {
-            McActive e; e.id = first + it; e.vbase = pre[0]; e.tbase = pre[1];
-            list[pre[2]++] = e;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t c = p[q] >> (8 * it);
+            if (code_nt(c)) {
+                McActive e; e.id = first + 4 * q + it; e.vbase = pre[0]; e.tbase = pre[1];
+                list[pre[2]++] = e;
+            }
+            pre[0] += code_created(c); pre[1] += code_nt(c);
         }
-        pre[0] += code_created(c); pre[1] += code_nt(c);
-    }
 }
 
 // ---- pass 3b: vertices and faces, one thread per ACTIVE cube (all lanes busy) ---------------------------------
@@ -511,7 +584,7 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
                 const signed char* eb = MC_EDGE_B[e];
                 const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
                 const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
-                const double w1 = 1.0 / (SK_EPS + fabs(c.v[ka])), w2 = 1.0 / (SK_EPS + fabs(c.v[kb]));
+                const double w1 = 1.0 / (SK_EPS + fabs(pick(c, ka))), w2 = 1.0 / (SK_EPS + fabs(pick(c, kb)));
                 double fx = 0, fy = 0, fz = 0, ff = 0;
                 fx += (double)ea[2] * w1; fy += (double)ea[1] * w1; fz += (double)ea[0] * w1; ff += w1;
                 fx += (double)eb[2] * w2; fy += (double)eb[1] * w2; fz += (double)eb[0] * w2; ff += w2;
@@ -617,7 +690,7 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
         corner_gradients(c, g);
         float gx = 0, gy = 0, gz = 0;   // contribution per reference
         float s1 = 0, s2 = 0;
-        int i1 = 0, i2 = 0;
+        double ga[3] = {0, 0, 0}, gb[3] = {0, 0, 0};   // gradients at the two ends of the edge (select chains, no scratch)
         if (e == 12) {
             double w[8], sx = 0, sy = 0, sz = 0;
 #pragma unroll
@@ -629,9 +702,16 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
         } else {
             const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;
             const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4;
-            i1 = bitwise_index(MC_EDGE_A[e]); i2 = bitwise_index(MC_EDGE_B[e]);
-            s1 = (float)(1.0 / (SK_EPS + fabs(c.v[ka])));   // `strength` is a C float in skimage
-            s2 = (float)(1.0 / (SK_EPS + fabs(c.v[kb])));
+            const int i1 = bitwise_index(MC_EDGE_A[e]), i2 = bitwise_index(MC_EDGE_B[e]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    ga[a] = i1 == q ? g[3 * q + a] : ga[a];
+                    gb[a] = i2 == q ? g[3 * q + a] : gb[a];
+                }
+            s1 = (float)(1.0 / (SK_EPS + fabs(pick(c, ka))));   // `strength` is a C float in skimage
+            s2 = (float)(1.0 / (SK_EPS + fabs(pick(c, kb))));
         }
         bool referenced = false;
         for (int i = 0; i < 3 * nt; ++i) {
@@ -639,8 +719,8 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
             referenced = true;
             if (e == 12) { nx += gx; ny += gy; nz += gz; }
             else {
-                nx += (float)(g[3 * i1] * (double)s1); ny += (float)(g[3 * i1 + 1] * (double)s1); nz += (float)(g[3 * i1 + 2] * (double)s1);
-                nx += (float)(g[3 * i2] * (double)s2); ny += (float)(g[3 * i2 + 1] * (double)s2); nz += (float)(g[3 * i2 + 2] * (double)s2);
+                nx += (float)(ga[0] * (double)s1); ny += (float)(ga[1] * (double)s1); nz += (float)(ga[2] * (double)s1);
+                nx += (float)(gb[0] * (double)s2); ny += (float)(gb[1] * (double)s2); nz += (float)(gb[2] * (double)s2);
             }
         }
         if (referenced && vmax > (double)value) value = (float)vmax;
@@ -704,7 +784,17 @@ int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, doubl
     NM_REQUIRE(d.cubes < (int64_t(1) << 40), "volume too large");
     McWorkspace ws;
     carve(d, static_cast<char*>(d_workspace), &ws);
-    hipLaunchKernelGGL(mc_classify, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, ws.codes,
+    constexpr int bx = 32, by = MC_BLOCK / bx;   // 64 / 128 x-groups per workgroup measured the same
+    const dim3 bricks((unsigned)(((d.c2 + MC_ITEMS - 1) / MC_ITEMS + bx - 1) / bx), (unsigned)((d.c1 + by - 1) / by),
+                      (unsigned)((d.c0 + MC_ZRUN - 1) / MC_ZRUN));
+    NM_REQUIRE(bricks.y <= 65535u && bricks.z <= 65535u, "volume too large");
+    // the (<= 3) code bytes behind the last cube share a dword with real cubes: keep them zero for the word readers
+    NM_HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t*>(ws.codes) + (d.cubes & ~int64_t(3)), 0, 8, stream));
+    float thr = (float)iso;                        // largest float <= iso (exact equivalence of the sign test)
+    if ((double)thr > iso) thr = nextafterf(thr, -INFINITY);
+    hipLaunchKernelGGL(mc_classify<bx>, bricks, dim3(MC_BLOCK), 0, stream, d_volume, d, iso, thr,
+                       reinterpret_cast<uint8_t*>(ws.codes));
+    hipLaunchKernelGGL(mc_tile_sums, dim3((unsigned)((ws.tiles + 3) / 4)), dim3(256), 0, stream, d, ws.codes, ws.tiles,
                        ws.tile_sums);
     const int64_t groups = (ws.tiles + 1023) / 1024;
     hipLaunchKernelGGL(mc_scan_groups, dim3((unsigned)groups), dim3(1024), 0, stream, ws.tile_sums, ws.tiles, ws.group_sums);
@@ -734,8 +824,8 @@ int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double
     out.verts = d_verts; out.faces = d_faces; out.normals = d_normals; out.values = d_values;
     for (int a = 0; a < 3; ++a) out.edge_vertex[a] = ws.edge[a];
     const unsigned ablocks = (unsigned)((faces + 255) / 256);   // active cubes <= faces; surplus threads exit
-    hipLaunchKernelGGL(mc_compact, dim3((unsigned)ws.tiles), dim3(MC_BLOCK), 0, stream, d, ws.codes, ws.tile_sums, ws.group_sums,
-                       ws.active);
+    hipLaunchKernelGGL(mc_compact, dim3((unsigned)((ws.tiles + 3) / 4)), dim3(256), 0, stream, d, ws.codes, ws.tiles,
+                       ws.tile_sums, ws.group_sums, ws.active);
     hipLaunchKernelGGL(mc_emit<false>, dim3(ablocks), dim3(256), 0, stream, d_volume, d, iso, ws.active, ws.totals, out,
                        ws.vertex_cube, ws.vertex_edge);
     hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, d, iso, ws.active, ws.totals, out,
