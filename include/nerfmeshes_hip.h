@@ -268,6 +268,15 @@ int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double
                void* d_vertex_scratch, int64_t vertices, int64_t faces, float* d_verts, int32_t* d_faces,
                float* d_normals, float* d_values, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mesh export: export_obj (src/nerf/nerf_helpers.py:86-111), byte-identical text.  HOST arrays:
+ * vertices (V,3), diffuse (C,3) with C <= V allowed (colours only while they last), normals (N,3),
+ * triangles (F,3) int32, 0-based.  Numbers are printed as Python prints repr(float(x)).  Multi-threaded.
+ * ------------------------------------------------------------------------------------------ */
+int nm_export_obj(const float* h_vertices, int64_t num_vertices, const float* h_diffuse, int64_t num_diffuse,
+                  const float* h_normals, int64_t num_normals, const int32_t* h_triangles, int64_t num_triangles,
+                  const char* path);
+
 #ifdef __cplusplus
 }
 #endif

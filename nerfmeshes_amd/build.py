@@ -14,7 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libnerfmeshes_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["nerf_mlp.hip", "nerf_train.hip", "mlp_api.hip", "ray_ops.hip", "marching_cubes.hip", "buff_tree.hip"]
+SOURCES = ["nerf_mlp.hip", "nerf_train.hip", "mlp_api.hip", "ray_ops.hip", "marching_cubes.hip", "buff_tree.hip", "obj_writer.cpp"]
 HEADERS = ["nm_internal.h", "mlp_device.h", os.path.join("..", "..", "include", "nerfmeshes_hip.h"), "mc_luts.h"]
 # -ffp-contract=off: the reference computes a*b+c with two roundings (torch eager ops); every fused
 # multiply-add in the kernels is an explicit fmaf()/MFMA.
@@ -48,7 +48,7 @@ def build(force=False, verbose=True):
     procs = []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for src in _present(SOURCES):
-        obj = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, "build", os.path.splitext(src)[0] + ".o")
         cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
