@@ -60,7 +60,10 @@ def fit(model, batches, iters, log_every=0):
         nd.all_reduce_gradients(model.parameters())
         optimizer.step()
         scheduler.step()
-        model.global_step = step + 1
+        try:
+            model.global_step = step + 1          # a LightningModule's global_step belongs to its Trainer
+        except AttributeError:
+            pass
         losses.append(out["loss"].detach())
         if log_every and (step + 1) % log_every == 0:
             print(f"step {step + 1}: loss {float(losses[-1]):.5f} psnr {float(mse2psnr(out['log']['train/fine_loss'])):.2f}")
