@@ -2,6 +2,8 @@
 // feature -> view branch -> rgb in ONE kernel, fp32 MFMA (v_mfma_f32_16x16x4_f32), activations
 // never leave registers, weights streamed L2 -> LDS with global_load_lds (direct-to-LDS DMA).
 //
+// The kernel template itself lives in mlp_device.h (shared with the training kernels of nerf_train.hip);
+// this file holds the plan table and the launcher.
 // Replaces (reference file:line under /root/reference/src):
 //   nerf/modules.py:26-34      PositionalEncoding.forward      (expand, mul, view, sin, cos, cat)
 //   nerf/models.py:60-80       FlexibleNeRFModel.forward       (12x addmm, 9x relu, 3x cat, sigmoid)
@@ -14,9 +16,9 @@
 //   B (activ.) : lane l holds act[k = l>>4][sample = l&15]      (one VGPR)
 //   D          : lane l, reg r holds out[row = 4*(l>>4)+r][sample = l&15]
 // so D of tile nt, register r is exactly the B operand of the NEXT layer's k-step s = 4*nt + r, in
-// which lane group g = l>>4 supplies input feature k = 16*nt + 4*g + r.  The host packer
-// (mlp_pack.cpp) permutes the weight columns accordingly, which is why bias+ReLU'd accumulators
-// feed the next layer's MFMAs directly: no LDS round trip, no transposes, no HBM traffic for
+// which lane group g = l>>4 supplies input feature k = 16*nt + 4*g + r.  The packer (mlp_api.hip: an
+// index map built once on the host + one gather kernel) permutes the weight columns accordingly, which
+// is why bias+ReLU'd accumulators feed the next layer's MFMAs directly: no LDS round trip, no transposes, no HBM traffic for
 // activations.  Weights (2.4 MB / model, L2-resident) are the only streamed operand:
 // every workgroup pulls the same linear "A-operand stream" through a 2-deep LDS ring in 8-k-step
 // chunks; each lane reads its operands for 4 consecutive output tiles with one conflict-free
