@@ -53,6 +53,11 @@ def forward_train(mlp, origins, dirs, t):
     n, H, L = rays * samples, int(mlp.desc["hidden_size"]), int(mlp.desc["num_layers"])
     tiles = (n + 15) // 16
     f32 = dict(dtype=torch.float32, device=mlp.device)
+    tape_bytes = 4 * n * (L * H + H + H // 2)
+    if 2.1 * tape_bytes > torch.cuda.get_device_properties(mlp.device).total_memory:     # tape + deltas of the backward
+        raise _lib.HipLibraryError(
+            f"the training tape of {rays} rays x {samples} samples needs {tape_bytes / 2**30:.0f} GiB (+ as much for the "
+            "deltas): use a smaller ray chunk, or torch.no_grad() if this is inference")
     tape = dict(h=torch.empty(L, n, H, **f32), feat=torch.empty(n, H, **f32), v=torch.empty(n, H // 2, **f32),
                 mask_h=torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
                 mask_v=torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
