@@ -13,7 +13,6 @@ skipped; sigma is bit-identical to the full evaluation).
 import argparse
 import os
 
-import numpy as np
 import torch
 
 from . import hip_ops, models

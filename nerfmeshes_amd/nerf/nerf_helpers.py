@@ -1,5 +1,4 @@
 """Helper functions the three scripts import by name (mirror of /root/reference/src/nerf/nerf_helpers.py)."""
-import math
 import os
 
 import numpy as np

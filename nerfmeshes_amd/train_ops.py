@@ -16,7 +16,7 @@ import ctypes as C
 import torch
 
 from . import _lib, hip_ops
-from ._lib import BundleGrads, BundleOut, MlpDeltas, MlpTape, MlpWeights, check
+from ._lib import BundleGrads, MlpDeltas, MlpTape, MlpWeights, check
 from .hip_ops import _dev32, _ptr, _stream
 
 
