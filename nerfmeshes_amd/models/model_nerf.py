@@ -124,7 +124,9 @@ class NeRFModel(BaseModel):
         loss = coarse_loss
         if self.cfg.models.use_fine:
             fine_loss /= batch_count
-            loss = loss + fine_loss
+            # in place, as the reference (model_nerf.py:137): `loss` aliases `coarse_loss`, so the logged
+            # train/coarse_loss becomes the total loss while train/coarse_psnr keeps the coarse value
+            loss += fine_loss
             log.update({"train/fine_loss": fine_loss, "train/fine_psnr": self.criterion_psnr(fine_loss)})
         return {"loss": loss, "log": {"train/loss": loss, **log, "train/lr": self._current_lr()}}
 
@@ -147,7 +149,7 @@ class NeRFModel(BaseModel):
         images = {"validation/rgb_coarse/": torch.cat(rgb_c, 0)}
         if self.model_fine is not None:
             fine_loss /= batch_count
-            loss = loss + fine_loss
+            loss += fine_loss                      # in place: the same aliasing as in training_step (model_nerf.py:195)
             log.update({"validation/fine_loss": fine_loss, "validation/fine_psnr": self.criterion_psnr(fine_loss)})
             images["validation/rgb_fine/"] = torch.cat(rgb_f, 0)
         experiment = getattr(getattr(self, "logger", None), "experiment", None)

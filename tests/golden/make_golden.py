@@ -250,6 +250,39 @@ def case_buff_tree(name):
     print(name, [out[f"voxels_after{k}"].shape[0] for k in (1, 2)], "voxels after the two rounds")
 
 
+def case_train_step(name):
+    """(f)-2: the UNMODIFIED reference's NeRFModel.training_step (model_nerf.py:88-151) on a fixed ray batch in
+    train() mode (perturb off, noise 0 -- the deterministic part of the step), then loss.backward(): loss, the logged
+    values and the gradient of all 54 tensors.  Two chunks, the second one ragged (float batch_count)."""
+    nerf, models = ref_import.load()
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = S.hparams(num_coarse=16, num_fine=16, chunksize=96, train_noise_std=0.0, **kw)
+    torch.manual_seed(7)
+    m = models.NeRFModel(hp)
+    with torch.no_grad():
+        for net in (m.model_coarse, m.model_fine):
+            net.fc_alpha.weight.mul_(40.0)
+    m.train()
+    m.trainer = type("T", (), {"optimizers": [type("O", (), {"param_groups": [{"lr": 5e-3}]})()]})()
+    g = torch.Generator().manual_seed(3)
+    rays = 150                                                   # 96 + 54
+    o = torch.tensor([0.2, -0.1, 3.5])
+    d = torch.nn.functional.normalize(torch.tensor([[0.0, 0.1, -1.0]]) + 0.3 * torch.randn(rays, 3, generator=g), dim=-1)
+    target = torch.rand(rays, 3, generator=g)
+    batch = dict(ray_origins=o[None], ray_directions=d[None], ray_targets=target[None], ray_bounds=torch.tensor([[2.0, 6.0]]))
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
+    res = dict(origin=o.numpy(), directions=d.numpy(), targets=target.numpy(), loss=float(out["loss"]),
+               hparams_keys=np.array(list(hp.keys())), hparams_vals=np.array([repr(v) for v in hp.values()]))
+    for k, v in out["log"].items():
+        res["log." + k] = np.float32(float(v))
+    for k, p in m.named_parameters():
+        res["param." + k] = p.detach().numpy().copy()
+        res["grad." + k] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print(name, "loss", float(out["loss"]), "tensors", sum(1 for _ in m.named_parameters()))
+
+
 def case_obj(name):
     """(f)-1: the reference's OBJ text writer (nerf_helpers.py:86-111) on a tiny mesh."""
     import contextlib, io
@@ -273,8 +306,11 @@ if __name__ == "__main__":
         case_buff("buff_fern")
     elif "--buff-tree" in sys.argv:
         case_buff_tree("buff_tree")
+    elif "--train-step" in sys.argv:
+        case_train_step("train_step")
     else:
         main()
         case_buff("buff_fern")
         case_buff_tree("buff_tree")
+        case_train_step("train_step")
         case_obj("export_obj")

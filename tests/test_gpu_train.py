@@ -304,3 +304,32 @@ def test_full_size_gradients_equal_the_sum_over_sub_batches():
         assert float(ref.abs().max()) > 0.0, k
         err = float((whole[k] - ref).abs().max() / ref.abs().max())
         assert err < 5e-4, (k, err)
+
+
+def test_training_step_against_the_reference_golden():
+    """NeRFModel.training_step on the MI355X against the UNMODIFIED reference's training_step (fixture
+    tests/golden/train_step.npz: loss, logged values, gradient of all 32 tensors; two chunks, the second ragged)."""
+    from tests.helpers import golden_hparams, load_golden
+    from nerfmeshes_amd import models
+    g = load_golden("train_step")
+    model = models.NeRFModel(golden_hparams(g))
+    state = model.state_dict()
+    for k in g.files:
+        if k.startswith("param."):
+            state[k[len("param."):]] = torch.from_numpy(g[k])
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    batch = dict(ray_origins=torch.from_numpy(g["origin"])[None, None], ray_directions=torch.from_numpy(g["directions"])[None],
+                 ray_targets=torch.from_numpy(g["targets"])[None], ray_bounds=torch.tensor([[2.0, 6.0]]))
+    out = model.training_step(batch, 0)
+    out["loss"].backward()
+    ref_loss = float(g["loss"])
+    assert abs(float(out["loss"].detach()) - ref_loss) < 1e-4 * ref_loss
+    for key in ("train/loss", "train/coarse_loss", "train/coarse_psnr", "train/fine_loss", "train/fine_psnr", "train/lr"):
+        assert key in out["log"], key
+        ref = float(g["log." + key])
+        assert abs(float(out["log"][key]) - ref) < 2e-4 * max(1.0, abs(ref)), (key, float(out["log"][key]), ref)
+    for name, p in model.named_parameters():
+        ref = torch.from_numpy(g["grad." + name])
+        assert p.grad is not None and p.grad.shape == ref.shape, name
+        assert _rel(p.grad, ref) < 2e-3, (name, _rel(p.grad, ref))

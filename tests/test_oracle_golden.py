@@ -178,3 +178,54 @@ def test_buff_tree_maintenance_matches_reference(capsys):
     assert np.array_equal(tree.voxels.numpy(), g["voxels_after2"])
     assert tree.voxels.shape[0] < int(g["max_voxel_count"])
     capsys.readouterr()
+
+
+def _train_step_golden():
+    g = load_golden("train_step")
+    hp = golden_hparams(g)
+    params = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    grads = {k[len("grad."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}
+    return g, hp, params, grads
+
+
+def test_training_step_loss_and_gradients_match_reference():
+    """(f)-2: autograd over the oracle chain reproduces the UNMODIFIED reference's training_step -- loss (with its
+    float batch_count over a ragged second chunk) and the gradient of all 32 tensors.  This pins the ground truth the
+    GPU gradient tests (tests/test_gpu_train.py) are measured against."""
+    g, hp, params, grads = _train_step_golden()
+    sc, sf, rs = specs_from_hparams(hp)
+    rs = O.RenderSpec(num_coarse=rs.num_coarse, num_fine=rs.num_fine, training=True)
+    w = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    wc = {k[len("model_coarse."):]: v for k, v in w.items() if k.startswith("model_coarse.")}
+    wf = {k[len("model_fine."):]: v for k, v in w.items() if k.startswith("model_fine.")}
+    o, d, tgt = torch.from_numpy(g["origin"])[None], torch.from_numpy(g["directions"]), torch.from_numpy(g["targets"])
+    chunk = int(hp["nerf.train.chunksize"])
+    batch_count = d.shape[0] / chunk
+    coarse_loss, fine_loss = 0, 0
+    for s in range(0, d.shape[0], chunk):
+        dd, tt = d[s:s + chunk], tgt[s:s + chunk]
+        t_c = O.coarse_intervals(2.0, 6.0, rs.num_coarse, dd.shape[0])
+        n = dd.shape[0]
+
+        def net(weights, spec, t):
+            pts = O.ray_points(t, dd, o).reshape(-1, 3)
+            dirs = dd[:, None, :].expand(-1, t.shape[1], -1).reshape(-1, 3)
+            return O.mlp_forward(weights, spec, pts, dirs, keep_graph=True).reshape(n, -1, 4)
+
+        bc = O.composite(net(wc, sc, t_c), t_c, dd, rs)
+        t_f = O.sample_pdf_intervals(t_c, bc["weights"].detach(), rs.num_fine)
+        bf = O.composite(net(wf, sf, t_f), t_f, dd, rs)
+        coarse_loss = coarse_loss + torch.nn.functional.mse_loss(bc["rgb_map"], tt)
+        fine_loss = fine_loss + torch.nn.functional.mse_loss(bf["rgb_map"], tt)
+    loss = coarse_loss / batch_count + fine_loss / batch_count
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6 * float(g["loss"])
+    # reference quirk (model_nerf.py:127-137): `loss = coarse_loss` aliases the tensor and `loss += fine_loss` adds in
+    # place, so the LOGGED train/coarse_loss is the total loss, while train/coarse_psnr was taken before the add
+    assert abs(float(g["log.train/coarse_loss"]) - float(g["loss"])) <= 1e-7
+    assert abs(float(O.mse2psnr((coarse_loss / batch_count).detach())) - float(g["log.train/coarse_psnr"])) <= 1e-4
+    assert abs(float((fine_loss / batch_count).detach()) - float(g["log.train/fine_loss"])) <= 1e-6
+    for k, ref in grads.items():
+        got = w[k].grad
+        assert got is not None and got.shape == ref.shape, k
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
