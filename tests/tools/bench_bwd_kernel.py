@@ -1,3 +1,4 @@
+"""Times nm_mlp_backward alone (8x256, 2048 rays x 192 samples); used for the PMC passes in profiles/r01_pmc_train_kernels.json."""
 import os, sys, json, torch, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nerfmeshes_amd import hip_ops, synthetic as S, train_ops as T, _lib
@@ -19,4 +20,4 @@ torch.cuda.synchronize(); a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Ev
 a.record()
 for _ in range(10): run()
 b.record(); torch.cuda.synchronize(); ms=a.elapsed_time(b)/10
-print(json.dumps({"abl":os.environ.get("NM_TRAIN_ABL","0"),"bwd_ms":ms,"tflops":2*(128*256+8*256*256)*n/ms/1e9}))
+print(json.dumps({"bwd_ms":ms,"tflops":2*(128*256+8*256*256)*n/ms/1e9}))
