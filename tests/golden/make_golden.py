@@ -283,6 +283,51 @@ def case_train_step(name):
     print(name, "loss", float(out["loss"]), "tensors", sum(1 for _ in m.named_parameters()))
 
 
+def case_buff_train_step(name):
+    """(f)-3: the UNMODIFIED reference's BuFFModel.training_step (model_buff.py:79-124; TensorBoard loggers stubbed) on
+    a fixed per-ray-origin batch, then loss.backward(): loss, logged values, the gradient of all 16 tensors."""
+    import contextlib, io
+    nerf, models = ref_import.load()
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=32, num_fine=32, near=0.0, far=1.2, dataset_type="colmap",
+                   train_noise_std=0.0, **kw)
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.BuFFModel(hp)
+    with torch.no_grad():
+        m.model.fc_alpha.weight.mul_(60.0)
+    m.train()
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return None
+        def __getattr__(self, k): return _Any()
+
+    m.trainer = type("T", (), {"optimizers": [type("O", (), {"param_groups": [{"lr": 5e-3}]})()]})()
+    m.logger = type("L", (), {"experiment": _Any()})()
+    m.global_step = 0
+    g = torch.Generator().manual_seed(3)
+    n = 96
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 0.9
+    d = torch.nn.functional.normalize(-o + 0.2 * torch.randn(n, 3, generator=g), dim=-1)
+    d[:6] = torch.nn.functional.normalize(o[:6], dim=-1)            # looking away: uniform samples replace the tree's
+    tgt = torch.rand(n, 3, generator=g)
+    batch = dict(ray_origins=o[None], ray_directions=d[None], ray_targets=tgt[None], ray_bounds=torch.tensor([[0.0, 1.2]]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = m.training_step(batch, 0)
+    out["loss"].backward()
+    res = dict(origins=o.numpy(), directions=d.numpy(), targets=tgt.numpy(), loss=float(out["loss"].detach()),
+               counter=m.tree.counter, hparams_keys=np.array(list(hp.keys())),
+               hparams_vals=np.array([repr(v) for v in hp.values()]))
+    for k, v in out["log"].items():
+        res["log." + k] = np.float32(float(v))
+    for k, p in m.named_parameters():
+        res["param." + k] = p.detach().numpy().copy()
+        res["grad." + k] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print(name, "loss", res["loss"], "tensors", sum(1 for _ in m.named_parameters()))
+
+
 def case_obj(name):
     """(f)-1: the reference's OBJ text writer (nerf_helpers.py:86-111) on a tiny mesh."""
     import contextlib, io
@@ -308,9 +353,12 @@ if __name__ == "__main__":
         case_buff_tree("buff_tree")
     elif "--train-step" in sys.argv:
         case_train_step("train_step")
+    elif "--buff-train-step" in sys.argv:
+        case_buff_train_step("buff_train_step")
     else:
         main()
         case_buff("buff_fern")
         case_buff_tree("buff_tree")
         case_train_step("train_step")
+        case_buff_train_step("buff_train_step")
         case_obj("export_obj")

@@ -286,3 +286,32 @@ def test_buff_tree_integration_and_training_step(pkg):
     with torch.no_grad():
         out = model.query((o.cuda(), d.cuda(), torch.tensor([0.0, 1.2])))
     assert bool(torch.isfinite(out.rgb_map).all())
+
+
+def test_buff_training_step_against_the_reference_golden(pkg):
+    """BuFFModel.training_step on the MI355X against the UNMODIFIED reference's (tests/golden/buff_train_step.npz):
+    loss, logged PSNR, gradient of all 16 tensors; the tree received one integration step."""
+    from nerfmeshes_amd import models
+    g = load_golden("buff_train_step")
+    model = models.BuFFModel(golden_hparams(g))
+    state = model.state_dict()
+    for k in g.files:
+        if k.startswith("param."):
+            state[k[len("param."):]] = torch.from_numpy(g[k])
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    model.global_step = 0
+    batch = dict(ray_origins=torch.from_numpy(g["origins"])[None], ray_directions=torch.from_numpy(g["directions"])[None],
+                 ray_targets=torch.from_numpy(g["targets"])[None], ray_bounds=torch.tensor([[0.0, 1.2]]))
+    out = model.training_step(batch, 0)
+    out["loss"].backward()
+    ref_loss = float(g["loss"])
+    assert abs(float(out["loss"].detach()) - ref_loss) < 1e-4 * ref_loss
+    assert abs(float(out["log"]["train/psnr"].detach()) - float(g["log.train/psnr"])) < 1e-2
+    assert set(out["log"]) == {"train/loss", "train/psnr", "train/lr"}
+    for name, p in model.named_parameters():
+        ref = torch.from_numpy(g["grad." + name])
+        assert p.grad is not None and p.grad.shape == ref.shape, name
+        err = float((p.grad.cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-3, (name, err)
+    assert model.tree.counter == int(g["counter"]) and float(model.tree.memm.max()) > 0.0

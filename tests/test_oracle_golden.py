@@ -229,3 +229,33 @@ def test_training_step_loss_and_gradients_match_reference():
         got = w[k].grad
         assert got is not None and got.shape == ref.shape, k
         assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
+
+
+def test_buff_training_step_loss_and_gradients_match_reference():
+    """(f)-3: autograd over the oracle's BuFF chain (voxel sampler -> network -> compositing -> MSE) reproduces the
+    UNMODIFIED reference's BuFFModel.training_step: loss and the gradient of all 16 tensors (the voxel ids, which the
+    reference reports inconsistently, do not enter the rendering)."""
+    g = load_golden("buff_train_step")
+    hp = golden_hparams(g)
+    sc, _, rs = specs_from_hparams(hp)
+    rs = O.RenderSpec(num_coarse=rs.num_coarse, num_fine=0, training=True)
+    w = {k[len("param.model."):]: torch.from_numpy(g[k]).clone().requires_grad_(True) for k in g.files
+         if k.startswith("param.model.")}
+    o, d, tgt = (torch.from_numpy(g[k]) for k in ("origins", "directions", "targets"))
+    near, far = float(hp["dataset.near"]), float(hp["dataset.far"])
+    voxels = O.buff_initial_voxels(near, far, int(hp["tree.subdivision_outer_count"]))
+    z, _, mask = O.buff_intersect(voxels, o, d, near, far, rs.num_coarse)
+    uniform = O.coarse_intervals(near, far, rs.num_coarse, d.shape[0])
+    t = torch.where(mask[:, None], z, uniform)
+    assert 0 < int((~mask).sum()) < d.shape[0]
+    pts = O.ray_points(t, d, o).reshape(-1, 3)
+    dirs = d[:, None, :].expand(-1, t.shape[1], -1).reshape(-1, 3)
+    rad = O.mlp_forward(w, sc, pts, dirs, keep_graph=True).reshape(d.shape[0], -1, 4)
+    loss = torch.nn.functional.mse_loss(O.composite(rad, t, d, rs)["rgb_map"], tgt)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6 * float(g["loss"])
+    assert abs(float(O.mse2psnr(loss.detach())) - float(g["log.train/psnr"])) <= 1e-4
+    assert int(g["counter"]) == 2
+    for k, v in w.items():
+        ref = torch.from_numpy(g["grad.model." + k])
+        assert float((v.grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
