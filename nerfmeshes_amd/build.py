@@ -41,15 +41,23 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d) if not os.path.isabs(d) else d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+ABLATION_LIB_PATH = os.path.join(CSRC, "libnerfmeshes_hip_ablations.so")
+
+
+def build(force=False, verbose=True, ablations=False):
+    """Product library by default.  ablations=True builds a SEPARATE library with -DNM_ABLATIONS (the MLP kernel
+    A/B variants, some of which compute wrong results on purpose, selectable there by NM_MLP_VARIANT); nothing in
+    the package loads it -- scripts/bench_mlp.py points nerfmeshes_amd._lib at it explicitly."""
+    lib_path = ABLATION_LIB_PATH if ablations else LIB_PATH
+    if not ablations and not force and not needs_build():
         return LIB_PATH
     objs = []
     procs = []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    bdir = os.path.join(CSRC, "build_ablations" if ablations else "build")
+    os.makedirs(bdir, exist_ok=True)
     for src in _present(SOURCES):
-        obj = os.path.join(CSRC, "build", os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc()] + FLAGS + (["-DNM_ABLATIONS"] if ablations else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -60,12 +68,12 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out.strip():
             print(out.decode())
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, ablations="--ablations" in sys.argv))

@@ -48,8 +48,10 @@ static MlpPlan make_plan(int variant) {
                    &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>};
 }
 
-// variant 0 is the production choice; the others exist for within-process A/B runs (scripts/bench_mlp.py,
-// NM_MLP_VARIANT=<n>) and are only instantiated for the headline 8x256 network.
+// variant 0 is the production choice and the ONLY one in libnerfmeshes_hip.so.  The others exist for within-process
+// A/B runs (scripts/bench_mlp.py) and are compiled only with -DNM_ABLATIONS into a separate library
+// (libnerfmeshes_hip_ablations.so, `python -m nerfmeshes_amd.build --ablations`), where NM_MLP_VARIANT=<n> selects
+// them; the product library never reads that variable, so an inherited environment cannot change its results.
 static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 8, 8, true, true, true>(0),
     make_plan<128, 10, 4, 8, 8, true, true, true>(0),
@@ -57,6 +59,7 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 6, 4, 8, 8, true, true, true>(0),
     make_plan<128, 6, 4, 8, 8, true, true, true>(0),
     make_plan<64, 6, 4, 8, 8, true, true, true>(0),
+#ifdef NM_ABLATIONS
     // measured on MI355X, 2^23 points, 8x256 (profiles/r01_mlp_variants.json): v0 141.1 TFLOP/s
     make_plan<256, 10, 4, 8, 16, true, true, true>(1),     // 16-k-step chunks: 137.6
     make_plan<256, 10, 4, 8, 8, false, true, false>(2),    // round-1 first version (no prefetch, L2 biases): 133.7
@@ -71,11 +74,14 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 4>(14),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 6>(16),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 7>(17),
+#endif
 };
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
     int want = 0;
+#ifdef NM_ABLATIONS
     if (const char* v = getenv("NM_MLP_VARIANT")) want = atoi(v);
+#endif
     const MlpPlan* fallback = nullptr;
     for (const MlpPlan& p : g_plans)
         if (p.H == H && p.FX == FX && p.FD == FD) {

@@ -22,6 +22,45 @@ def world():
     return 0, 1
 
 
+def init_from_env(backend=None):
+    """Join the process group a `torch.distributed.run` launcher describes through RANK / LOCAL_RANK /
+    WORLD_SIZE (the reference's only multi-GPU hook is `Trainer(gpus=...)`, /root/reference/src/train_nerf.py:35-37,79;
+    here the scripts are launched one process per GPU).  Binds this process to its GPU, initialises RCCL
+    (backend "nccl") -- or `backend` when given, e.g. "gloo" in the CPU tests -- and returns (rank, world, device).
+    Without a launcher environment it is a no-op returning (0, 1, current device)."""
+    import os
+    dist = _dist()
+    have_gpu = torch.cuda.is_available()
+    if "WORLD_SIZE" not in os.environ or not dist.is_available():
+        return 0, 1, torch.device("cuda", torch.cuda.current_device()) if have_gpu else torch.device("cpu")
+    rank, ws = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    backend = backend or ("nccl" if have_gpu else "gloo")
+    device = torch.device("cpu")
+    if have_gpu:
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=ws, **kw)
+    return rank, ws, device
+
+
+def shutdown():
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def round_robin_counts(n, world_size):
+    """Items per rank when item i goes to rank i % world_size."""
+    return [len(range(r, n, world_size)) for r in range(world_size)]
+
+
 def split_range(n, rank, world_size):
     """Contiguous near-equal split of range(n): the first n % world ranks get one extra item."""
     base, extra = divmod(n, world_size)
@@ -40,8 +79,12 @@ def all_gather_rows(local, counts):
     (all_gather_into_tensor -> one RCCL ring over xGMI); ragged shards are padded to the largest."""
     dist = _dist()
     rank, ws = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
+    # an initialised group of ONE rank still goes through the collective (a device copy): the single-GPU
+    # tests and `bench.py` exercise the same RCCL entry point the 8-GPU run uses
+    if len(counts) != ws or counts[rank] != local.shape[0]:
+        raise ValueError(f"all_gather_rows: rank {rank} holds {local.shape[0]} rows, counts = {list(counts)}")
     tail = tuple(local.shape[1:])
     if len(set(counts)) == 1:
         out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)

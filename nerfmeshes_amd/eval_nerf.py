@@ -40,8 +40,14 @@ def eval_nerf(model, views, cfg, device="cuda", chunksize=None):
     from . import dist as nd
     rank, world = nd.world()
     losses, rgb = [], None
+    scored = [0] * world                      # views WITH targets per rank (every rank walks the whole iterable)
+    slots = []                                # (owner rank, index among that rank's scored views), in view order
     for view_nr, (pose, h, w, focal, targets) in enumerate(views):
-        if view_nr % world != rank:           # views are independent: round-robin over the ranks
+        owner = view_nr % world               # views are independent: round-robin over the ranks
+        if targets is not None:
+            slots.append((owner, scored[owner]))
+            scored[owner] += 1
+        if owner != rank:
             continue
         rgb, _ = render_view(model, pose, h, w, focal, bounds, chunksize, device)
         if targets is not None:
@@ -53,9 +59,14 @@ def eval_nerf(model, views, cfg, device="cuda", chunksize=None):
             loss /= batch_count
             losses.append(loss)
             print(f"[EVAL] Iter: {len(losses) - 1} Loss MSE {loss} / PSNR: {mse2psnr(loss)}")
-    if world > 1 and losses:                  # assemble the per-view losses of all ranks (same count per rank assumed)
-        mine = torch.stack(losses).to(device)
-        losses = list(nd.all_gather_rows(mine, [mine.shape[0]] * world))
+    if world > 1:
+        # Ranks hold DIFFERENT numbers of views when the view count is not a multiple of the world size (possibly
+        # none): every rank enters the one collective with its (scored[rank],) tensor -- empty included -- and the
+        # rank-major result is re-interleaved into view order.
+        mine = torch.stack(losses).to(device) if losses else torch.empty(0, dtype=torch.float32, device=device)
+        flat = nd.all_gather_rows(mine.to(torch.float32), scored)
+        starts = [sum(scored[:r]) for r in range(world)]
+        losses = [flat[starts[r] + k] for r, k in slots]
     total = torch.stack(losses).mean() if losses else None
     if total is not None:
         print(f"Dataset loss MSE: {total} / PSNR: {mse2psnr(total)}")
@@ -71,11 +82,16 @@ def main(argv=None):
     args = p.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("eval_nerf needs a MI355X: the HIP path has no CPU fallback")
+    from . import dist as nd
+    rank, world, device = nd.init_from_env()          # one process per GPU under torch.distributed.run
     pp = PathParser()
     cfg, _ = pp.parse(None, args.log_checkpoint, None, args.checkpoint)
-    model = getattr(models, cfg.experiment.model).load_from_checkpoint(pp.checkpoint_path).eval().to("cuda")
-    with torch.no_grad():
-        eval_nerf(model, synthetic_views(args.views), cfg, "cuda", args.chunksize)
+    model = getattr(models, cfg.experiment.model).load_from_checkpoint(pp.checkpoint_path).eval().to(device)
+    try:
+        with torch.no_grad():
+            return eval_nerf(model, synthetic_views(args.views), cfg, device, args.chunksize)
+    finally:
+        nd.shutdown()
 
 
 if __name__ == "__main__":

@@ -105,6 +105,7 @@ def export_marching_cubes(model, args, cfg, device):
     """mesh_nerf.py:131-201."""
     if args.super_sampling >= 1:
         return extract_geometry_with_super_sampling(model, device, args)
+    from . import dist as nd
     cache_path = os.path.join(args.save_dir, args.cache_name)
     cached = os.path.exists(cache_path)
     cache_new = args.use_cached_mesh and not cached
@@ -115,11 +116,16 @@ def export_marching_cubes(model, args, cfg, device):
     else:
         print("Generating mesh geometry...")
         vertices, triangles, normals, density = extract_geometry(model, device, args)
-        if cache_new or args.override_cache_mesh:
+        if (cache_new or args.override_cache_mesh) and nd.world()[0] == 0:
             torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(), density.cpu().numpy()), cache_path)
             print(f"Cached mesh geometry saved to {cache_path}")
 
-    targets, directions = vertices, -normals
+    # Appearance: one query per vertex.  Vertices are independent, so under torch.distributed every rank queries a
+    # contiguous range of them and one ragged all-gather assembles the (V,3) colours; rank 0 writes the file.
+    rank, world = nd.world()
+    counts = [b - a for a, b in (nd.split_range(vertices.shape[0], r, world) for r in range(world))]
+    lo, hi = nd.split_range(vertices.shape[0], rank, world)
+    targets, directions = vertices[lo:hi], -normals[lo:hi]
     diffuse = []
     # --batch-size bounds the reference's per-call memory (default 1024); on a 288 GB device the per-call overhead
     # of a 1024-ray launch sequence dominates, so at least 65 536 vertices go into one call
@@ -134,8 +140,10 @@ def export_marching_cubes(model, args, cfg, device):
         ray_origins = targets - args.view_disparity * directions
         for o, d in batchify(ray_origins, directions, batch_size=chunk, device=device, progress=False):
             diffuse.append(model.query((o, d, ray_bounds)).rgb_map)
-    diffuse = torch.cat(diffuse, dim=0).cpu().numpy()
-    export_obj(vertices.cpu(), triangles.cpu(), diffuse, normals.cpu(), os.path.join(args.save_dir, args.mesh_name))
+    diffuse = torch.cat(diffuse, dim=0) if diffuse else torch.empty(0, 3, dtype=torch.float32, device=device)
+    diffuse = nd.all_gather_rows(diffuse.contiguous(), counts).cpu().numpy()
+    if rank == 0:
+        export_obj(vertices.cpu(), triangles.cpu(), diffuse, normals.cpu(), os.path.join(args.save_dir, args.mesh_name))
     return vertices, triangles, normals, diffuse
 
 
@@ -165,12 +173,16 @@ def main(argv=None):
     cfg, _ = path_parser.parse(None, args.log_checkpoint, None, args.checkpoint)
     if not torch.cuda.is_available():
         raise SystemExit("mesh_nerf needs a MI355X: the HIP path has no CPU fallback")
-    device = "cuda"
+    from . import dist as nd
+    rank, world, device = nd.init_from_env()          # one process per GPU under torch.distributed.run
     print(f"Loading model from {path_parser.checkpoint_path}")
     model = getattr(models, cfg.experiment.model).load_from_checkpoint(path_parser.checkpoint_path)
     model = model.eval().to(device)
-    with torch.no_grad():
-        export_marching_cubes(model, args, cfg, device)
+    try:
+        with torch.no_grad():
+            return export_marching_cubes(model, args, cfg, device)
+    finally:
+        nd.shutdown()
 
 
 if __name__ == "__main__":

@@ -58,6 +58,30 @@ class BuFFModel(BaseModel):
             lr = self.cfg.optimizer.lr
         return {"loss": loss, "log": {**log, "train/lr": lr}}
 
+    def validation_step(self, image_ray_batch, batch_idx):
+        """model_buff.py:126-164: one whole image in chunks of cfg.nerf.validation.chunksize, loss = sum of the chunk
+        MSEs over the FLOAT batch count (the reference's quirk); images go to the logger if one is attached."""
+        from ..nerf.nerf_helpers import cast_to_image
+        bundle = DataBundle.deserialize(image_ray_batch).to_ray_batch()
+        dev = self.model.layer1.weight.device
+        batch_size = self.cfg.nerf.validation.chunksize
+        batch_count = bundle.ray_targets.shape[0] / batch_size
+        loss, rgb_chunks = 0.0, []
+        for i in range(0, bundle.ray_targets.shape[0], batch_size):
+            sl = slice(i, i + batch_size)
+            out = self.forward((bundle.ray_origins, bundle.ray_directions[sl], bundle.ray_bounds))
+            loss += self.loss(out.rgb_map, bundle.ray_targets[sl].to(dev))
+            rgb_chunks.append(out.rgb_map)
+        loss /= batch_count
+        rgb_map = torch.cat(rgb_chunks, 0)
+        experiment = getattr(getattr(self, "logger", None), "experiment", None)
+        if experiment is not None and bundle.hwf is not None:
+            experiment.add_image("validation/rgb_coarse/" + str(batch_idx),
+                                 cast_to_image(rgb_map.view(bundle.hwf[0], bundle.hwf[1], 3)), self.global_step)
+            experiment.add_image("validation/img_target/" + str(batch_idx),
+                                 cast_to_image(bundle.ray_targets.view(bundle.hwf[0], bundle.hwf[1], 3)), self.global_step)
+        return {"val_loss": loss, "log": {"validation/loss": loss, "validation/psnr": self.criterion_psnr(loss)}}
+
     def on_save_checkpoint(self, checkpoint):
         checkpoint["tree"] = self.tree.serialize()
 

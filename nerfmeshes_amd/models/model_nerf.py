@@ -66,7 +66,12 @@ class NeRFModel(BaseModel):
             t = train_ops.perturb_intervals(t, torch.rand(t.shape, dtype=t.dtype, device=dev))
 
         def render(net, t):
-            radiance = train_ops.mlp_rays(net, origins, dirs, t)
+            # the tape (L*n*H fp32, ~3 GB at 2048 x 192 samples) is recorded only when a backward pass can follow;
+            # eval with perturb / validation noise under torch.no_grad() runs the plain inference kernel
+            if net.needs_grad():
+                radiance = train_ops.mlp_rays(net, origins, dirs, t)
+            else:
+                radiance = net.hip().eval_rays(origins, dirs, t)
             noise = torch.randn(t.shape, dtype=t.dtype, device=dev) * noise_std if noise_std > 0.0 else None
             b = train_ops.composite(radiance, t, dirs, noise, vr.attenuation_threshold, bool(vr.white_background))
             if not vr.training:                                         # modules.py:108-109
@@ -92,11 +97,10 @@ class NeRFModel(BaseModel):
         """The reference's manual batching (model_nerf.py:93-112): slices of `chunk` rays; origins are shared
         unless the rays are in NDC.  Tensors already in GPU memory stay there (no host round trip per chunk)."""
         dev = self.device
-        origins, dirs, bounds = bundle.ray_origins.to(dev), bundle.ray_directions.to(dev), bundle.ray_bounds
-        targets = bundle.ray_targets.to(dev)
+        origins, dirs, bounds, targets = bundle.ray_origins, bundle.ray_directions, bundle.ray_bounds, bundle.ray_targets
         for i in range(0, targets.shape[0], chunk):
-            sl = slice(i, i + chunk)
-            yield (origins[sl] if self.cfg.dataset.use_ndc else origins, dirs[sl], bounds), targets[sl]
+            sl = slice(i, i + chunk)   # moved per chunk, as the reference: a whole image bundle may not fit next to a tape
+            yield ((origins[sl] if self.cfg.dataset.use_ndc else origins).to(dev), dirs[sl].to(dev), bounds), targets[sl].to(dev)
 
     def _current_lr(self):
         trainer = getattr(self, "trainer", None)

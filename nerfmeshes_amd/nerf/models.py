@@ -54,6 +54,12 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._hip_key = key
         return self._hip
 
+    def refresh(self):
+        """Force a device re-pack on the next use.  `hip()` notices optimizer steps and every in-place op that goes
+        through autograd's version counter; edits through `p.data` (EMA, manual clipping) bypass the counter -- call
+        this after them."""
+        self._hip_key = None
+
     def needs_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 

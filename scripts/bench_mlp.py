@@ -1,10 +1,16 @@
-"""Within-process interleaved A/B of the fused-MLP kernel variants (NM_MLP_VARIANT), 8x256 network.
+"""Within-process interleaved A/B of the fused-MLP kernel variants (NM_MLP_VARIANT), 8x256 network.  Runs against
+the SEPARATE ablation library (`python -m nerfmeshes_amd.build --ablations`; the product library holds variant 0 only
+and ignores NM_MLP_VARIANT).
     python scripts/bench_mlp.py [variants ...]     e.g.  python scripts/bench_mlp.py 0 1 2 3 4 5
 """
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from nerfmeshes_amd import _lib, build as hip_build
+if not os.path.exists(hip_build.ABLATION_LIB_PATH):
+    hip_build.build(ablations=True, verbose=False)
+_lib.LIB_PATH = hip_build.ABLATION_LIB_PATH           # explicit: nothing else in the package loads this library
 from nerfmeshes_amd import hip_ops, synthetic as S
 
 variants = [int(v) for v in sys.argv[1:] if "," not in v] or [0]

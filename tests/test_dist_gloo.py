@@ -106,3 +106,58 @@ def test_gradient_all_reduce_two_ranks_is_the_mean():
             np.testing.assert_allclose(res[r][1][k], mean, rtol=1e-6, atol=1e-7)
     for r in range(2):
         np.testing.assert_allclose(res[r][2], np.full(4, 0.5, dtype=np.float32))
+
+
+# ---- eval_nerf's per-view loss gather: unequal and empty shards (views % world != 0) -------------------------------
+def _fake_render(model, pose, h, w, focal, bounds, chunksize, device):      # rgb depends on the view only
+    v = float(pose[0, 0])
+    rgb = torch.full((h * w, 3), 0.25) + 0.01 * v * torch.arange(h * w * 3, dtype=torch.float32).reshape(-1, 3) / (h * w * 3)
+    return rgb, rgb[:, 0]
+
+
+def _eval_job(rank, world, num_views=1):
+    from nerfmeshes_amd import eval_nerf as E
+    from nerfmeshes_amd import synthetic as S
+    from nerfmeshes_amd.models.model_helpers import nest_dict
+    from nerfmeshes_amd.nerf import CfgNode
+    E.render_view = _fake_render
+    views = []
+    for i in range(num_views):
+        pose = np.eye(4, dtype=np.float32) * (i + 1)
+        tgt = None if (num_views == 5 and i == 1) else torch.full((6 * 4, 3), 0.5)      # one view without targets
+        views.append((pose, 6, 4, 10.0, tgt))
+    cfg = CfgNode(nest_dict(S.hparams(chunksize=8), sep="."))
+    losses, total, psnr, _ = E.eval_nerf(None, views, cfg, device="cpu")
+    return [float(x) for x in losses], None if total is None else float(total)
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("num_views", [1, 3, 4, 5])
+def test_eval_loss_gather_ragged_views(num_views):
+    """1 view on 2 ranks (rank 1 holds none), 3 and 5 views (unequal counts; one view unscored):
+    every rank must enter the collective and get the losses back in VIEW order."""
+    import functools
+    single = _eval_job(0, 1, num_views)              # no process group: plain loop
+    res = _run(functools.partial(_eval_job, num_views=num_views))
+    for losses, total in res:
+        assert losses == pytest.approx(single[0], rel=0, abs=0)
+        assert total == pytest.approx(single[1], rel=1e-7)
+
+
+def test_init_from_env_gloo(monkeypatch):
+    """`init_from_env` reads the launcher variables, joins the group and is a no-op without them."""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert nd.init_from_env()[:2] == (0, 1)
+    monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    try:
+        rank, ws, dev = nd.init_from_env(backend="gloo")
+        assert (rank, ws) == (0, 1) and dist.is_initialized()
+        # an initialised one-rank group still runs the collective
+        out = nd.all_gather_rows(torch.arange(6.0).reshape(3, 2), [3])
+        assert torch.equal(out, torch.arange(6.0).reshape(3, 2))
+        with pytest.raises(ValueError):
+            nd.all_gather_rows(torch.zeros(2, 2), [3])
+    finally:
+        nd.shutdown()
+    assert not dist.is_initialized()

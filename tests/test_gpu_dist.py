@@ -1,0 +1,78 @@
+"""GPU: the RCCL path on real hardware.  One process per GPU under torch.distributed.run (rendezvous on 127.0.0.1):
+world size 1 always (the collective entry points run on a one-rank RCCL communicator), world size 2 when the box has
+two GPUs (N-rank pixels / grid / mesh == 1-rank, bit for bit).  Also bench.py's launcher behaviour: `--gpus N` beyond
+the visible GPUs must exit non-zero instead of mislabelling a 1-GPU run, and the RCCL leg of the bench must report
+what the all-gather delivered."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def _torchrun(nproc, script, *args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
+    return subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_rccl_sharded_render_grid_mesh(world):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X")
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    r = _torchrun(world, os.path.join("tests", "tools", "dist_worker.py"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert f"DIST_OK world={world} backend=nccl" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--headline-only"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "visible" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout, "no bench line may be printed for a run that could not happen"
+
+
+def test_bench_rccl_leg_on_one_rank():
+    """bench.py under a launcher environment of ONE rank: RCCL is initialised, the pixels go through the all-gather,
+    and the line says how many ranks the collective saw."""
+    r = _torchrun(1, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "1", "--headline-only")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl"]["backend"] == "nccl" and line["rccl"]["ranks_in_all_gather"] == 1
+    assert line["rccl"]["slots_match_rank_checksums"] is True
+    assert line["value"] > 1e5 and 0.5 < line["roofline"]["frac"] < 1.0
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher must start two ranks by itself and print n_gpus: 2."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--headline-only"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["ranks_in_all_gather"] == 2 and line["rccl"]["slots_match_rank_checksums"]
