@@ -237,6 +237,18 @@ int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origin
                       const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
                       int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream);
 
+/* The same with an explicit tie order for the three sorts of the reference (src/nerf/tree.py:300,306,335 call
+ * torch.sort with its UNSTABLE default):
+ *   NM_TIES_STABLE     ties keep voxel-index / sample order: every id is the voxel its sample lies in (default);
+ *   NM_TIES_REFERENCE  ties ordered as torch's CPU sort orders them (libstdc++ std::sort over (key, index) pairs,
+ *                      restated in the kernel): d_idx equals the reference's output bit for bit, including its
+ *                      scrambled attribution of samples to the crossed voxels.  Parity / reproduction mode:
+ *                      sequential per ray, ~100x slower; nvox <= 8192.  d_z and d_mask are identical in both. */
+enum { NM_TIES_STABLE = 0, NM_TIES_REFERENCE = 1 };
+int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                         const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
+                         int32_t samples, int32_t tie_order, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream);
+
 /* TreeSampling.ray_batch_integration (src/nerf/tree.py:177-206), training-time tree maintenance: the samples of
  * the rays that hit the tree -- d_idx / d_weights / d_mask_weights, `count` elements each (= indices[mask],
  * weights[mask], mask_weights[mask] flattened) -- update the running voxel weights d_memm (nvox,) in place:

@@ -95,6 +95,8 @@ SIGNATURES = {
                                      c_void_p]),
     "nm_buff_intersect": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
                                     C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nm_buff_intersect_ex": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
+                                       C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_tree_workspace_bytes": (C.c_int64, [C.c_int32]),
     "nm_tree_integrate": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p,
                                     c_void_p]),

@@ -158,6 +158,266 @@ __global__ __launch_bounds__(256) void buff_intersect_kernel(const float* __rest
     }
 }
 
+
+// ---- opt-in: voxel ids with the reference's OWN tie order ---------------------------------------------------------
+// The reference calls torch.sort three times with its unstable default (tree.py:300, :306, :335).  On the CPU build it
+// was written against (and the golden vectors were generated with: torch 2.10, tests/golden/make_golden.py) that is
+// libstdc++'s std::sort -- introsort -- over (key, index) pairs
+// (ATen/native/cpu/SortingKernel.cpp: std::sort(composite accessor, KeyValueCompAsc / KeyValueCompDesc)), a
+// deterministic algorithm: probed equal for ATEN_CPU_CAPABILITY = default / avx2 / avx512, and a line-by-line
+// restatement reproduces torch.sort's indices on tie-heavy inputs (tests/test_introsort_restatement.py).  The order of
+// ties decides (a) the order of equal entry depths -- common: every voxel of a slab shares the slab's entry plane --
+// hence the 0/1 hit sequence, (b) which crossed voxel each slot of the "rolled to the front" list is attributed to
+// (tree.py:306-309: the VALUES are placed by a boolean mask, in order; the INDICES come from the unstable sort), and
+// (c) the order of samples with equal depth.  This kernel replays exactly that: one wavefront per ray, the three
+// introsorts run on lane 0 over LDS (they are sequential algorithms), everything else is wave-parallel.  It exists
+// for parity (ids == the reference's, bit for bit, also on rays where they are not the voxels the samples lie in);
+// the default kernel above keeps the stable, geometrically meaningful order and is ~100x faster.
+struct CmpAsc {   // KeyValueCompAsc<float>: NaNs last
+    __device__ __forceinline__ bool operator()(float a, float b) const { return (!(a != a) && (b != b)) || (a < b); }
+};
+struct CmpDesc {  // KeyValueCompDesc<float>: NaNs first
+    __device__ __forceinline__ bool operator()(float a, float b) const { return ((a != a) && !(b != b)) || (a > b); }
+};
+
+template <typename Cmp>
+struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + __final_insertion_sort, threshold 16
+    float* k;
+    unsigned short* ix;
+    Cmp cmp;
+    __device__ __forceinline__ void swap(int i, int j) {
+        const float tk = k[i]; k[i] = k[j]; k[j] = tk;
+        const unsigned short ti = ix[i]; ix[i] = ix[j]; ix[j] = ti;
+    }
+    __device__ void move_median_to_first(int result, int a, int b, int c) {
+        if (cmp(k[a], k[b])) {
+            if (cmp(k[b], k[c])) swap(result, b);
+            else if (cmp(k[a], k[c])) swap(result, c);
+            else swap(result, a);
+        } else if (cmp(k[a], k[c])) swap(result, a);
+        else if (cmp(k[b], k[c])) swap(result, c);
+        else swap(result, b);
+    }
+    __device__ int unguarded_partition(int first, int last, int pivot) {
+        for (;;) {
+            while (cmp(k[first], k[pivot])) ++first;
+            --last;
+            while (cmp(k[pivot], k[last])) --last;
+            if (!(first < last)) return first;
+            swap(first, last);
+            ++first;
+        }
+    }
+    // heap fallback (__partial_sort(first, last, last) = make_heap + sort_heap) when the depth limit is reached
+    __device__ void push_heap(int first, int hole, int top, float vk, unsigned short vi) {
+        int parent = (hole - 1) / 2;
+        while (hole > top && cmp(k[first + parent], vk)) {
+            k[first + hole] = k[first + parent]; ix[first + hole] = ix[first + parent];
+            hole = parent; parent = (hole - 1) / 2;
+        }
+        k[first + hole] = vk; ix[first + hole] = vi;
+    }
+    __device__ void adjust_heap(int first, int hole, int len, float vk, unsigned short vi) {
+        const int top = hole;
+        int child = hole;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (cmp(k[first + child], k[first + child - 1])) --child;
+            k[first + hole] = k[first + child]; ix[first + hole] = ix[first + child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            k[first + hole] = k[first + child - 1]; ix[first + hole] = ix[first + child - 1];
+            hole = child - 1;
+        }
+        push_heap(first, hole, top, vk, vi);
+    }
+    __device__ void heap_sort(int first, int last) {
+        const int len = last - first;
+        if (len >= 2) {
+            for (int parent = (len - 2) / 2;; --parent) {
+                adjust_heap(first, parent, len, k[first + parent], ix[first + parent]);
+                if (parent == 0) break;
+            }
+        }
+        while (last - first > 1) {
+            --last;
+            const float vk = k[last]; const unsigned short vi = ix[last];
+            k[last] = k[first]; ix[last] = ix[first];
+            adjust_heap(first, 0, last - first, vk, vi);
+        }
+    }
+    __device__ void unguarded_linear_insert(int last) {
+        const float vk = k[last]; const unsigned short vi = ix[last];
+        int next = last - 1;
+        while (cmp(vk, k[next])) { k[last] = k[next]; ix[last] = ix[next]; last = next; --next; }
+        k[last] = vk; ix[last] = vi;
+    }
+    __device__ void insertion_sort(int first, int last) {
+        if (first == last) return;
+        for (int i = first + 1; i != last; ++i) {
+            if (cmp(k[i], k[first])) {
+                const float vk = k[i]; const unsigned short vi = ix[i];
+                for (int j = i; j > first; --j) { k[j] = k[j - 1]; ix[j] = ix[j - 1]; }
+                k[first] = vk; ix[first] = vi;
+            } else unguarded_linear_insert(i);
+        }
+    }
+    __device__ void sort(int n) {
+        if (n <= 0) return;
+        int lg = 0;
+        while ((2 << lg) <= n) ++lg;          // std::__lg(n)
+        // __introsort_loop: recursion on the right part, iteration on the left; disjoint ranges, so an explicit stack
+        // in any order gives the same result
+        int st_first[64], st_last[64], st_depth[64], sp = 0;
+        st_first[0] = 0; st_last[0] = n; st_depth[0] = 2 * lg; sp = 1;
+        while (sp > 0) {
+            --sp;
+            int first = st_first[sp], last = st_last[sp], depth = st_depth[sp];
+            while (last - first > 16) {
+                if (depth == 0) { heap_sort(first, last); break; }
+                --depth;
+                const int mid = first + (last - first) / 2;
+                move_median_to_first(first, first + 1, mid, last - 1);
+                const int cut = unguarded_partition(first + 1, last, first);
+                st_first[sp] = cut; st_last[sp] = last; st_depth[sp] = depth; ++sp;
+                last = cut;
+            }
+        }
+        if (n > 16) {
+            insertion_sort(0, 16);
+            for (int i = 16; i < n; ++i) unguarded_linear_insert(i);
+        } else insertion_sort(0, n);
+    }
+};
+
+__global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __restrict__ voxels, int nvox, int npad,
+                                                               const float* __restrict__ origins, int origins_per_ray,
+                                                               const float* __restrict__ dirs, float near_, float far_,
+                                                               const float* __restrict__ u, int64_t rays, int samples,
+                                                               float* __restrict__ z_out, int64_t* __restrict__ idx_out,
+                                                               uint8_t* __restrict__ mask_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* key = reinterpret_cast<float*>(smem);                       // [npad] sort keys
+    float* r_tmin = key + npad;                                        // [npad] crossed boxes in reference order
+    float* r_cum = r_tmin + npad;                                      // [npad]
+    float* p_s = r_cum + npad;                                         // [BUFF_MAX_SAMPLES]
+    float* p_z = p_s + BUFF_MAX_SAMPLES;
+    int* p_bucket = reinterpret_cast<int*>(p_z + BUFF_MAX_SAMPLES);
+    unsigned short* perm1 = reinterpret_cast<unsigned short*>(p_bucket + BUFF_MAX_SAMPLES);   // crosses_sorted.indices
+    unsigned short* perm2 = perm1 + npad;                                                     // crosses_start.indices
+    unsigned short* p_ix = perm2 + npad;                               // [BUFF_MAX_SAMPLES] z sort indices
+    unsigned short* p_vid = p_ix + BUFF_MAX_SAMPLES;
+    unsigned char* hit = reinterpret_cast<unsigned char*>(p_vid + BUFF_MAX_SAMPLES);          // [npad] by box index
+    const int lane = threadIdx.x;
+    for (int64_t ray = blockIdx.x; ray < rays; ray += gridDim.x) {
+        const float* o = origins + (origins_per_ray ? 3 * ray : 0);
+        float inv[3], org[3];
+        int sgn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            org[a] = o[a];
+            inv[a] = 1.0f / dirs[3 * ray + a];
+            sgn[a] = inv[a] < 0.0f ? 1 : 0;
+        }
+        auto slab = [&](int n, float& tmin, float& tmax) -> bool {
+            const float* b = voxels + 6 * (int64_t)n;
+            float lo_t[3], hi_t[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo_t[a] = (b[3 * sgn[a] + a] - org[a]) * inv[a];
+                hi_t[a] = (b[3 * (1 - sgn[a]) + a] - org[a]) * inv[a];
+            }
+            bool valid = (lo_t[0] <= hi_t[1]) && (lo_t[1] <= hi_t[0]);
+            tmin = lo_t[1] > lo_t[0] ? lo_t[1] : lo_t[0];
+            tmax = hi_t[1] < hi_t[0] ? hi_t[1] : hi_t[0];
+            valid = valid && (tmin <= hi_t[2]) && (lo_t[2] <= tmax);
+            tmin = lo_t[2] > tmin ? lo_t[2] : tmin;
+            tmax = hi_t[2] < tmax ? hi_t[2] : tmax;
+            return valid && (tmin >= near_) && (tmax <= far_);
+        };
+        for (int n = lane; n < nvox; n += 64) {
+            float tmin, tmax;
+            hit[n] = slab(n, tmin, tmax) ? 1 : 0;
+            key[n] = tmin;
+            perm1[n] = (unsigned short)n;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { Introsort<CmpAsc> s1{key, perm1, CmpAsc()}; s1.sort(nvox); }      // tree.py:300
+        __builtin_amdgcn_wave_barrier();
+        // crossed boxes in sorted order (tree.py:303-309: values placed through the boolean mask, i.e. in order)
+        int K = 0;
+        for (int base = 0; base < nvox; base += 64) {
+            const int p = base + lane;
+            bool v = false;
+            int n = 0;
+            if (p < nvox) { n = perm1[p]; v = hit[n] != 0; }
+            const unsigned long long bal = __ballot(v);
+            if (v) {
+                float tmin, tmax;
+                slab(n, tmin, tmax);
+                const int pos = K + __popcll(bal & ((1ull << lane) - 1ull));
+                r_tmin[pos] = tmin;
+                r_cum[pos] = tmax - tmin;
+            }
+            K += __popcll(bal);
+            if (p < nvox) { key[p] = v ? 1.0f : 0.0f; perm2[p] = (unsigned short)p; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { Introsort<CmpDesc> s2{key, perm2, CmpDesc()}; s2.sort(nvox); }    // tree.py:306
+        __builtin_amdgcn_wave_barrier();
+        double carry = 0.0;
+        for (int base = 0; base < K; base += 64) {
+            const int i = base + lane;
+            double incl = i < K ? (double)r_cum[i] : 0.0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double pv = shfl_up_d(incl, off);
+                if (lane >= off) incl += pv;
+            }
+            incl += carry;
+            if (i < K) r_cum[i] = (float)incl;
+            const int lo = __double2loint(incl), hi = __double2hiint(incl);
+            carry = __hiloint2double(__shfl(hi, 63), __shfl(lo, 63));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float total = K > 0 ? r_cum[K - 1] : 0.0f;
+        for (int j = lane; j < samples; j += 64) {
+            const float s = u[j] * total;
+            int lo = 0, hi = K > 0 ? K - 1 : 0;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (r_cum[mid] < s) lo = mid + 1; else hi = mid;
+            }
+            p_s[j] = s;
+            p_bucket[j] = lo;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < samples; j += 64) {
+            const int bkt = p_bucket[j];
+            int lo = 0, hi = j;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (p_bucket[mid] < bkt) lo = mid + 1; else hi = mid;
+            }
+            const float offset = p_s[j] - p_s[lo];
+            p_z[j] = (K > 0 ? r_tmin[bkt] : 0.0f) + offset;
+            p_vid[j] = perm1[perm2[bkt]];          // tree.py:331-332: crosses_sorted.indices[crosses_start.indices[bucket]]
+            p_ix[j] = (unsigned short)j;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { Introsort<CmpAsc> s3{p_z, p_ix, CmpAsc()}; s3.sort(samples); }    // tree.py:335
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < samples; j += 64) {
+            z_out[ray * samples + j] = p_z[j];
+            idx_out[ray * samples + j] = p_vid[p_ix[j]];
+        }
+        if (lane == 0) mask_out[ray] = K > 0 ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- training-time weight integration (tree.py:177-206) ------------------------------------------------------
 // acc[v] = sum of the sample weights that fell into voxel v over the whole ray batch, freq[v] = how many of them
 // were still visible (mask_weights); the reference materialises two dense (R, N) scatter targets per step, here
@@ -210,18 +470,45 @@ extern "C" int nm_tree_integrate(const int64_t* d_idx, const float* d_weights, c
     return 0;
 }
 
-extern "C" int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
-                                 const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
-                                 int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream_) {
+// one overflow flag per device (allocated on the device the call runs on)
+static int* overflow_flag() {
+    static int* flags[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!flags[dev]) {
+        if (hipMalloc(&flags[dev], sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(flags[dev], 0, sizeof(int)) != hipSuccess) return nullptr;
+    }
+    return flags[dev];
+}
+
+extern "C" int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                                    const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
+                                    int32_t samples, int32_t tie_order, float* d_z, int64_t* d_idx, uint8_t* d_mask,
+                                    void* stream_) {
     NM_REQUIRE(d_voxels && d_origins && d_dirs && d_u && d_z && d_idx && d_mask, "bad argument");
     NM_REQUIRE(nvox > 0 && samples > 0 && samples <= BUFF_MAX_SAMPLES, "buff_intersect: samples must be in [1, 512]");
+    NM_REQUIRE(tie_order == NM_TIES_STABLE || tie_order == NM_TIES_REFERENCE, "buff_intersect: unknown tie order");
     if (rays <= 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static int* d_overflow = nullptr;
-    if (!d_overflow) {
-        NM_HIP_CHECK(hipMalloc(&d_overflow, sizeof(int)));
-        NM_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
+    if (tie_order == NM_TIES_REFERENCE) {
+        NM_REQUIRE(nvox <= 8192, "buff_intersect(reference tie order): at most 8192 voxels");
+        const int npad = (nvox + 63) & ~63;
+        const size_t lds = (size_t)npad * (3 * 4 + 2 * 2 + 1) + BUFF_MAX_SAMPLES * (3 * 4 + 2 * 2);
+        static size_t attr = 0;
+        if (attr < lds) {
+            NM_HIP_CHECK(hipFuncSetAttribute((const void*)buff_reference_ids_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = lds;
+        }
+        hipLaunchKernelGGL(buff_reference_ids_kernel, dim3((unsigned)(rays < 8192 ? rays : 8192)), dim3(64), lds, stream,
+                           d_voxels, nvox, npad, d_origins, origins_per_ray, d_dirs, near_, far_, d_u, rays, samples, d_z,
+                           d_idx, d_mask);
+        NM_HIP_CHECK(hipGetLastError());
+        return 0;
     }
+    int* d_overflow = overflow_flag();
+    NM_REQUIRE(d_overflow != nullptr, "buff_intersect: cannot allocate the overflow flag");
     const int64_t blocks = (rays + 3) / 4;
     hipLaunchKernelGGL(buff_intersect_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream,
                        d_voxels, nvox, d_origins, origins_per_ray, d_dirs, near_, far_, d_u, rays, samples, d_z, d_idx,
@@ -236,4 +523,11 @@ extern "C" int nm_buff_intersect(const float* d_voxels, int32_t nvox, const floa
         return 4;
     }
     return 0;
+}
+
+extern "C" int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                                 const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
+                                 int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream_) {
+    return nm_buff_intersect_ex(d_voxels, nvox, d_origins, origins_per_ray, d_dirs, near_, far_, d_u, rays, samples,
+                                NM_TIES_STABLE, d_z, d_idx, d_mask, stream_);
 }

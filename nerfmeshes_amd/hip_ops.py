@@ -224,9 +224,16 @@ def mlp_profile_read():
     return n.value, ms.value, fl.value
 
 
-def buff_intersect(voxels, origins, dirs, near, far, samples):
-    """TreeSampling.batch_ray_voxel_intersect on the GPU (nm_buff_intersect):
-    (z (R,S) f32, voxel ids (R,S) i64, ray_mask (R,) bool)."""
+TIE_ORDERS = {"stable": 0, "reference": 1}
+
+
+def buff_intersect(voxels, origins, dirs, near, far, samples, ids="stable"):
+    """TreeSampling.batch_ray_voxel_intersect on the GPU (nm_buff_intersect_ex):
+    (z (R,S) f32, voxel ids (R,S) i64, ray_mask (R,) bool).  ids="stable" (default): every id is the voxel its
+    sample lies in; ids="reference": ties ordered as the reference's three unstable torch.sort calls order them on
+    the CPU (libstdc++ introsort, restated in the kernel) -- the reference's ids bit for bit (parity mode, slow)."""
+    if ids not in TIE_ORDERS:
+        raise ValueError(f"ids must be one of {sorted(TIE_ORDERS)}, got {ids!r}")
     lib = _lib.load()
     voxels = _dev32(voxels, name="voxels")
     dev = voxels.device
@@ -236,9 +243,10 @@ def buff_intersect(voxels, origins, dirs, near, far, samples):
     z = torch.empty(rays, samples, dtype=torch.float32, device=dev)
     idx = torch.empty(rays, samples, dtype=torch.int64, device=dev)
     mask = torch.empty(rays, dtype=torch.uint8, device=dev)
-    check(lib.nm_buff_intersect(_ptr(voxels), voxels.shape[0], _ptr(origins), int(origins.shape[0] == rays and rays > 1),
-                                _ptr(dirs), float(near), float(far), _ptr(u), rays, samples, _ptr(z), _ptr(idx),
-                                _ptr(mask), _stream()), "nm_buff_intersect")
+    check(lib.nm_buff_intersect_ex(_ptr(voxels), voxels.shape[0], _ptr(origins),
+                                   int(origins.shape[0] == rays and rays > 1), _ptr(dirs), float(near), float(far), _ptr(u),
+                                   rays, samples, TIE_ORDERS[ids], _ptr(z), _ptr(idx), _ptr(mask), _stream()),
+          "nm_buff_intersect_ex")
     return z, idx, mask.bool()
 
 

@@ -57,6 +57,10 @@ class TreeSampling:
         self.voxels = None
         self.memm = None
         self.counter = 1
+        # "stable" (default): every voxel id is the voxel its sample lies in.  "reference": ties ordered as the
+        # reference's three unstable torch.sort calls order them on the CPU -- its ids, hence its memm and its
+        # refined voxel sets, bit for bit (tests/golden/buff_sampled_tree.npz); optional hparams key `tree.tie_order`.
+        self.tie_order = getattr(self.config.tree, "tie_order", "stable")
         self.consolidate()
 
     def ticked(self, step):
@@ -114,7 +118,8 @@ class TreeSampling:
         """(z_vals (R,S) f32, voxel indices (R,S) i64, ray_mask (R,) bool) -- tree.py:215-343."""
         if self.config.tree.use_random_sampling:
             raise NotImplementedError("tree.use_random_sampling (multinomial branch) is not implemented on the HIP path")
-        return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count))
+        return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count),
+                                      ids=getattr(self, "tie_order", "stable"))
 
     def serialize(self):
         return {"root": self.root, "voxels": self.voxels, "memm": self.memm, "counter": self.counter}

@@ -357,10 +357,14 @@ def buff_initial_voxels(near, far, outer_count):
     return torch.stack(out, 0)
 
 
-def buff_intersect(voxels, origins, dirs, near, far, samples_count):
+def buff_intersect(voxels, origins, dirs, near, far, samples_count, ties="stable"):
     """TreeSampling.batch_ray_voxel_intersect, deterministic branch (tree.py:215-343).
-    Returns (z_vals (R,S), voxel indices (R,S) int64, ray_mask (R,) bool); sorts are made stable so that the
-    voxel indices are well defined (the reference leaves ties to the sort implementation)."""
+    Returns (z_vals (R,S), voxel indices (R,S) int64, ray_mask (R,) bool).
+    ties="stable": the three sorts are stable, so every id is the voxel its sample lies in.
+    ties="reference": the sorts are issued exactly as the reference issues them (torch.sort's unstable default --
+    on the CPU libstdc++'s introsort over (key, index) pairs, a deterministic algorithm, see oracle/introsort.py):
+    the ids equal the reference's bit for bit on the same torch build (tests/golden/buff_fern.npz)."""
+    stable = {"stable": True, "reference": False}[ties]
     voxels, origins, dirs = _t(voxels), _t(origins), _t(dirs)
     R, N = dirs.shape[0], voxels.shape[0]
     inv = 1 / dirs
@@ -382,10 +386,10 @@ def buff_intersect(voxels, origins, dirs, near, far, samples_count):
     tmax = torch.where(tvmax[..., 2] < tmax, tvmax[..., 2], tmax)
     mask = mask & (tmin >= near) & (tmax <= far)
     ray_mask = mask.sum(-1) > 0
-    order = torch.sort(tmin, dim=-1, stable=True)
+    order = torch.sort(tmin, dim=-1, stable=stable)
     inter = torch.stack((tmin, tmax), -1).gather(-2, order.indices[..., None].expand(R, N, 2))
     mask_sorted = mask.gather(-1, order.indices)
-    start = torch.sort(mask_sorted.long(), dim=-1, descending=True, stable=True)
+    start = torch.sort(mask_sorted.long(), dim=-1, descending=True, stable=stable)
     res = torch.zeros_like(inter)
     res[start.values.bool()] = inter[mask_sorted]
     cums = torch.cumsum(res[..., 1] - res[..., 0], -1)
@@ -395,7 +399,7 @@ def buff_intersect(voxels, origins, dirs, near, far, samples_count):
     offset = samples - samples.gather(-1, first)
     z = res[..., 0].gather(-1, bucket) + offset
     vox = order.indices.gather(-1, start.indices.gather(-1, bucket))
-    z, zorder = torch.sort(z, dim=-1, stable=True)
+    z, zorder = torch.sort(z, dim=-1, stable=stable)
     return z, vox.gather(-1, zorder), ray_mask
 
 

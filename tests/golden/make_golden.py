@@ -90,6 +90,29 @@ def case_render(name, hp, seed_c, seed_f, gain, bias, n_rays, near, far, per_ray
     print(name, "rays", n_rays, "acc", float((fine or coarse).acc_map.mean()))
 
 
+def case_view(name, hp, n_rays, view=0, chunk=2048):
+    """PSNR-parity fixture: `n_rays` strided rays of one 800x800 bench view (smooth scene) through the reference's
+    NeRFModel.forward in validation chunks; only the final rgb maps are kept (the 1e-4 dB bar is a whole-image
+    quantity: it needs thousands of rays, not the 256 of the stage-by-stage fixtures)."""
+    nerf, models = ref_import.load()
+    m = models.NeRFModel(hp).eval()
+    w = gen_weights(S.SCENE_SEED, 0, 0, **mlp_kwargs(hp, "coarse"))
+    load_weights(m, "model_coarse.", w)
+    load_weights(m, "model_fine.", w)
+    o, d, idx = lego_rays(n_rays, view=view)
+    bounds = torch.tensor([2.0, 6.0], dtype=torch.float32)
+    rgb_c, rgb_f = [], []
+    with torch.no_grad():
+        for s in range(0, n_rays, chunk):
+            coarse, fine = m.forward((o, d[s:s + chunk], bounds))
+            rgb_c.append(coarse.rgb_map)
+            rgb_f.append(fine.rgb_map)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), pose=S.orbit_poses(4)[view], ray_index=idx.numpy(),
+                        bounds=bounds.numpy(), seed=S.SCENE_SEED,
+                        **{"coarse.rgb_map": torch.cat(rgb_c).numpy(), "fine.rgb_map": torch.cat(rgb_f).numpy()})
+    print(name, "rays", n_rays)
+
+
 def case_mlp(name, hp, seed, gain, bias, n):
     """R3/R7: sample_points(points, dirs) on scattered points, incl. large coordinates."""
     nerf, models = ref_import.load()
@@ -250,6 +273,43 @@ def case_buff_tree(name):
     print(name, [out[f"voxels_after{k}"].shape[0] for k in (1, 2)], "voxels after the two rounds")
 
 
+def case_buff_sampled_tree(name):
+    """R9 consequence: the UNMODIFIED reference's BuFFModel.forward in train() mode (model_buff.py:34-73) on three
+    fixed ray batches -- each forward samples through batch_ray_voxel_intersect and integrates ITS OWN voxel ids into
+    memm (tree.py:177-206) -- then consolidate().  Holds memm after every step and the voxel set afterwards: what the
+    tree looks like when the ids come from the reference's unstable sorts."""
+    import contextlib, io
+    nerf, models = ref_import.load()
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2,
+                   dataset_type="colmap", train_noise_std=0.0, **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.BuFFModel(hp)
+    w = S.make_mlp_weights(13, density_gain=400.0, density_bias=4.0, **kw)
+    load_weights(m, "model.", w)
+    m.train()
+    g = torch.Generator().manual_seed(77)
+    out = dict(seed=13, gain=400.0, bias=4.0, hparams_keys=np.array(list(hp.keys())),
+               hparams_vals=np.array([repr(v) for v in hp.values()]))
+    bounds = torch.tensor([0.0, 1.2])
+    for k in range(3):
+        n = 128
+        o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * (0.75 + 0.5 * torch.rand(n, 1, generator=g))
+        d = torch.nn.functional.normalize((torch.rand(n, 3, generator=g) - 0.5) * 0.9 - o, dim=-1)
+        d[:4] = torch.nn.functional.normalize(o[:4], dim=-1)          # a few rays that miss the tree
+        m.global_step = k
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            b = m.forward((o, d, bounds))
+        out.update({f"origins{k}": o.numpy(), f"directions{k}": d.numpy(), f"memm{k}": m.tree.memm.numpy().copy(),
+                    f"rgb{k}": b.rgb_map.numpy()})
+    out["counter"] = m.tree.counter
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.tree.consolidate()
+    out["voxels_after"] = m.tree.voxels.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "memm > eps:", int((out["memm2"] > hp["tree.eps"]).sum()), "voxels after consolidate:", out["voxels_after"].shape[0])
+
+
 def case_train_step(name):
     """(f)-2: the UNMODIFIED reference's NeRFModel.training_step (model_nerf.py:88-151) on a fixed ray batch in
     train() mode (perturb off, noise 0 -- the deterministic part of the step), then loss.backward(): loss, the logged
@@ -345,7 +405,11 @@ def case_obj(name):
 
 
 if __name__ == "__main__":
-    if "--obj" in sys.argv:
+    if "--buff-sampled-tree" in sys.argv:
+        case_buff_sampled_tree("buff_sampled_tree")
+    elif "--view8k" in sys.argv:
+        case_view("render_lego_view_8k", S.hparams(), 8192)
+    elif "--obj" in sys.argv:
         case_obj("export_obj")
     elif "--buff" in sys.argv:
         case_buff("buff_fern")

@@ -41,6 +41,14 @@ def test_buff_intersect_vs_reference_golden(pkg):
         assert np.array_equal(z.cpu().numpy()[hit], g["z" + suffix][hit]), "depths must be bit-identical"
         zo, io, mo = O.buff_intersect(g["voxels"], o, g["directions"], 0.0, 1.2, 192)
         assert np.array_equal(idx.cpu().numpy()[hit], io.numpy()[hit]), "voxel ids vs the stable-order oracle"
+        # NM_TIES_REFERENCE: the reference's own (unstable-sort) tie order, restated in the kernel -> its ids, its
+        # depths and its mask, bit for bit, on EVERY ray (hit or not) -- the golden holds the unmodified reference's
+        zr, ir, mr = pkg["ops"].buff_intersect(vox, torch.from_numpy(o).cuda(), torch.from_numpy(g["directions"]).cuda(),
+                                               0.0, 1.2, 192, ids="reference")
+        assert np.array_equal(mr.cpu().numpy(), hit)
+        assert np.array_equal(zr.cpu().numpy(), g["z" + suffix])
+        assert np.array_equal(ir.cpu().numpy(), g["idx" + suffix]), "ids must equal buff_fern.npz['idx'] exactly"
+        assert np.array_equal(zr.cpu().numpy()[hit], z.cpu().numpy()[hit]), "the two tie orders share depths"
 
 
 @pytest.mark.parametrize("rays,samples,nvox_side", [(1, 64, 12), (777, 192, 12), (300, 33, 5)])
@@ -55,6 +63,38 @@ def test_buff_intersect_vs_oracle(pkg, rays, samples, nvox_side):
     assert np.array_equal(mask.cpu().numpy(), hit)
     assert np.array_equal(z.cpu().numpy()[hit], zo.numpy()[hit])
     assert np.array_equal(idx.cpu().numpy()[hit], io.numpy()[hit])
+    zr, ir, mr = O.buff_intersect(vox, o, d, 0.0, 1.2, samples, ties="reference")
+    z2, i2, m2 = pkg["ops"].buff_intersect(vox.cuda(), o.cuda(), d.cuda(), 0.0, 1.2, samples, ids="reference")
+    assert np.array_equal(m2.cpu().numpy(), mr.numpy())
+    if bool(mr.any()):      # (with no hit at all the reference returns random depths, tree.py:281-285)
+        assert np.array_equal(z2.cpu().numpy(), zr.numpy()) and np.array_equal(i2.cpu().numpy(), ir.numpy())
+
+
+def test_buff_sampled_tree_reference_tie_order(pkg):
+    """R9 end to end on the GPU: BuFFModel.forward in train mode with tree.tie_order = "reference" samples (nm_buff_intersect_ex,
+    NM_TIES_REFERENCE), renders and integrates three ray batches; memm after every step and the consolidated voxel set
+    equal the UNMODIFIED reference's (tests/golden/buff_sampled_tree.npz: it sampled with its own unstable sorts)."""
+    g = load_golden("buff_sampled_tree")
+    hp = golden_hparams(g)
+    hp["tree.tie_order"] = "reference"
+    m = pkg["models"].BuFFModel(hp)
+    kw = mlp_kwargs(hp, "coarse")
+    _load(m, "model.", S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw))
+    m = m.train().to("cuda")
+    assert m.tree.tie_order == "reference"
+    for k in range(3):
+        m.global_step = k
+        with torch.no_grad():
+            b = m.forward((torch.from_numpy(g[f"origins{k}"]).cuda(), torch.from_numpy(g[f"directions{k}"]).cuda(),
+                           torch.tensor([0.0, 1.2])))
+        assert float((b.rgb_map.cpu() - torch.from_numpy(g[f"rgb{k}"])).abs().max()) < 2e-4, k
+        ref = torch.from_numpy(g[f"memm{k}"])
+        got = m.tree.memm.cpu()
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, (k, float((got - ref).abs().max()))
+        assert bool(((got != 0) == (ref != 0)).all()), "the same voxels must have received weight"
+    assert m.tree.counter == int(g["counter"])
+    m.tree.consolidate()
+    assert np.array_equal(m.tree.voxels.cpu().numpy(), g["voxels_after"])
 
 
 def test_buff_model_forward_golden(pkg):

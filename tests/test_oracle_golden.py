@@ -34,6 +34,28 @@ def test_render_matches_reference(case):
                 np.testing.assert_allclose(got, ref, err_msg=f"{case} {prefix}{k}", **TOL)
 
 
+def _view8k_rays():
+    g = load_golden("render_lego_view_8k")
+    o, d = O.get_ray_bundle(800, 800, S.LEGO_FOCAL_800, g["pose"])
+    return g, o[None].contiguous(), d.reshape(-1, 3)[torch.from_numpy(g["ray_index"])].contiguous()
+
+
+def test_view8k_parity_fixture_matches_reference():
+    """The PSNR-parity fixture (8192 strided rays of a bench view through the unmodified reference): the oracle
+    reproduces a slice of it (the whole fixture is rendered on the GPU side), and the parity helper reads 0."""
+    from oracle import parity
+    g, o, d = _view8k_rays()
+    w = S.make_scene_weights(int(g["seed"]))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sl = slice(2048, 2048 + 512)
+    with torch.no_grad():
+        c, f = O.render(w, w, O.MLPSpec(), O.MLPSpec(), O.RenderSpec(), o, d[sl], 2.0, 6.0)
+    np.testing.assert_allclose(c["rgb_map"].numpy(), g["coarse.rgb_map"][sl], **TOL)
+    np.testing.assert_allclose(f["rgb_map"].numpy(), g["fine.rgb_map"][sl], rtol=2e-5, atol=2e-5)
+    p = parity.psnr_parity(f["rgb_map"].numpy(), g["fine.rgb_map"][sl], chunk=2048)
+    assert p["abs_dpsnr_db"] <= 1e-4, p
+
+
 def test_mlp_points_match_reference():
     g = load_golden("mlp_8x256_points")
     w = gen_weights(g["seed"], g["gain"], g["bias"])
@@ -139,6 +161,13 @@ def test_buff_tree_and_intersect_match_reference():
 
     assert inside(idx.numpy()) == 1.0
     assert inside(g["idx"]) < 0.5
+    # ... and with the reference's own tie order (its three sorts issued unstably: libstdc++ introsort on this torch
+    # build, oracle/introsort.py) the oracle reproduces the reference's ids EXACTLY -- every R9 output has its golden
+    for o, suffix in ((g["origins"], ""), (g["origins"][40:41], "_shared")):
+        z, idx, mask = O.buff_intersect(vox, o, g["directions"], 0.0, 1.2, 192, ties="reference")
+        np.testing.assert_array_equal(mask.numpy(), g["mask" + suffix])
+        np.testing.assert_array_equal(z.numpy(), g["z" + suffix])
+        np.testing.assert_array_equal(idx.numpy(), g["idx" + suffix])
 
 
 def test_export_obj_text_matches_reference(tmp_path):
@@ -177,6 +206,81 @@ def test_buff_tree_maintenance_matches_reference(capsys):
     tree.consolidate()
     assert np.array_equal(tree.voxels.numpy(), g["voxels_after2"])
     assert tree.voxels.shape[0] < int(g["max_voxel_count"])
+    capsys.readouterr()
+
+
+def _sampled_tree_chain(g, ties, intersect, mlp, composite, integrate):
+    """BuFFModel.forward in train mode, three batches (model_buff.py:34-73), with pluggable stages: returns
+    (memm after each step, rgb of each step)."""
+    vox = O.buff_initial_voxels(0.0, 1.2, 12)
+    memm, memms, rgbs = torch.zeros(vox.shape[0]), [], []
+    for k in range(3):
+        o, d = torch.from_numpy(g[f"origins{k}"]), torch.from_numpy(g[f"directions{k}"])
+        z, idx, mask = intersect(vox, o, d, ties)
+        uni = O.coarse_intervals(0.0, 1.2, 192, d.shape[0]).contiguous()
+        z = torch.where(mask[:, None], z, uni)
+        b = composite(mlp(o, d, z), z, d)
+        memm = integrate(memm, k + 1, idx[mask], b["weights"][mask], b["mask_weights"][mask])
+        memms.append(memm.clone())
+        rgbs.append(b["rgb_map"])
+    return memms, rgbs
+
+
+def test_buff_sampled_tree_reference_tie_order(capsys):
+    """R9's consequence, pinned: the UNMODIFIED reference sampling + integrating its own voxel ids for three training
+    forwards, then consolidate (tests/golden/buff_sampled_tree.npz).  With ties="reference" the oracle chain
+    reproduces memm after every step and the consolidated voxel set EXACTLY; with the stable order (the product
+    default) the per-ray attribution differs, so memm differs -- by how much, and what it does to the voxel set, is
+    measured here rather than assumed."""
+    from nerfmeshes_amd.models.model_helpers import nest_dict
+    from nerfmeshes_amd.nerf import CfgNode, TreeSampling
+    g = load_golden("buff_sampled_tree")
+    hp = golden_hparams(g)
+    kw = {k: hp[f"models.coarse.{k}"] for k in ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz", "num_encoding_fn_dir")}
+    w = S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw)
+    spec, rs = O.MLPSpec(**kw), O.RenderSpec(num_coarse=192, num_fine=0, training=True)
+
+    def mlp(o, d, z):
+        pts = O.ray_points(z, d, o).reshape(-1, 3)
+        return O.mlp_forward(w, spec, pts, d[:, None, :].expand(-1, 192, -1).reshape(-1, 3)).reshape(d.shape[0], 192, 4)
+
+    def run(ties):
+        return _sampled_tree_chain(g, ties, lambda v, o, d, t: O.buff_intersect(v, o, d, 0.0, 1.2, 192, ties=t), mlp,
+                                   lambda rad, z, d: O.composite(rad, z, d, rs), O.buff_integrate)
+
+    def consolidated(memm):
+        tree = TreeSampling(CfgNode(nest_dict(hp, sep=".")), "cpu")
+        tree.memm = memm.clone()
+        tree.consolidate()
+        return tree.voxels.numpy()
+
+    memms, rgbs = run("reference")
+    for k in range(3):
+        np.testing.assert_allclose(rgbs[k].numpy(), g[f"rgb{k}"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(memms[k].numpy(), g[f"memm{k}"], rtol=1e-5, atol=1e-9)
+    assert np.array_equal(consolidated(memms[2]), g["voxels_after"])
+    # the stable order: same rays, same depths, same weights -- only WHICH crossed voxel a weight is booked on differs
+    stable, rgbs_s = run("stable")
+    for k in range(3):
+        np.testing.assert_allclose(rgbs_s[k].numpy(), g[f"rgb{k}"], rtol=2e-5, atol=2e-6)
+    ref, got = torch.from_numpy(g["memm2"]), stable[2]
+    eps = float(hp["tree.eps"])
+    keep_ref, keep_got = set(torch.nonzero(ref > eps).reshape(-1).tolist()), set(torch.nonzero(got > eps).reshape(-1).tolist())
+    print(f"stable vs reference ids: voxels above eps {len(keep_got)} vs {len(keep_ref)}, common {len(keep_ref & keep_got)}; "
+          f"total weight {float(got.sum()):.6f} vs {float(ref.sum()):.6f}")
+    # Measured (this fixture): 699 vs 691 voxels above tree.eps, only 299 in common -- the reference's scrambled
+    # attribution is NOT a benign relabelling, it changes which voxels the tree keeps and refines.  That is why
+    # NM_TIES_REFERENCE exists (bit-for-bit reproduction of the reference's training-time tree) next to the stable
+    # default (every weight booked on the voxel its sample lies in).  Both orders book the same weights on the same
+    # rays' crossed voxels, so the supports stay inside the set of crossed voxels and are of similar size.
+    crossed = set()
+    vox = O.buff_initial_voxels(0.0, 1.2, 12)
+    for k in range(3):
+        _, idx, mask = O.buff_intersect(vox, torch.from_numpy(g[f"origins{k}"]), torch.from_numpy(g[f"directions{k}"]),
+                                        0.0, 1.2, 192)
+        crossed |= set(idx[mask].reshape(-1).tolist())
+    assert keep_got <= crossed
+    assert abs(len(keep_got) - len(keep_ref)) < 0.1 * len(keep_ref) and len(keep_ref & keep_got) < 0.6 * len(keep_ref)
     capsys.readouterr()
 
 
