@@ -176,6 +176,9 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
     t0 = time.perf_counter()
     rv, rf, rn, rval = mc_oracle.marching_cubes(vol, iso)
     dt = time.perf_counter() - t0
+    # the level itself: the GPU replays numpy's fp32 reductions (nm_np_stats) -> must equal numpy's own on the host copy
+    iso_numpy = float(min(max(iso_request, vol.min() + vol.std()), vol.max() - vol.std()))
+    out["marching_cubes"]["iso_equals_numpy_fp32"] = bool(iso == iso_numpy)
     same = (np.array_equal(rf, f.cpu().numpy()) and rv.tobytes() == v.cpu().numpy().tobytes()
             and rn.tobytes() == n.cpu().numpy().tobytes() and rval.tobytes() == val.cpu().numpy().tobytes())
     out["marching_cubes"].update({"bitwise_identical_to_oracle": bool(same),

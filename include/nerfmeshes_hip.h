@@ -108,6 +108,31 @@ int nm_mlp_grid_query(nm_mlp* mlp, const float* d_ax0, const float* d_ax1, const
 int nm_ray_bundle(const float* h_c2w, int32_t height, int32_t width, float focal, int64_t first,
                   int64_t count, float* d_dirs, float* h_origin, void* stream);
 
+/* A camera view: the inputs of get_ray_bundle (+ DataBundle.ndc, src/data/data_helpers.py:164-165).  Rays of a view
+ * can be generated INSIDE the render kernels (nm_render_view below): ray r is pixel first+r of the row-major (H,W)
+ * image; no origin / direction buffer is read or written, the host hands over 12 floats. */
+typedef struct nm_view {
+    float c2w[12];                 /* rows of tform_cam2world[:3,:4] */
+    int32_t height, width;
+    double focal;                  /* a python float in the reference: enters ndc_rays' constants in fp64 */
+    int32_t use_ndc;               /* cfg.dataset.use_ndc: apply ndc_rays(H, W, focal, ndc_near, o, d) to every ray */
+    double ndc_near;               /* 1.0 in the reference (data_helpers.py:165) */
+} nm_view;
+
+/* Materialise the rays of pixels [first, first+rays): d_origins (rays,3), d_dirs (rays,3) -- get_ray_bundle, then
+ * ndc_rays when view->use_ndc (origins become per-ray). */
+int nm_view_rays(const nm_view* view, int64_t first_pixel, int64_t rays, float* d_origins, float* d_dirs, void* stream);
+
+/* ndc_rays  (src/nerf/nerf_helpers.py:280-307) on n rays: d_origins (1,3) or (n,3), d_dirs (n,3) ->
+ * d_out_origins (n,3), d_out_dirs (n,3); op for op, python-float constants computed in fp64 and rounded once. */
+int nm_ndc_rays(int32_t height, int32_t width, double focal, double near_, const float* d_origins, int origins_per_ray,
+                const float* d_dirs, int64_t n, float* d_out_origins, float* d_out_dirs, void* stream);
+
+/* PositionalEncoding.forward  (src/nerf/modules.py:26-34) on its own: d_x (n,dim) ->
+ * d_out (n, [dim] + 2*dim*num_bands) = [x | sin(x_c * f_k), c-major | cos(...)]; h_bands = frequency_bands (host). */
+int nm_positional_encoding(const float* d_x, int64_t n, int32_t dim, const float* h_bands, int32_t num_bands,
+                           int32_t include_input, float* d_out, void* stream);
+
 /* RaySampleInterval.forward, deterministic branch  (src/nerf/modules.py:157-186):
  * t[r][k] = near*(1-u[k]) + far*u[k]   (or the lindisp form).  d_u = linspace(0,1,samples) as the
  * module buffer holds it; d_near/d_far are (1,) when bounds_per_ray == 0 else (rays,). */
@@ -150,6 +175,14 @@ int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
                    int bounds_per_ray, const float* d_u_coarse, const float* d_u_fine, int64_t rays,
                    void* d_workspace, const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out,
                    void* stream);
+
+/* The same for rays generated in the kernels from a camera pose (no ray buffers; saves the 24 B/ray read and the
+ * host-side `batchify` H2D of src/nerf/nerf_helpers.py:128): pixels [first_pixel, first_pixel+rays) of `view`.
+ * Bit-identical to nm_render_rays on the rays nm_view_rays materialises. */
+int nm_render_view(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const nm_view* view, int64_t first_pixel,
+                   int64_t rays, const float* d_near, const float* d_far, int bounds_per_ray, const float* d_u_coarse,
+                   const float* d_u_fine, void* d_workspace, const nm_bundle_out* coarse_out,
+                   const nm_bundle_out* fine_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training path: the arithmetic of NeRFModel.training_step
@@ -225,6 +258,13 @@ int nm_composite_backward(const float* d_radiance, const float* d_t, const float
 /* SamplePDF.forward with per-ray random u (src/nerf/modules.py:224-228): d_u (rays,fine). */
 int nm_sample_pdf_rand(const float* d_t, const float* d_weights, const float* d_u, int64_t rays, int32_t coarse,
                        int32_t fine, float* d_t_out, void* stream);
+
+/* numpy's fp32 statistics of a device array, bit for bit (src/mesh_nerf.py:56-65 picks the marching-cubes level from
+ * density.min() / .max() / .std() / .mean() of a numpy fp32 array; the mesh topology depends on that level):
+ * h_out6 = [sum, mean, var, std, min, max] as numpy computes them (8192-element buffer chunks accumulated sequentially,
+ * pairwise summation with 8 interleaved accumulators inside a chunk, fp32 throughout).  Synchronises the stream. */
+int64_t nm_np_stats_workspace_bytes(int64_t n);
+int nm_np_stats(const float* d_x, int64_t n, void* d_workspace, float* h_out6, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BuFF voxel-tree sampler: TreeSampling.batch_ray_voxel_intersect, deterministic branch

@@ -51,6 +51,11 @@ class RenderCfg(C.Structure):
                 ("white_background", C.c_int32), ("training", C.c_int32), ("attenuation_threshold", C.c_float)]
 
 
+class View(C.Structure):
+    _fields_ = [("c2w", C.c_float * 12), ("height", C.c_int32), ("width", C.c_int32), ("focal", C.c_double),
+                ("use_ndc", C.c_int32), ("ndc_near", C.c_double)]
+
+
 # name -> (restype, argtypes); the single source the symbol-export test iterates over.
 SIGNATURES = {
     "nm_last_error": (C.c_char_p, []),
@@ -78,6 +83,14 @@ SIGNATURES = {
     "nm_render_rays": (C.c_int, [c_void_p, c_void_p, C.POINTER(RenderCfg), c_void_p, C.c_int, c_void_p, c_void_p,
                                  c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, c_void_p, C.POINTER(BundleOut),
                                  C.POINTER(BundleOut), c_void_p]),
+    "nm_render_view": (C.c_int, [c_void_p, c_void_p, C.POINTER(RenderCfg), C.POINTER(View), C.c_int64, C.c_int64, c_void_p,
+                                 c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, C.POINTER(BundleOut),
+                                 C.POINTER(BundleOut), c_void_p]),
+    "nm_view_rays": (C.c_int, [C.POINTER(View), C.c_int64, C.c_int64, c_void_p, c_void_p, c_void_p]),
+    "nm_ndc_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, c_void_p, C.c_int, c_void_p, C.c_int64,
+                              c_void_p, c_void_p, c_void_p]),
+    "nm_positional_encoding": (C.c_int, [c_void_p, C.c_int64, C.c_int32, c_float_p, C.c_int32, C.c_int32, c_void_p,
+                                         c_void_p]),
     # training path
     "nm_mlp_refresh": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p]),
     "nm_mlp_forward_train": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32,
@@ -97,6 +110,8 @@ SIGNATURES = {
                                     C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_buff_intersect_ex": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
                                        C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nm_np_stats_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "nm_np_stats": (C.c_int, [c_void_p, C.c_int64, c_void_p, c_float_p, c_void_p]),
     "nm_tree_workspace_bytes": (C.c_int64, [C.c_int32]),
     "nm_tree_integrate": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p,
                                     c_void_p]),

@@ -349,6 +349,23 @@ int nm_mlp_eval_rays(nm_mlp* m, const float* d_origins, int origins_per_ray, con
     return launch_mlp_timed(m, a, 0, static_cast<hipStream_t>(stream));
 }
 
+}  // extern "C"
+
+namespace nm {
+int nm_mlp_eval_view_internal(nm_mlp* m, const RayGen* gen, const float* d_t, int64_t rays, int32_t samples,
+                              float* d_radiance, hipStream_t stream) {
+    NM_REQUIRE(m && gen && d_t && d_radiance && rays >= 0 && samples > 0, "bad argument");
+    MlpArgs a = m->base;
+    a.mode = MODE_VIEW;
+    a.a = nullptr; a.b = nullptr; a.c = d_t;
+    a.samples = samples; a.gen = *gen;
+    a.n = rays * samples; a.out = d_radiance;
+    return launch_mlp_timed(m, a, 0, stream);
+}
+}  // namespace nm
+
+extern "C" {
+
 int nm_mlp_grid_query(nm_mlp* m, const float* d_ax0, const float* d_ax1, const float* d_ax2, int32_t n0, int32_t n1,
                       int32_t n2, int64_t first, int64_t count, int32_t density_only, float* d_out, void* stream) {
     NM_REQUIRE(m && d_ax0 && d_ax1 && d_ax2 && d_out, "bad argument");

@@ -271,6 +271,16 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
                 const float dt = d[i] * t;   // -ffp-contract=off: two roundings, as torch (model_helpers.py:33)
                 p[i] = o[i] + dt;
             }
+        } else if (args.mode == MODE_VIEW) {
+            const int64_t ray = sidx / args.samples;
+            const float t = args.c[sidx];
+            float o[3];
+            nm_gen_ray(args.gen, ray, o, d);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float dt = d[i] * t;
+                p[i] = o[i] + dt;
+            }
         } else {
             const int64_t flat = args.first + sidx;
             const int64_t plane = (int64_t)args.n1 * args.n2;

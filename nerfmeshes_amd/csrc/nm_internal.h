@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
 
 #include "../../include/nerfmeshes_hip.h"
@@ -33,7 +34,60 @@ constexpr int KC = 8;          // k-steps (of 4 input features) per LDS weight c
 constexpr int MAX_FREQ_XYZ = 16;
 constexpr int MAX_FREQ_DIR = 8;
 
-enum MlpMode : int { MODE_POINTS = 0, MODE_RAYS = 1, MODE_GRID = 2 };
+enum MlpMode : int { MODE_POINTS = 0, MODE_RAYS = 1, MODE_GRID = 2, MODE_VIEW = 3 };
+
+// Pinhole rays generated inside the consuming kernel from the camera pose (get_ray_bundle,
+// /root/reference/src/nerf/nerf_helpers.py:226-277, optionally followed by ndc_rays, :280-307): ray r of a launch
+// is pixel `first + r` (row-major).  The expressions are the ones ray_bundle_kernel / ndc_rays_kernel use, so a
+// render from the pose is bit-identical to a render from a materialised ray buffer.
+struct RayGen {
+    float rot[9];            // c2w[:3,:3], row-major
+    float origin[3];         // c2w[:3,3]
+    int32_t height, width;
+    float focal;
+    int32_t enabled;
+    int32_t ndc;             // apply ndc_rays(H, W, focal, near, o, d) to every generated ray
+    float ndc_near, c_w, c_h, two_near, m_two_near;   // fp64 host constants of ndc_rays rounded to fp32, as torch does
+    int64_t first;
+};
+
+__device__ __forceinline__ float nm_norm3(float x, float y, float z) {
+    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));  // matches at::norm(p=2) on CPU bit for bit
+}
+
+// ndc_rays (nerf_helpers.py:280-307), op for op: python-float scalars enter every tensor op rounded to fp32
+__device__ __forceinline__ void nm_ndc_ray(float near32, float c_w, float c_h, float two_near, float m_two_near,
+                                           float (&o)[3], float (&d)[3]) {
+    const float t = -(near32 + o[2]) / d[2];
+    float q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const float td = t * d[a]; q[a] = o[a] + td; }
+    const float o0 = (c_w * q[0]) / q[2];
+    const float o1 = (c_h * q[1]) / q[2];
+    const float rq = 1.0f / q[2];            // python-float / tensor is Tensor.__rtruediv__ = reciprocal() * scalar
+    const float o2 = 1.0f + rq * two_near;
+    const float d0 = c_w * (d[0] / d[2] - q[0] / q[2]);
+    const float d1 = c_h * (d[1] / d[2] - q[1] / q[2]);
+    const float d2 = rq * m_two_near;
+    o[0] = o0; o[1] = o1; o[2] = o2;
+    d[0] = d0; d[1] = d1; d[2] = d2;
+}
+
+__device__ __forceinline__ void nm_gen_ray(const RayGen& g, int64_t ray, float (&o)[3], float (&d)[3]) {
+    const int64_t pix = g.first + ray;
+    const int row = (int)(pix / g.width), colx = (int)(pix - (int64_t)row * g.width);
+    const float x = ((float)colx - (float)(g.width * 0.5)) / g.focal;
+    const float y = -((float)row - (float)(g.height * 0.5)) / g.focal;
+    const float z = -1.0f;
+    const float n = nm_norm3(x, y, z);
+    const float dx = x / n, dy = y / n, dz = z / n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (dx * g.rot[3 * a] + dy * g.rot[3 * a + 1]) + dz * g.rot[3 * a + 2];
+        o[a] = g.origin[a];
+    }
+    if (g.ndc) nm_ndc_ray(g.ndc_near, g.c_w, g.c_h, g.two_near, g.m_two_near, o, d);
+}
 
 // Kernel arguments (passed by value).
 struct MlpArgs {
@@ -62,6 +116,7 @@ struct MlpArgs {
     uint64_t* mask_h;        // (L, tiles, 64): layers_xyz[0..L-2] then fc_feat; per lane, bit 4*tile+reg = activation > 0
     uint64_t* mask_v;        // (tiles, 64)
     int64_t tiles;           // ceil(n / 16)
+    RayGen gen;              // VIEW: rays generated from the pose (c = t as in RAYS; a, b unused)
 };
 
 // Kernel arguments of the backward (delta propagation) kernel.
@@ -88,6 +143,10 @@ enum TensorId : int {
 struct WeightPtrs { const float* p[T_COUNT]; };
 
 struct MlpPlan;  // host-side description of one template instantiation
+
+// fused MLP over rays generated from a camera pose (mlp_api.hip; used by the render path in ray_ops.hip)
+int nm_mlp_eval_view_internal(nm_mlp* m, const RayGen* gen, const float* d_t, int64_t rays, int32_t samples,
+                              float* d_radiance, hipStream_t stream);
 
 }  // namespace nm
 

@@ -43,9 +43,7 @@ __device__ __forceinline__ double wave_exclusive_scan(double v, int lane) {
     return lane == 0 ? (MUL ? 1.0 : 0.0) : prev;
 }
 
-__device__ __forceinline__ float torch_norm3(float x, float y, float z) {
-    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));  // matches at::norm(p=2) on CPU bit for bit
-}
+__device__ __forceinline__ float torch_norm3(float x, float y, float z) { return nm_norm3(x, y, z); }
 
 // ---- R0: pinhole rays -----------------------------------------------------------------------
 struct Pose { float r[9]; };
@@ -63,6 +61,49 @@ __global__ void ray_bundle_kernel(Pose pose, int height, int width, float focal,
     const float dx = x / n, dy = y / n, dz = z / n;
 #pragma unroll
     for (int a = 0; a < 3; ++a) dirs[3 * i + a] = (dx * pose.r[3 * a] + dy * pose.r[3 * a + 1]) + dz * pose.r[3 * a + 2];
+}
+
+__global__ void view_rays_kernel(const RayGen gen, int64_t rays, float* __restrict__ out_o, float* __restrict__ out_d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rays) return;
+    float o[3], d[3];
+    nm_gen_ray(gen, i, o, d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { out_o[3 * i + a] = o[a]; out_d[3 * i + a] = d[a]; }
+}
+
+// ndc_rays (nerf_helpers.py:280-307) over n rays; origins (1,3) shared or (n,3)
+__global__ void ndc_rays_kernel(const float* __restrict__ origins, int origins_per_ray, const float* __restrict__ dirs,
+                                int64_t n, float near32, float c_w, float c_h, float two_near, float m_two_near,
+                                float* __restrict__ out_o, float* __restrict__ out_d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* op = origins + (origins_per_ray ? 3 * i : 0);
+    float o[3] = {op[0], op[1], op[2]}, d[3] = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+    nm_ndc_ray(near32, c_w, c_h, two_near, m_two_near, o, d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { out_o[3 * i + a] = o[a]; out_d[3 * i + a] = d[a]; }
+}
+
+// PositionalEncoding.forward (modules.py:26-34) on (n, dim) rows: [x | sin(x_c * f_k) c-major | cos(...)]
+struct BandArgs { float f[MAX_FREQ_XYZ]; };
+__global__ void positional_encoding_kernel(const float* __restrict__ x, int64_t n, int dim, int nf, int include_input,
+                                           BandArgs bands, float* __restrict__ out) {
+    const int width = 2 * dim * nf + (include_input ? dim : 0);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (int64_t)(dim * nf)) return;
+    const int64_t row = i / (dim * nf);
+    const int a = (int)(i - row * (dim * nf));       // a = coord * nf + freq
+    const int c = a / nf, k = a - c * nf;
+    const float v = x[row * dim + c];
+    float* o = out + row * width;
+    const float arg = bands.f[k] * v;
+    float sv, cv;
+    sincosf(arg, &sv, &cv);
+    const int base = include_input ? dim : 0;
+    o[base + a] = sv;
+    o[base + dim * nf + a] = cv;
+    if (include_input && k == 0) o[c] = v;
 }
 
 // ---- R1: coarse depth samples -----------------------------------------------------------------
@@ -91,11 +132,19 @@ template <int PER>
 __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ radiance,
                                                         const float* __restrict__ t, const float* __restrict__ dirs,
                                                         const float* __restrict__ noise, int64_t rays, int samples,
-                                                        float thr, int white_bg, int training, nm_bundle_out out) {
+                                                        float thr, int white_bg, int training, nm_bundle_out out,
+                                                        const RayGen gen) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= rays) return;
-    const float norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    float norm;
+    if (gen.enabled) {       // rays generated from the pose: no direction buffer exists
+        float go[3], gd[3];
+        nm_gen_ray(gen, ray, go, gd);
+        norm = torch_norm3(gd[0], gd[1], gd[2]);
+    } else {
+        norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    }
     const float* tr = t + ray * samples;
     const f32x4* rr = reinterpret_cast<const f32x4*>(radiance) + ray * samples;
 
@@ -316,14 +365,17 @@ int launch_coarse_intervals(const float* d_u, const float* d_near, const float* 
 }
 
 int launch_composite(const float* d_radiance, const float* d_t, const float* d_dirs, const float* d_noise, int64_t rays,
-                     int samples, float thr, int white_bg, int training, const nm_bundle_out& out, hipStream_t stream) {
+                     int samples, float thr, int white_bg, int training, const nm_bundle_out& out, hipStream_t stream,
+                     const RayGen* gen_ptr = nullptr) {
     if (rays <= 0) return 0;
+    RayGen gen;
+    if (gen_ptr) gen = *gen_ptr; else memset(&gen, 0, sizeof(gen));
     NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
     const dim3 grid((unsigned)((rays + 3) / 4)), block(256);
     const int per = (samples + 63) / 64;
 #define NM_COMPOSITE(P)                                                                                      \
     hipLaunchKernelGGL(composite_kernel<P>, grid, block, 0, stream, d_radiance, d_t, d_dirs, d_noise, rays, samples, \
-                       thr, white_bg, training, out)
+                       thr, white_bg, training, out, gen)
     switch (per) {
         case 1: NM_COMPOSITE(1); break;
         case 2: NM_COMPOSITE(2); break;
@@ -436,14 +488,12 @@ int64_t nm_render_workspace_bytes(int64_t rays, int32_t num_coarse, int32_t num_
     return (int64_t)b;
 }
 
-int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const float* d_origins, int origins_per_ray,
-                   const float* d_dirs, const float* d_near, const float* d_far, int bounds_per_ray,
-                   const float* d_u_coarse, const float* d_u_fine, int64_t rays, void* d_workspace,
-                   const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out, void* stream_) {
-    NM_REQUIRE(coarse && cfg && d_origins && d_dirs && d_near && d_far && d_u_coarse && d_workspace && coarse_out,
-               "bad argument");
-    NM_REQUIRE(!fine || (d_u_fine && fine_out && cfg->num_fine > 0), "fine network needs u_fine / fine_out / num_fine");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+// NeRFModel.forward (model_nerf.py:37-78); `gen` != nullptr: the rays come from the pose (no origin / direction buffers)
+static int render_impl(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const float* d_origins, int origins_per_ray,
+                       const float* d_dirs, const RayGen* gen, const float* d_near, const float* d_far,
+                       int bounds_per_ray, const float* d_u_coarse, const float* d_u_fine, int64_t rays,
+                       void* d_workspace, const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out,
+                       hipStream_t stream) {
     if (rays <= 0) return 0;
     const int sc = cfg->num_coarse, sf = cfg->num_coarse + cfg->num_fine;
     char* ws = static_cast<char*>(d_workspace);
@@ -451,21 +501,114 @@ int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
     float* rad_c = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sc * 16);
     float* w_c = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sc * 4);
     int rc;
+    auto mlp = [&](nm_mlp* m, const float* t, int samples, float* rad) -> int {
+        if (!gen) return nm_mlp_eval_rays(m, d_origins, origins_per_ray, d_dirs, t, rays, samples, rad, stream);
+        return nm_mlp_eval_view_internal(m, gen, t, rays, samples, rad, stream);
+    };
     // RaySampleInterval -> intervals_to_ray_points -> model_coarse -> volume_renderer (model_nerf.py:52-62)
     if ((rc = launch_coarse_intervals(d_u_coarse, d_near, d_far, bounds_per_ray, cfg->lindisp, rays, sc, t_c, stream))) return rc;
-    if ((rc = nm_mlp_eval_rays(coarse, d_origins, origins_per_ray, d_dirs, t_c, rays, sc, rad_c, stream))) return rc;
+    if ((rc = mlp(coarse, t_c, sc, rad_c))) return rc;
     nm_bundle_out co = *coarse_out;
     if (!co.d_weights) co.d_weights = w_c;
     if ((rc = launch_composite(rad_c, t_c, d_dirs, nullptr, rays, sc, cfg->attenuation_threshold, cfg->white_background,
-                               cfg->training, co, stream))) return rc;
+                               cfg->training, co, stream, gen))) return rc;
     if (!fine) return 0;
     // sample_pdf -> intervals_to_ray_points -> model_fine -> volume_renderer (model_nerf.py:65-76)
     float* t_f = reinterpret_cast<float*>(ws); ws += align256(rays * (size_t)sf * 4);
     float* rad_f = reinterpret_cast<float*>(ws);
     if ((rc = launch_sample_pdf(t_c, co.d_weights, d_u_fine, 0, rays, sc, cfg->num_fine, t_f, stream))) return rc;
-    if ((rc = nm_mlp_eval_rays(fine, d_origins, origins_per_ray, d_dirs, t_f, rays, sf, rad_f, stream))) return rc;
+    if ((rc = mlp(fine, t_f, sf, rad_f))) return rc;
     return launch_composite(rad_f, t_f, d_dirs, nullptr, rays, sf, cfg->attenuation_threshold, cfg->white_background,
-                            cfg->training, *fine_out, stream);
+                            cfg->training, *fine_out, stream, gen);
+}
+
+int nm_render_rays(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const float* d_origins, int origins_per_ray,
+                   const float* d_dirs, const float* d_near, const float* d_far, int bounds_per_ray,
+                   const float* d_u_coarse, const float* d_u_fine, int64_t rays, void* d_workspace,
+                   const nm_bundle_out* coarse_out, const nm_bundle_out* fine_out, void* stream_) {
+    NM_REQUIRE(coarse && cfg && d_origins && d_dirs && d_near && d_far && d_u_coarse && d_workspace && coarse_out,
+               "bad argument");
+    NM_REQUIRE(!fine || (d_u_fine && fine_out && cfg->num_fine > 0), "fine network needs u_fine / fine_out / num_fine");
+    return render_impl(coarse, fine, cfg, d_origins, origins_per_ray, d_dirs, nullptr, d_near, d_far, bounds_per_ray,
+                       d_u_coarse, d_u_fine, rays, d_workspace, coarse_out, fine_out, static_cast<hipStream_t>(stream_));
+}
+
+static int make_raygen(const nm_view* v, int64_t first, RayGen* g) {
+    NM_REQUIRE(v && v->height > 0 && v->width > 0 && v->focal > 0.0, "bad view");
+    memset(g, 0, sizeof(*g));
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) g->rot[3 * a + b] = v->c2w[4 * a + b];
+        g->origin[a] = v->c2w[4 * a + 3];
+    }
+    g->height = v->height; g->width = v->width; g->focal = (float)v->focal;
+    g->enabled = 1; g->ndc = v->use_ndc ? 1 : 0; g->first = first;
+    // ndc_rays' python-float constants (nerf_helpers.py:288-303), computed in fp64 and rounded once, as torch does
+    g->ndc_near = (float)v->ndc_near;
+    g->c_w = (float)(-1.0 / (v->width / (2.0 * v->focal)));
+    g->c_h = (float)(-1.0 / (v->height / (2.0 * v->focal)));
+    g->two_near = (float)(2.0 * v->ndc_near);
+    g->m_two_near = (float)(-2.0 * v->ndc_near);
+    return 0;
+}
+
+int nm_render_view(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const nm_view* view, int64_t first_pixel,
+                   int64_t rays, const float* d_near, const float* d_far, int bounds_per_ray, const float* d_u_coarse,
+                   const float* d_u_fine, void* d_workspace, const nm_bundle_out* coarse_out,
+                   const nm_bundle_out* fine_out, void* stream_) {
+    NM_REQUIRE(coarse && cfg && view && d_near && d_far && d_u_coarse && d_workspace && coarse_out, "bad argument");
+    NM_REQUIRE(!fine || (d_u_fine && fine_out && cfg->num_fine > 0), "fine network needs u_fine / fine_out / num_fine");
+    NM_REQUIRE(first_pixel >= 0 && rays >= 0 && first_pixel + rays <= (int64_t)view->height * view->width, "pixel range");
+    RayGen g;
+    int rc = make_raygen(view, first_pixel, &g);
+    if (rc) return rc;
+    return render_impl(coarse, fine, cfg, nullptr, 0, nullptr, &g, d_near, d_far, bounds_per_ray, d_u_coarse, d_u_fine,
+                       rays, d_workspace, coarse_out, fine_out, static_cast<hipStream_t>(stream_));
+}
+
+int nm_view_rays(const nm_view* view, int64_t first_pixel, int64_t rays, float* d_origins, float* d_dirs, void* stream_) {
+    NM_REQUIRE(view && d_origins && d_dirs, "bad argument");
+    NM_REQUIRE(first_pixel >= 0 && rays >= 0 && first_pixel + rays <= (int64_t)view->height * view->width, "pixel range");
+    RayGen g;
+    int rc = make_raygen(view, first_pixel, &g);
+    if (rc || rays == 0) return rc;
+    hipLaunchKernelGGL(view_rays_kernel, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), g, rays, d_origins, d_dirs);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nm_ndc_rays(int32_t height, int32_t width, double focal, double near_, const float* d_origins, int origins_per_ray,
+                const float* d_dirs, int64_t n, float* d_out_origins, float* d_out_dirs, void* stream_) {
+    NM_REQUIRE(d_origins && d_dirs && d_out_origins && d_out_dirs && height > 0 && width > 0 && focal > 0.0 && n >= 0,
+               "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       d_origins, origins_per_ray, d_dirs, n, (float)near_, (float)(-1.0 / (width / (2.0 * focal))),
+                       (float)(-1.0 / (height / (2.0 * focal))), (float)(2.0 * near_), (float)(-2.0 * near_),
+                       d_out_origins, d_out_dirs);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nm_positional_encoding(const float* d_x, int64_t n, int32_t dim, const float* h_bands, int32_t num_bands,
+                           int32_t include_input, float* d_out, void* stream_) {
+    NM_REQUIRE(d_x && h_bands && d_out && n >= 0 && dim >= 1, "bad argument");
+    NM_REQUIRE(num_bands >= 0 && num_bands <= MAX_FREQ_XYZ, "positional_encoding: at most 16 frequency bands");
+    if (n == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int width = 2 * dim * num_bands + (include_input ? dim : 0);
+    if (num_bands == 0) {   // encoding = the input itself (or nothing)
+        if (include_input) NM_HIP_CHECK(hipMemcpyAsync(d_out, d_x, (size_t)n * dim * 4, hipMemcpyDeviceToDevice, stream));
+        (void)width;
+        return 0;
+    }
+    BandArgs b;
+    for (int k = 0; k < MAX_FREQ_XYZ; ++k) b.f[k] = k < num_bands ? h_bands[k] : 0.0f;
+    const int64_t work = n * (int64_t)(dim * num_bands);
+    hipLaunchKernelGGL(positional_encoding_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, d_x, n,
+                       dim, num_bands, include_input, b, d_out);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

@@ -23,11 +23,25 @@ def synthetic_views(count, height=800, width=800, focal=synthetic.LEGO_FOCAL_800
 
 
 def render_view(model, pose, height, width, focal, bounds, chunksize, device="cuda"):
-    origin, dirs = hip_ops.ray_bundle(pose, height, width, focal, device=device)
-    origin = origin[None]
+    """One view in chunks of `chunksize` rays (eval_nerf.py:62-65).  A NeRFModel in deterministic eval generates the
+    rays inside the kernels from the pose (query_view); other models get get_ray_bundle's rays."""
     rgb, disp = [], []
-    for s in range(0, dirs.shape[0], chunksize):
-        out = model.query((origin, dirs[s:s + chunksize], bounds))
+    n = height * width
+    try_view = hasattr(model, "query_view")
+    origin = dirs = None
+    for s in range(0, n, chunksize):
+        count = min(chunksize, n - s)
+        out = None
+        if try_view:
+            try:
+                out = model.query_view(pose, height, width, focal, bounds, first=s, count=count)
+            except RuntimeError:
+                try_view = False
+        if out is None:
+            if dirs is None:
+                origin, dirs = hip_ops.ray_bundle(pose, height, width, focal, device=device)
+                origin = origin[None]
+            out = model.query((origin, dirs[s:s + count], bounds))
         rgb.append(out.rgb_map)
         disp.append(out.disp_map)
     return torch.cat(rgb, 0), torch.cat(disp, 0)

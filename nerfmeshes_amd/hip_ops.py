@@ -213,6 +213,73 @@ def render_rays(coarse, fine, origins, dirs, near, far, u_coarse, u_fine, lindis
     return ct, ft
 
 
+def make_view(c2w, height, width, focal, ndc_near=None):
+    """nm_view from a (3|4, 4) camera-to-world matrix; ndc_near != None selects NDC rays (DataBundle.ndc uses 1.0)."""
+    pose = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w,
+                                           dtype=np.float32)[:3, :4]).reshape(-1)
+    return _lib.View((C.c_float * 12)(*pose.tolist()), int(height), int(width), float(focal),
+                     int(ndc_near is not None), float(ndc_near if ndc_near is not None else 1.0))
+
+
+def view_rays(view, first=0, count=None, device="cuda"):
+    """The rays nm_render_view generates, materialised: (origins (count,3), dirs (count,3))."""
+    count = view.height * view.width - first if count is None else count
+    o = torch.empty(count, 3, dtype=torch.float32, device=device)
+    d = torch.empty(count, 3, dtype=torch.float32, device=device)
+    check(_lib.load().nm_view_rays(C.byref(view), first, count, _ptr(o), _ptr(d), _stream()), "nm_view_rays")
+    return o, d
+
+
+def ndc_rays(height, width, focal, near, origins, dirs):
+    """ndc_rays (nerf_helpers.py:280-307) on the GPU (nm_ndc_rays): origins (...,3) broadcastable to dirs (...,3)."""
+    dirs = _dev32(dirs, name="rays_d")
+    shape = dirs.shape
+    d = dirs.reshape(-1, 3)
+    origins = _dev32(origins, dirs.device, "rays_o")
+    per_ray = origins.numel() != 3
+    o = (origins.expand(shape).reshape(-1, 3) if per_ray else origins.reshape(1, 3)).contiguous()
+    oo, od = torch.empty_like(d), torch.empty_like(d)
+    check(_lib.load().nm_ndc_rays(int(height), int(width), float(focal), float(near), _ptr(o), int(per_ray), _ptr(d),
+                                  d.shape[0], _ptr(oo), _ptr(od), _stream()), "nm_ndc_rays")
+    return oo.reshape(shape), od.reshape(shape)
+
+
+def positional_encoding(x, bands, include_input=True):
+    """PositionalEncoding.forward (modules.py:26-34) on the GPU (nm_positional_encoding)."""
+    x = _dev32(x, name="x")
+    lead, dim = x.shape[:-1], x.shape[-1]
+    b = np.ascontiguousarray(np.asarray(bands.detach().cpu() if isinstance(bands, torch.Tensor) else bands,
+                                        dtype=np.float32))
+    flat = x.reshape(-1, dim)
+    out = torch.empty(flat.shape[0], 2 * dim * b.size + (dim if include_input else 0), dtype=torch.float32, device=x.device)
+    check(_lib.load().nm_positional_encoding(_ptr(flat), flat.shape[0], dim, b.ctypes.data_as(_lib.c_float_p), b.size,
+                                             int(bool(include_input)), _ptr(out), _stream()), "nm_positional_encoding")
+    return out.reshape(*lead, out.shape[-1])
+
+
+def render_view(coarse, fine, view, near, far, u_coarse, u_fine, first=0, count=None, lindisp=False,
+                white_background=False, training=False, attenuation_threshold=1e-5):
+    """NeRFModel.forward on rays generated in the kernels from the camera pose (nm_render_view): pixels
+    [first, first+count) of `view` (hip_ops.make_view).  Returns (coarse dict, fine dict | None)."""
+    lib = _lib.load()
+    device = coarse.device
+    count = view.height * view.width - first if count is None else count
+    near, far = _dev32(near, device).reshape(-1), _dev32(far, device).reshape(-1)
+    u_coarse = _dev32(u_coarse, device)
+    sc = u_coarse.numel()
+    nf = 0 if fine is None else int(u_fine.numel())
+    u_f = None if fine is None else _dev32(u_fine, device)
+    cfg = RenderCfg(sc, nf, int(lindisp), int(white_background), int(training), float(attenuation_threshold))
+    ws = _workspace(int(lib.nm_render_workspace_bytes(count, sc, nf)), device)
+    ct, cout = _alloc_bundle(count, sc, device)
+    ft, fout = (None, None) if fine is None else _alloc_bundle(count, sc + nf, device)
+    per_ray_b = int(near.numel() == count and count > 1)
+    check(lib.nm_render_view(coarse.handle, fine.handle if fine is not None else None, C.byref(cfg), C.byref(view),
+                             first, count, _ptr(near), _ptr(far), per_ray_b, _ptr(u_coarse), _ptr(u_f), _ptr(ws),
+                             C.byref(cout), C.byref(fout) if fout is not None else None, _stream()), "nm_render_view")
+    return ct, ft
+
+
 def mlp_profile_enable(on=True):
     check(_lib.load().nm_mlp_profile_enable(int(on)), "nm_mlp_profile_enable")
 
@@ -266,6 +333,19 @@ def tree_integrate(memm, counter, indices, weights, mask_weights):
     check(lib.nm_tree_integrate(_ptr(idx), _ptr(w), _ptr(mw), idx.numel(), memm.numel(), int(counter), _ptr(memm),
                                 _ptr(ws), _stream()), "nm_tree_integrate")
     return memm
+
+
+def np_stats(x):
+    """numpy's fp32 statistics of a GPU tensor, bit for bit (nm_np_stats): dict(sum, mean, var, std, min, max) of python
+    floats holding the fp32 values `x.cpu().numpy().sum() / .mean() / .var() / .std() / .min() / .max()` would give."""
+    lib = _lib.load()
+    x = _dev32(x, name="x").reshape(-1)
+    if x.numel() == 0:
+        raise ValueError("np_stats of an empty tensor")
+    ws = torch.empty(int(lib.nm_np_stats_workspace_bytes(x.numel())), dtype=torch.uint8, device=x.device)
+    out = np.zeros(6, dtype=np.float32)
+    check(lib.nm_np_stats(_ptr(x), x.numel(), _ptr(ws), out.ctypes.data_as(_lib.c_float_p), _stream()), "nm_np_stats")
+    return dict(zip(("sum", "mean", "var", "std", "min", "max"), (np.float32(v) for v in out)))
 
 
 def marching_cubes(volume, level):

@@ -72,14 +72,13 @@ def extract_density(model, args, device, nums):
 
 
 def extract_iso_level(density, args):
-    """mesh_nerf.py:56-65.  `density` may be a numpy array (reference behaviour, numpy fp32 reductions) or a GPU
-    tensor (reductions on the GPU, std accumulated in fp64 -- differs from numpy's fp32 pairwise sum by <= 1 ulp,
-    which matters only when the clamp is active)."""
+    """mesh_nerf.py:56-65.  `density` may be a numpy array (the reference's own code path) or a GPU tensor: then the
+    statistics are numpy's fp32 reductions replayed on the device (nm_np_stats: 8192-element chunks, pairwise sums,
+    fp32 mean / variance) -- the SAME iso value bit for bit, which is what "bit-identical topology for the same
+    iso-level" needs whenever the clamp to [min + std, max - std] is active."""
     if isinstance(density, torch.Tensor):
-        lo, hi = (float(v) for v in torch.aminmax(density))
-        d64 = density.double()
-        std = float(torch.sqrt(((d64 - d64.mean()) ** 2).mean()).float())
-        mean = float(d64.mean())
+        st = hip_ops.np_stats(density)
+        lo, hi, std, mean = st["min"], st["max"], st["std"], st["mean"]
     else:
         lo, hi, std, mean = density.min(), density.max(), density.std(), density.mean()
     iso_value = min(max(args.iso_level, lo + std), hi - std)

@@ -93,6 +93,26 @@ class NeRFModel(BaseModel):
         coarse, fine = self.forward(ray_batch)
         return fine if fine is not None else coarse
 
+    def query_view(self, pose, height, width, focal, bounds, first=0, count=None):
+        """`query` for pixels [first, first+count) of a camera view, the rays generated inside the kernels from the
+        pose (nm_render_view; get_ray_bundle + cfg.dataset.use_ndc's ndc_rays): no ray buffers, no per-chunk H2D
+        (nerf_helpers.py:128).  Bit-identical to query() on get_ray_bundle's rays.  Deterministic eval only."""
+        nerf_cfg = self.cfg.nerf.train if self.model_coarse.training else self.cfg.nerf.validation
+        vr = self.volume_renderer
+        noise_std = vr.train_radiance_field_noise_std if vr.training else vr.val_radiance_field_noise_std
+        if nerf_cfg.perturb or noise_std > 0.0 or self.model_coarse.needs_grad():
+            raise RuntimeError("query_view is the deterministic inference path (no perturb / noise / autograd)")
+        near, far = bounds
+        view = hip_ops.make_view(pose, height, width, focal, ndc_near=1.0 if self.cfg.dataset.use_ndc else None)
+        fine = self.model_fine.hip() if self.model_fine is not None else None
+        cb, fb = hip_ops.render_view(
+            self.model_coarse.hip(), fine, view, torch.as_tensor(near, dtype=torch.float32).reshape(-1),
+            torch.as_tensor(far, dtype=torch.float32).reshape(-1), self.sampler.point_intervals.reshape(-1),
+            self.sample_pdf.u if fine is not None else None, first=first, count=count, lindisp=bool(nerf_cfg.lindisp),
+            white_background=bool(vr.white_background), training=bool(vr.training),
+            attenuation_threshold=vr.attenuation_threshold)
+        return OutputBundle(**(fb if fb is not None else cb))
+
     def _chunks(self, bundle, chunk):
         """The reference's manual batching (model_nerf.py:93-112): slices of `chunk` rays; origins are shared
         unless the rays are in NDC.  Tensors already in GPU memory stay there (no host round trip per chunk)."""

@@ -21,9 +21,9 @@ class OutputBundle:
 
 
 class PositionalEncoding(torch.nn.Module):
-    """Holds `frequency_bands` (state_dict compatibility, modules.py:16-24).  The encoding itself is
-    computed inside the fused MLP kernel and never materialised; calling this module on its own is not
-    part of the accelerated path."""
+    """modules.py:8-37.  Inside FlexibleNeRFModel the encoding is computed in the fused MLP kernel and never
+    materialised; called on its own, `forward` runs nm_positional_encoding and returns the same rows the reference
+    does ([x | sin(x_c * f_k), coordinate-major | cos(...)])."""
 
     def __init__(self, num_encoding_functions=6, include_input=True, log_sampling=True):
         super().__init__()
@@ -37,8 +37,7 @@ class PositionalEncoding(torch.nn.Module):
         return 6 * self.num_encoding_functions + (3 if self.include_input else 0)
 
     def forward(self, x):
-        raise NotImplementedError("PositionalEncoding is fused into the HIP MLP kernels (FlexibleNeRFModel.forward; "
-                                  "train_ops.encode_samples returns the rows the weight gradients need)")
+        return hip_ops.positional_encoding(x, self.frequency_bands, self.include_input)
 
 
 class VolumeRenderer(torch.nn.Module):

@@ -57,17 +57,8 @@ def get_ray_bundle(height, width, focal_length, tform_cam2world):
 
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    """nerf_helpers.py:280-307 (elementwise torch ops on whatever device the rays live on; per-image
-    preprocessing, not part of the per-chunk hot loop)."""
-    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
-    rays_o = rays_o + t[..., None] * rays_d
-    sx, sy = -1.0 / (W / (2.0 * focal)), -1.0 / (H / (2.0 * focal))
-    o = torch.stack([sx * rays_o[..., 0] / rays_o[..., 2], sy * rays_o[..., 1] / rays_o[..., 2],
-                     1.0 + 2.0 * near / rays_o[..., 2]], -1)
-    d = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2]),
-                     sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2]),
-                     -2.0 * near / rays_o[..., 2]], -1)
-    return o, d
+    """nerf_helpers.py:280-307 -> nm_ndc_rays (one HIP kernel, op for op as the reference's torch expressions)."""
+    return hip_ops.ndc_rays(H, W, focal, near, rays_o, rays_d)
 
 
 def cast_to_image(tensor):

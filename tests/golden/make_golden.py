@@ -310,6 +310,52 @@ def case_buff_sampled_tree(name):
     print(name, "memm > eps:", int((out["memm2"] > hp["tree.eps"]).sum()), "voxels after consolidate:", out["voxels_after"].shape[0])
 
 
+def case_ref_cache(name):
+    """(f)-4: a ray cache written by the reference's OWN CachingDataset (datasets.py:132-283): a subclass whose
+    load_dataset() returns a seeded synthetic DataBundle (two 12x16 images + poses; the image readers are out of
+    scope), `use_caching=True` -> cache_dataset() -> get_ray_bundle -> save_dataset -> <cache>/train/NNNN.data.
+    Also records what the reference's __getitem__ returns for index 1 under torch.manual_seed(7) (TRAIN: the random
+    ray subset) and the VALIDATION cache with use_ndc=True."""
+    import contextlib, importlib, io, shutil, tempfile
+    nerf, models = ref_import.load()
+    sys.path.insert(0, ref_import.REF_SRC)
+    try:
+        # the loaders import cv2 / imageio / colmap readers at module level: stubs suffice (never called)
+        datasets = importlib.import_module("data.datasets")
+        helpers = importlib.import_module("data.data_helpers")
+    finally:
+        sys.path.remove(ref_import.REF_SRC)
+    out_dir = os.path.join(HERE, name)
+    shutil.rmtree(out_dir, ignore_errors=True)
+    h, w, focal = 12, 16, 20.0
+    items = {}
+    for use_ndc, kind in ((False, datasets.DatasetType.TRAIN), (True, datasets.DatasetType.VALIDATION)):
+        hp = S.hparams(num_coarse=8, num_fine=8, use_ndc=use_ndc)
+        hp.update({"dataset.caching.use_caching": True, "dataset.caching.cache_dir": out_dir,
+                   "nerf.train.num_random_rays": 40})
+        cfg = nerf.CfgNode(models.model_helpers.nest_dict(hp, sep=".")) if hasattr(models, "model_helpers") else None
+        if cfg is None:
+            from models.model_helpers import nest_dict
+            cfg = nerf.CfgNode(nest_dict(hp, sep="."))
+
+        class Synth(datasets.CachingDataset):
+            def load_dataset(self):
+                g = torch.Generator().manual_seed(3)
+                poses = torch.from_numpy(S.orbit_poses(5)[1:3].copy())
+                return helpers.DataBundle(poses=poses, ray_targets=torch.rand(2, h, w, 3, generator=g),
+                                          ray_bounds=self.ray_bounds, hwf=(h, w, focal), size=2)
+
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ds = Synth(cfg, kind)
+            ds.paths = sorted(ds.paths)
+            torch.manual_seed(7)
+            item = ds[1]
+        items[kind.value] = {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in item.items()}
+    np.savez_compressed(os.path.join(out_dir, "getitem_seed7.npz"),
+                        **{f"{kind}.{k}": v for kind, d in items.items() for k, v in d.items()})
+    print(name, sorted(os.listdir(os.path.join(out_dir, "train"))), sorted(os.listdir(os.path.join(out_dir, "val"))))
+
+
 def case_train_step(name):
     """(f)-2: the UNMODIFIED reference's NeRFModel.training_step (model_nerf.py:88-151) on a fixed ray batch in
     train() mode (perturb off, noise 0 -- the deterministic part of the step), then loss.backward(): loss, the logged
@@ -405,7 +451,9 @@ def case_obj(name):
 
 
 if __name__ == "__main__":
-    if "--buff-sampled-tree" in sys.argv:
+    if "--ref-cache" in sys.argv:
+        case_ref_cache("ref_cache")
+    elif "--buff-sampled-tree" in sys.argv:
         case_buff_sampled_tree("buff_sampled_tree")
     elif "--view8k" in sys.argv:
         case_view("render_lego_view_8k", S.hparams(), 8192)

@@ -101,3 +101,39 @@ def test_split_k_weight_gradient_product_equals_the_plain_one():
         assert train_ops._tn(a[:, :4].contiguous(), b).shape == (4, 7)
     names = train_ops.param_names(8)
     assert len(names) == 2 + 2 * 7 + 8 and names[0] == "layer1.weight" and names[-1] == "fc_rgb.bias"
+
+
+def test_reads_a_cache_written_by_the_reference(tmp_path):
+    """(f)-4: tests/golden/ref_cache/{train,val}/NNNN.data were written by the UNMODIFIED reference's CachingDataset
+    (cache_dataset -> get_ray_bundle [-> ndc] -> save_dataset; tests/golden/make_golden.py --ref-cache).
+    CachedRayDataset reads them as they are, and __getitem__ under the same torch seed returns what the reference's
+    __getitem__ returned (recorded in getitem_seed7.npz): the same random ray subset, pixel for pixel."""
+    import os
+    import numpy as np
+    from oracle import nerf_oracle as O
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cache")
+    rec = np.load(os.path.join(root, "getitem_seed7.npz"))
+    flat = S.hparams(num_coarse=8, num_fine=8)
+    flat.update({"dataset.caching.cache_dir": root, "dataset.caching.use_caching": True, "nerf.train.num_random_rays": 40})
+    train = CachedRayDataset(CfgNode(nest_dict(flat, sep=".")), DatasetType.TRAIN)
+    assert len(train) == 2 and train.coords.shape == (12 * 16, 2)
+    raw = torch.load(train.paths[1], weights_only=False)
+    assert set(raw) == {"ray_origins", "ray_directions", "ray_targets", "ray_bounds", "size", "hwf"}
+    o, d = O.get_ray_bundle(12, 16, 20.0, S.orbit_poses(5)[2])
+    assert torch.equal(raw["ray_directions"], d) and torch.equal(raw["ray_origins"], o)       # the reference's rays
+    torch.manual_seed(7)
+    item = train[1]
+    for k in ("ray_origins", "ray_directions", "ray_targets", "ray_bounds"):
+        assert np.array_equal(item[k].numpy(), rec["train." + k]), k
+    assert item["ray_directions"].shape == (40, 3) and tuple(item["hwf"]) == (12, 16, 20.0)
+    # validation split cached with use_ndc=True: per-pixel NDC origins, whole image, no sub-sampling
+    flat["dataset.use_ndc"] = True
+    val = CachedRayDataset(CfgNode(nest_dict(flat, sep=".")), DatasetType.VALIDATION)
+    item = val[1]
+    no, nd = O.ndc_rays(12, 16, 20.0, 1.0, o[None, None, :], d)
+    assert torch.equal(item["ray_origins"], no) and torch.equal(item["ray_directions"], nd)
+    for k in ("ray_origins", "ray_directions", "ray_targets"):
+        assert np.array_equal(item[k].numpy(), rec["val." + k]), k
+    # (a reference quirk preserved in the files: DataBundle.__getitem__ indexes EVERY tensor whose first dimension equals
+    # the image count, so with exactly two images the (2,) ray_bounds is cut down to one scalar -- data_helpers.py:98-101)
+    assert item["ray_bounds"].shape == () and np.array_equal(item["ray_bounds"].numpy(), rec["val.ray_bounds"])

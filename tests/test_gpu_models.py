@@ -205,6 +205,9 @@ def test_mesh_pipeline_vs_oracle(pkg, tmp_path):
         args.res = 48
         v, f, n, density = mesh.extract_geometry(m, "cuda", args)
         iso = mesh.extract_iso_level(density, args)
+        # the GPU-tensor path of extract_iso_level replays numpy's fp32 reductions: the SAME level the reference's
+        # numpy code (mesh_nerf.py:56-65) computes on this grid, bit for bit
+        assert iso == mesh.extract_iso_level(density.cpu().numpy(), args)
         rv, rf, rn, _ = mc_oracle.marching_cubes(density.cpu().numpy(), iso)
         assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(n.cpu().numpy(), rn)
         ref_v = (torch.from_numpy(rv) / (48 / 2.0) - 1.0) * 1.2
@@ -214,12 +217,63 @@ def test_mesh_pipeline_vs_oracle(pkg, tmp_path):
             args.mesh_name = f"mesh_{int(nvd)}.obj"
             vv, ff, nn, diffuse = mesh.export_marching_cubes(m, args, None, "cuda")
             assert diffuse.shape == (vv.shape[0], 3) and diffuse.min() >= 0 and diffuse.max() <= 1
+            # R13 colours vs the oracle on the SAME vertices / normals, both branches (mesh_nerf.py:161-201):
+            # sample_points(v, -n)[..., :3] directly, or a short ray from v + eps * n back along -n through `query`
+            w = gen_weights(g["seed"], g["gain"], g["bias"])
+            vc, dirs = vv.cpu(), -nn.cpu()
+            sel = torch.arange(0, vc.shape[0], max(1, vc.shape[0] // 3000))
+            if nvd:
+                ref = O.mlp_forward(w, O.MLPSpec(), vc[sel], dirs[sel])[:, :3]
+                tol = 2e-5
+            else:
+                origins = vc[sel] - args.view_disparity * dirs[sel]
+                _, fine = O.render(w, w, O.MLPSpec(), O.MLPSpec(), O.RenderSpec(), origins, dirs[sel], 0.0,
+                                   args.view_disparity_max_bound)
+                ref, tol = fine["rgb_map"], 2e-4
+            err = np.abs(diffuse[sel.numpy()] - ref.numpy()).max(-1)
+            assert np.median(err) < 1e-5 and (err <= tol).mean() >= 0.995 and err.max() < 5e-2, \
+                (nvd, err.max(), np.median(err), (err > tol).sum())
             lines = open(tmp_path / args.mesh_name).read().splitlines()
             assert sum(l.startswith("v ") for l in lines) == vv.shape[0]
             assert sum(l.startswith("vn ") for l in lines) == vv.shape[0]
             assert sum(l.startswith("f ") for l in lines) == ff.shape[0]
             a = [int(t.split("//")[0]) for t in next(l for l in lines if l.startswith("f ")).split()[1:]]
             assert a == [int(x) + 1 for x in ff[0].tolist()]
+
+
+@pytest.mark.parametrize("n", [1, 7, 128, 1000, 8192, 8193, 3 * 8192 + 77, 100003, 96 ** 3])
+def test_np_stats_equal_numpy_bit_for_bit(pkg, n):
+    """nm_np_stats == numpy's fp32 .sum() / .mean() / .var() / .std() / .min() / .max() (what the reference's iso level
+    is made of), on chunk-aligned, ragged and grid-sized arrays."""
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal(n) * 40 + 10).astype(np.float32)
+    if n > 1000:
+        a[::97] *= 50.0                                  # heavy tail, like a density grid
+    st = pkg["ops"].np_stats(torch.from_numpy(a).cuda())
+    assert st["sum"] == a.sum() and st["mean"] == a.mean(), (st, a.sum(), a.mean())
+    assert st["var"] == a.var() and st["std"] == a.std(), (st, a.var(), a.std())
+    assert st["min"] == a.min() and st["max"] == a.max()
+
+
+def test_query_view_equals_query_on_materialised_rays(pkg):
+    """NeRFModel.query_view (rays generated in the kernels from the pose, NDC included) == query on get_ray_bundle's
+    rays, bit for bit, through the class API."""
+    from nerfmeshes_amd.nerf import get_ray_bundle, ndc_rays
+    kw = dict(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6, num_coarse=16, num_fine=16)
+    for use_ndc, bounds in ((False, torch.tensor([2.0, 6.0])), (True, torch.tensor([0.0, 1.0]))):
+        m = pkg["models"].NeRFModel(S.hparams(use_ndc=use_ndc, **kw)).eval().to("cuda")
+        with torch.no_grad():
+            m.model_coarse.fc_alpha.weight.mul_(30.0); m.model_fine.fc_alpha.weight.mul_(30.0)
+            pose, h, w, f = S.orbit_poses(5)[2], 21, 33, 40.0
+            o, d = get_ray_bundle(h, w, f, torch.from_numpy(pose))
+            d = d.reshape(-1, 3)
+            if use_ndc:
+                oo, dd = ndc_rays(h, w, f, 1.0, o[None, :], d)
+            else:
+                oo, dd = o[None], d
+            a = m.query_view(pose, h, w, f, bounds, first=5, count=600)
+            b = m.query((oo[5:605].contiguous() if use_ndc else oo, dd[5:605].contiguous(), bounds))
+        assert torch.equal(a.rgb_map, b.rgb_map) and torch.equal(a.depth_map, b.depth_map) and torch.equal(a.weights, b.weights)
 
 
 def test_eval_nerf_loop_matches_oracle_bookkeeping(pkg):

@@ -342,7 +342,10 @@ def test_full_size_view_properties(ops):
     assert 0.2 < float(acc_a.mean()) < 0.8, "the synthetic scene should be neither empty nor opaque"
 
 
-def test_ndc_rays_on_gpu_tensors(ops):
+def test_ndc_rays_kernel_vs_reference_golden(ops):
+    """(f)-4: ndc_rays (nerf_helpers.py:280-307) as one HIP kernel, op for op as the reference's torch expressions
+    (python-float constants rounded to fp32 once, scalar / tensor as reciprocal * scalar) -> the golden of the
+    unmodified reference (rays.npz), bit for bit."""
     from nerfmeshes_amd.nerf import ndc_rays
     g = load_golden("rays")
     for i in range(2):
@@ -350,8 +353,73 @@ def test_ndc_rays_on_gpu_tensors(ops):
         o = torch.from_numpy(g[f"origin{i}"]).cuda()
         d = torch.from_numpy(g[f"dirs{i}"]).cuda()
         no, nd = ndc_rays(int(h), int(w), f, 1.0, o.expand(int(h), int(w), 3) * 0.3, d)
-        _close(no, g[f"ndc_o{i}"], 2e-6, rtol=2e-6, what="ndc origins")
-        _close(nd, g[f"ndc_d{i}"], 2e-6, rtol=2e-6, what="ndc directions")
+        assert no.shape == d.shape and nd.shape == d.shape
+        np.testing.assert_array_equal(no.cpu().numpy(), g[f"ndc_o{i}"])
+        np.testing.assert_array_equal(nd.cpu().numpy(), g[f"ndc_d{i}"])
+        # shared (1,1,3) origin, as DataBundle.ndc passes it (data_helpers.py:165)
+        so, sd = ndc_rays(int(h), int(w), f, 1.0, (o * 0.3)[None, None, :], d)
+        assert torch.equal(so, no) and torch.equal(sd, nd)
+        ro, rd = O.ndc_rays(int(h), int(w), f, 1.0, (o.cpu() * 0.3)[None, None, :], d.cpu())
+        assert torch.equal(so.cpu(), ro) and torch.equal(sd.cpu(), rd)
+
+
+@pytest.mark.parametrize("ndc", [False, True])
+def test_render_view_in_kernel_ray_generation(ops, ndc):
+    """(f)-4: nm_render_view generates the rays of a camera view inside the MLP / compositing kernels (12 floats in, no
+    ray buffers).  The rays it generates are get_ray_bundle's [+ ndc_rays'] bit for bit (nm_view_rays vs nm_ray_bundle /
+    the reference golden), and the pixels equal nm_render_rays on the materialised rays bit for bit -- plain and NDC
+    (per-ray origins), on a ragged pixel range."""
+    g = load_golden("rays")
+    h, w, f = (float(v) for v in g["hwf0"])
+    h, w = int(h), int(w)
+    pose = g["pose0"]
+    view = ops.make_view(pose, h, w, f, ndc_near=1.0 if ndc else None)
+    vo, vd = ops.view_rays(view)
+    o, d = ops.ray_bundle(pose, h, w, f)
+    if not ndc:
+        assert torch.equal(vd, d) and torch.equal(vo, o[None].expand_as(vd))
+        _close(vd.reshape(h, w, 3), g["dirs0"], 1.2e-7, what="generated dirs vs reference")
+    else:
+        from nerfmeshes_amd.nerf import ndc_rays
+        no, nd = ndc_rays(h, w, f, 1.0, o[None, :], d)
+        assert torch.equal(vo, no) and torch.equal(vd, nd)
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    wts = S.make_mlp_weights(31, density_gain=20.0, density_bias=0.5, **kw)
+    mlp = ops.HipMLP(wts, kw, "cuda")
+    near, far = (torch.tensor([0.0]), torch.tensor([1.0])) if ndc else (torch.tensor([2.0]), torch.tensor([6.0]))
+    uc, uf = torch.linspace(0, 1, 32), torch.linspace(0, 1, 24)
+    first, count = 37, h * w - 50
+    cb, fb = ops.render_view(mlp, mlp, view, near, far, uc, uf, first=first, count=count)
+    cr, fr = ops.render_rays(mlp, mlp, vo[first:first + count].contiguous() if ndc else o[None],
+                             vd[first:first + count].contiguous(), near, far, uc, uf)
+    for k in BUNDLE_KEYS:
+        assert torch.equal(cb[k], cr[k]) and torch.equal(fb[k], fr[k]), k
+    assert float(fb["acc_map"].max()) > 0.05, "the scene must not be empty"
+    # full-size headline geometry: one 65 536-ray chunk of an 800x800 view, 8x256, 64+128
+    if not ndc:
+        kw8 = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+        big = ops.HipMLP(S.make_scene_weights(**kw8), kw8, "cuda")
+        pose8 = S.orbit_poses(4)[1]
+        v8 = ops.make_view(pose8, 800, 800, S.LEGO_FOCAL_800)
+        o8, d8 = ops.ray_bundle(pose8, 800, 800, S.LEGO_FOCAL_800)
+        n2, f2 = torch.tensor([2.0]), torch.tensor([6.0])
+        u64, u128 = torch.linspace(0, 1, 64), torch.linspace(0, 1, 128)
+        _, a = ops.render_view(big, big, v8, n2, f2, u64, u128, first=300000, count=65536)
+        _, b = ops.render_rays(big, big, o8[None], d8[300000:365536], n2, f2, u64, u128)
+        assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["depth_map"], b["depth_map"])
+
+
+@pytest.mark.parametrize("nf,include", [(10, True), (4, True), (6, False), (0, True)])
+def test_positional_encoding_module(ops, nf, include):
+    """R3a: PositionalEncoding.forward on its own (modules.py:26-34) -> nm_positional_encoding vs the oracle."""
+    from nerfmeshes_amd.nerf import PositionalEncoding
+    enc = PositionalEncoding(nf, include_input=include).cuda()
+    g = torch.Generator().manual_seed(nf)
+    x = (torch.rand(5, 77, 3, generator=g) * 2 - 1) * 3.0
+    got = enc(x.cuda()).cpu()
+    ref = O.positional_encoding(x, nf, include)
+    assert got.shape == ref.shape == (5, 77, enc.output_size())
+    _close(got, ref, 1e-6, what="positional encoding")     # sin/cos of arguments up to 2^9 * 3: <= 2 ulp of libm
 
 
 @pytest.mark.parametrize("rays", [1, 17, 2049])
