@@ -220,6 +220,42 @@ __device__ __forceinline__ uint64_t positive_mask(const float (&op)[COUNT]) {
     return m;
 }
 
+// The sample a lane evaluates: position p and view direction d, by input mode.
+__device__ __forceinline__ void fetch_sample(const MlpArgs& args, int64_t sidx, float (&p)[3], float (&d)[3]) {
+    if (args.mode == MODE_POINTS) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { p[i] = args.a[3 * sidx + i]; d[i] = args.b[3 * sidx + i]; }
+    } else if (args.mode == MODE_RAYS) {
+        const int64_t ray = sidx / args.samples;
+        const float t = args.c[sidx];
+        const float* o = args.a + (args.origins_per_ray ? 3 * ray : 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            d[i] = args.b[3 * ray + i];
+            const float dt = d[i] * t;   // -ffp-contract=off: two roundings, as torch (model_helpers.py:33)
+            p[i] = o[i] + dt;
+        }
+    } else if (args.mode == MODE_VIEW) {
+        const int64_t ray = sidx / args.samples;
+        const float t = args.c[sidx];
+        float o[3];
+        nm_gen_ray(args.gen, ray, o, d);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float dt = d[i] * t;
+            p[i] = o[i] + dt;
+        }
+    } else {
+        const int64_t flat = args.first + sidx;
+        const int64_t plane = (int64_t)args.n1 * args.n2;
+        const int64_t i0 = flat / plane;
+        const int64_t rem = flat - i0 * plane;
+        const int i1 = (int)(rem / args.n2), i2 = (int)(rem - (int64_t)i1 * args.n2);
+        p[0] = args.a[i0]; p[1] = args.b[i1]; p[2] = args.c[i2];
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];   // mesh_nerf.py:45: sample_points(samples, samples)
+    }
+}
+
 // ---- the fused forward kernel (TAPE: also records the activations the backward pass needs) ---------------
 template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD, int ABL, bool TAPE>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, const int num_layers,
@@ -258,38 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
 
         // ---- prologue: fetch the sample
         float p[3], d[3];
-        if (args.mode == MODE_POINTS) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { p[i] = args.a[3 * sidx + i]; d[i] = args.b[3 * sidx + i]; }
-        } else if (args.mode == MODE_RAYS) {
-            const int64_t ray = sidx / args.samples;
-            const float t = args.c[sidx];
-            const float* o = args.a + (args.origins_per_ray ? 3 * ray : 0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                d[i] = args.b[3 * ray + i];
-                const float dt = d[i] * t;   // -ffp-contract=off: two roundings, as torch (model_helpers.py:33)
-                p[i] = o[i] + dt;
-            }
-        } else if (args.mode == MODE_VIEW) {
-            const int64_t ray = sidx / args.samples;
-            const float t = args.c[sidx];
-            float o[3];
-            nm_gen_ray(args.gen, ray, o, d);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float dt = d[i] * t;
-                p[i] = o[i] + dt;
-            }
-        } else {
-            const int64_t flat = args.first + sidx;
-            const int64_t plane = (int64_t)args.n1 * args.n2;
-            const int64_t i0 = flat / plane;
-            const int64_t rem = flat - i0 * plane;
-            const int i1 = (int)(rem / args.n2), i2 = (int)(rem - (int64_t)i1 * args.n2);
-            p[0] = args.a[i0]; p[1] = args.b[i1]; p[2] = args.c[i2];
-            d[0] = p[0]; d[1] = p[1]; d[2] = p[2];   // mesh_nerf.py:45: sample_points(samples, samples)
-        }
+        fetch_sample(args, sidx, p, d);
         const float dummy[1] = {0.0f};
         float encx_keep[KEEP_ENC ? N::EX : 1];
         if constexpr (KEEP_ENC) encode<FX, N::EX, ABL>(encx_keep, p, args.bands_xyz, g);

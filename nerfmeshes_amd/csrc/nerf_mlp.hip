@@ -30,6 +30,8 @@
 
 #include "nm_internal.h"
 #include "mlp_device.h"
+#include "mlp_device_r3.h"
+#include "mlp_device_r4.h"
 
 namespace nm {
 
@@ -40,12 +42,26 @@ struct MlpPlan {
     int ring_bytes;
     bool lds_bias;
     void (*kernel)(const MlpArgs, const int, const int);
+    int wg_samples;      // samples one workgroup evaluates per iteration
+    int wg_per_cu;       // workgroups co-resident on a CU
 };
 
 template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD = false, int ABL = 0>
 static MlpPlan make_plan(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
-                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>};
+                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>, NW * 16, 8 / NW};
+}
+
+template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0>
+static MlpPlan make_plan3(int variant) {
+    return MlpPlan{H, FX, FD, NW, KCH, variant, 3 * Net<H, FX, FD, KCH>::LDSBUF, true, &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL>,
+                   NW * 16, 8 / NW};
+}
+
+template <int H, int FX, int FD, int NW, int KCH, int G>
+static MlpPlan make_plan4(int variant) {
+    return MlpPlan{H, FX, FD, NW, KCH, variant, 3 * Net<H, FX, FD, KCH>::LDSBUF, true, &mlp_kernel4<H, FX, FD, NW, KCH, G>,
+                   NW * 16 * G, 1};
 }
 
 // variant 0 is the production choice and the ONLY one in libnerfmeshes_hip.so.  The others exist for within-process
@@ -74,6 +90,19 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 4>(14),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 6>(16),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 7>(17),
+    // round 2: 3-slot ring, DMA two chunks ahead, operand prefetch across chunk / stage boundaries
+    make_plan3<256, 10, 4, 8, 8, 1>(20),    // + staggered DMA issue of the two waves of a SIMD
+    make_plan3<256, 10, 4, 8, 8, 0>(21),
+    make_plan3<256, 10, 4, 8, 8, 1, 1>(22),  // timing only (WRONG results): barriers do not wait for the DMA
+    make_plan3<256, 10, 4, 8, 8, 1, 2>(23),  // timing only (WRONG results): no weight DMA at all
+    make_plan3<256, 10, 4, 8, 8, 1, 3>(24),
+    make_plan3<256, 10, 4, 8, 8, 1, 4>(42),  // timing only (WRONG results): DMA instructions issued, one lane's worth of data
+    make_plan3<256, 10, 4, 8, 8, 2>(25),    // all DMA issued by the first-dispatched (older) wave of each SIMD pair
+    make_plan3<256, 10, 4, 8, 8, 3>(26),    // ... by the second-dispatched (younger) one
+    make_plan3<256, 10, 4, 8, 8, 4>(27),
+    make_plan3<256, 10, 4, 8, 8, 5>(28),    // weights staged global -> VGPR -> ds_write_b128 (no LDS-DMA instructions)    // staggered + issue priority alternating between the two waves every block
+    // 32 samples per wave (2 groups of 16), one wave per SIMD: every A-operand quad feeds 8 MFMAs
+    make_plan4<256, 10, 4, 4, 8, 2>(30),
 #endif
 };
 
@@ -108,8 +137,8 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
         NM_HIP_CHECK(hipFuncSetAttribute((const void*)p->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_bytes[idx] = lds_bytes;
     }
-    const int64_t wg_iters = (args.n + p->NW * 16 - 1) / (p->NW * 16);
-    const int64_t resident = (int64_t)m->num_cus * (8 / p->NW);   // workgroups co-resident per CU (2 waves / SIMD)
+    const int64_t wg_iters = (args.n + p->wg_samples - 1) / p->wg_samples;
+    const int64_t resident = (int64_t)m->num_cus * p->wg_per_cu;   // workgroups co-resident on the chip
     // persistent-style launch: a few workgroups per CU queue so the tail is balanced.
     int64_t grid = wg_iters < resident * 4 ? wg_iters : resident * 4;
     // keep the per-workgroup iteration count even across the grid where possible

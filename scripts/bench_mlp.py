@@ -13,6 +13,7 @@ if not os.path.exists(hip_build.ABLATION_LIB_PATH):
 _lib.LIB_PATH = hip_build.ABLATION_LIB_PATH           # explicit: nothing else in the package loads this library
 from nerfmeshes_amd import hip_ops, synthetic as S
 
+WRONG = set(range(11, 20)) | {22, 23, 24, 42, 43, 44}     # timing-only ablations
 variants = [int(v) for v in sys.argv[1:] if "," not in v] or [0]
 skews = [v for v in sys.argv[1:] if "," in v] or [None]
 kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
@@ -39,7 +40,7 @@ for rnd in range(6):
         a.record(); out = mlps[v].sample_points(pts, dirs); b.record(); torch.cuda.synchronize()
         if rnd == 0:
             if ref is None: ref = out.clone()
-            elif v < 10: assert torch.equal(out, ref), f"variant {v} is not bit-identical to variant {variants[0]}"
+            elif v not in WRONG: assert torch.equal(out, ref), f"variant {v} is not bit-identical to variant {variants[0]}"
         else:
             times[c].append(a.elapsed_time(b))
 flops = n * mlps[variants[0]].flops_per_sample()

@@ -257,7 +257,8 @@ def test_render_golden(ops, case):
     pre = "fine." if fb is not None else "coarse."
     par = parity.psnr_parity(final["rgb_map"].cpu(), g[pre + "rgb_map"], chunk=2048)
     print(f"{case}: {par}")
-    assert 20.0 < par["psnr_ref_db"] < 40.0, par
+    # (the reference's float batch_count, rays / 2048 < 1 on these small fixtures, inflates the loss: PSNR 34 dB - 10 log10(2048 / rays))
+    assert 10.0 < par["psnr_ref_db"] < 40.0, par
     # The 1e-4 dB bar is a whole-image quantity (one resampling-sensitive ray weighs 1/N): it is asserted as such on
     # the 8192-ray fixture below (test_psnr_parity_view8k) and on 32 768 rays in bench.py; a fixture of N rays is
     # held to the image-equivalent bar 1e-4 * 32768 / N, still on every ray it contains.
