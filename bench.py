@@ -416,7 +416,7 @@ def main():
                    else "single GPU"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": "nm::mlp_kernel<256,10,4,8>", "launches": launches,
+                     "kernel": "nm::mlp_kernel3<256,10,4,8,8,1>", "launches": launches,
                      "avg_launch_ms": kernel_ms / max(launches, 1),
                      "algorithmic_flops_per_ray": flops_per_ray,
                      "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / elapsed},

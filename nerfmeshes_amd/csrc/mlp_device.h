@@ -27,8 +27,25 @@ struct Net {
 };
 
 // ---- weight stream: HBM/L2 -> LDS DMA, 1 KiB per wave-instruction, LDS image == stream image ------
+// The DMA is `buffer_load_dwordx4 off, s[rsrc], s_offset lds` through a descriptor with ADD_TID_ENABLE and stride 16:
+// the hardware adds lane * 16 to the address, so the instruction reads NO address VGPR.  That matters more than
+// anything else about the stream: a VMEM instruction that fetches per-lane 64-bit addresses from the register file
+// (global_load_lds_dwordx4 v[a:a+1], off) holds up the MFMA issue of its SIMD for ~60 cycles, whatever it moves and
+// whichever wave issues it -- 2380 pieces per 128-sample tile = 6 % of the kernel (profiles/r02_mlp_variants.json);
+// the scalar-addressed form costs 1.3 %.  (In this mode the descriptor's DATA_FORMAT bits are stride[17:14]: left 0.)
 template <int NW>
 __device__ __forceinline__ void stream_to_lds(const char* src, char* dst, int bytes, int wave, int lane) {
+    (void)lane;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), (short)16, 0x7fffffff, 1 << 23);
+    const int units = (bytes + 1023) >> 10;
+    for (int u = wave; u < units; u += NW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, 0,
+                                                 u * 1024, 0, 0);
+}
+
+// round-1 form (per-lane 64-bit addresses in VGPRs), kept for the A/B variants of the ablation library
+template <int NW>
+__device__ __forceinline__ void stream_to_lds_vaddr(const char* src, char* dst, int bytes, int wave, int lane) {
     const int units = (bytes + 1023) >> 10;
     for (int u = wave; u < units; u += NW) {
         __builtin_amdgcn_global_load_lds(
@@ -81,7 +98,10 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NT], const float (&b1)[K
         // SIMD away from the matrix pipe for ~100 cycles per piece, 73 times per tile
         const int next_units = (next_bytes + 1023) >> 10;
         int next_u = wave;
-        if constexpr (!SPREAD && !(ABL & 4)) stream_to_lds<NW>(next_src, next_slot, next_bytes, wave, lane);
+        if constexpr (!SPREAD && !(ABL & 4)) {
+            if constexpr (ABL & 8) stream_to_lds_vaddr<NW>(next_src, next_slot, next_bytes, wave, lane);
+            else stream_to_lds<NW>(next_src, next_slot, next_bytes, wave, lane);
+        }
         if constexpr (STORE) {
             constexpr int TILES = KS1 / 4, PER_CHUNK = (TILES + NCH - 1) / NCH;
             if (store_row) {

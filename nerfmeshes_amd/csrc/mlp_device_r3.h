@@ -10,6 +10,8 @@
 //   * the DMA issue of the two waves sharing a SIMD is staggered (waves 0..NW/2-1 at k-step 0, the others half a chunk
 //     later): one wave's scalar/VMEM issue sequence runs under its partner's MFMAs instead of next to the partner's
 //     identical sequence.
+// Measured (profiles/r02_mlp_variants.json): on their own these two are worth +0.1 % -- the stall that mattered was
+// the address-VGPR read of the DMA instruction itself (see stream_to_lds in mlp_device.h).
 #pragma once
 #include "mlp_device.h"
 
@@ -25,13 +27,9 @@ struct NextChunks {          // the first two chunks of whatever stage runs next
 // operands of block j + 2 are fetched while block j runs (8 MFMAs = 256 matrix-pipe cycles of cover, 3 live operand
 // quads instead of round 1's 8), and the stream simply continues into the next chunk / the next stage: `carry` holds
 // blocks 0 and 1 of whatever comes next.
-// STAG: who issues the weight DMA and when --
-//   0 every wave at block 0 | 1 waves 0..NW/2-1 at block 0, the others half a chunk later |
-//   2 ONLY the first-dispatched half (the older wave of each SIMD pair) | 3 only the second half |
-//   4 like 1, plus the two waves of a SIMD swap issue priority every block (s_setprio)
-//   5 no LDS-DMA at all: each wave fetches its 1 KiB pieces with plain 16-byte global loads into 4 staging VGPRs and
-//     writes them to the slot with ds_write_b128, one piece per quarter chunk (measured: ONE global_load_lds costs the
-//     issuing SIMD ~110 matrix-pipe cycles whatever it moves -- 16 B or 1 KiB -- and whichever wave issues it)
+// STAG: 0 every wave issues its DMA pieces at block 0 of a chunk | 1 waves 0..NW/2-1 at block 0, the others half a chunk
+// later.  ABL (timing-only ablations, ablation library): 1 barriers do not wait for the DMA | 2 no DMA | 4 one lane per
+// DMA instruction | 8 round-1 DMA form (global_load_lds with per-lane address VGPRs).
 template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, int STAG, int ABL = 0>
 __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[KS1],
                                             const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
@@ -62,40 +60,23 @@ __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[
         char* dst = lds + slot2 * LDSBUF;
         const char* buf = lds + slot * LDSBUF + lane * 16;
         const char* nbuf = lds + slot1 * LDSBUF + lane * 16;
-        [[maybe_unused]] f32x4 staged = {0.0f, 0.0f, 0.0f, 0.0f};
-        [[maybe_unused]] int staged_u = -1;
-        [[maybe_unused]] const int units = (bytes + 1023) >> 10;
-        constexpr int PIECES = (LDSBUF / 1024 + NW - 1) / NW;           // pieces a wave may have to move per chunk
 #pragma unroll
         for (int j = 0; j < nblk; ++j) {
-            if constexpr (STAG == 5) {
-                const int every = nblk / PIECES > 0 ? nblk / PIECES : 1;
-                if (j % every == 0 && j / every < PIECES) {
-                    if (staged_u >= 0) *reinterpret_cast<f32x4*>(dst + staged_u * 1024 + lane * 16) = staged;
-                    const int u = wave + (j / every) * NW;
-                    staged_u = u < units ? u : -1;
-                    if (staged_u >= 0) staged = *reinterpret_cast<const f32x4*>(src + (size_t)u * 1024 + lane * 16);
-                }
-            } else
+            auto dma = [&]() {
+                if constexpr (ABL & 8) stream_to_lds_vaddr<NW>(src, dst, bytes, wave, lane);
+                else stream_to_lds<NW>(src, dst, bytes, wave, lane);
+            };
             if constexpr (ABL & 2) {
             } else if constexpr (ABL & 4) {   // timing only: the same instruction sequence moving 16 B instead of 1 KiB per piece
                 if (lane == 0) {
-                    if (j == 0 && wave < NW / 2) stream_to_lds<NW>(src, dst, bytes, wave, lane);
-                    if (j == nblk / 2 && wave >= NW / 2) stream_to_lds<NW>(src, dst, bytes, wave, lane);
+                    if (j == 0 && wave < NW / 2) stream_to_lds_vaddr<NW>(src, dst, bytes, wave, lane);
+                    if (j == nblk / 2 && wave >= NW / 2) stream_to_lds_vaddr<NW>(src, dst, bytes, wave, lane);
                 }
-            } else if constexpr (STAG == 1 || STAG == 4) {
-                if (j == 0 && wave < NW / 2) stream_to_lds<NW>(src, dst, bytes, wave, lane);
-                if (j == nblk / 2 && wave >= NW / 2) stream_to_lds<NW>(src, dst, bytes, wave, lane);
-            } else if constexpr (STAG == 2) {
-                if (j == 0 && wave < NW / 2) stream_to_lds<NW / 2>(src, dst, bytes, wave, lane);
-            } else if constexpr (STAG == 3) {
-                if (j == 0 && wave >= NW / 2) stream_to_lds<NW / 2>(src, dst, bytes, wave - NW / 2, lane);
+            } else if constexpr (STAG == 1) {
+                if (j == 0 && wave < NW / 2) dma();
+                if (j == nblk / 2 && wave >= NW / 2) dma();
             } else {
-                if (j == 0) stream_to_lds<NW>(src, dst, bytes, wave, lane);
-            }
-            if constexpr (STAG == 4) {
-                if (((j & 1) != 0) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
+                if (j == 0) dma();
             }
             const int ks = j / NB, blk = j % NB;
             const int s = c * KCH + ks;
@@ -108,9 +89,6 @@ __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 acc[blk * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[r0][q], b, acc[blk * 4 + q], 0, 0, 0);
-        }
-        if constexpr (STAG == 5) {
-            if (staged_u >= 0) *reinterpret_cast<f32x4*>(dst + staged_u * 1024 + lane * 16) = staged;
         }
         if constexpr (ABL & 1) __builtin_amdgcn_s_barrier();   // timing-only: no wait for the DMA (results WRONG)
         else __syncthreads();   // this wave's DMA pieces have landed (vmcnt(0)); after it the chunk after next is visible to all

@@ -31,7 +31,6 @@
 #include "nm_internal.h"
 #include "mlp_device.h"
 #include "mlp_device_r3.h"
-#include "mlp_device_r4.h"
 
 namespace nm {
 
@@ -58,51 +57,40 @@ static MlpPlan make_plan3(int variant) {
                    NW * 16, 8 / NW};
 }
 
-template <int H, int FX, int FD, int NW, int KCH, int G>
-static MlpPlan make_plan4(int variant) {
-    return MlpPlan{H, FX, FD, NW, KCH, variant, 3 * Net<H, FX, FD, KCH>::LDSBUF, true, &mlp_kernel4<H, FX, FD, NW, KCH, G>,
-                   NW * 16 * G, 1};
-}
-
 // variant 0 is the production choice and the ONLY one in libnerfmeshes_hip.so.  The others exist for within-process
 // A/B runs (scripts/bench_mlp.py) and are compiled only with -DNM_ABLATIONS into a separate library
 // (libnerfmeshes_hip_ablations.so, `python -m nerfmeshes_amd.build --ablations`), where NM_MLP_VARIANT=<n> selects
 // them; the product library never reads that variable, so an inherited environment cannot change its results.
 static const MlpPlan g_plans[] = {
-    make_plan<256, 10, 4, 8, 8, true, true, true>(0),
-    make_plan<128, 10, 4, 8, 8, true, true, true>(0),
+    // production: the round-2 kernel (3-slot ring, operand stream across boundaries, staggered scalar-addressed DMA)
+    // for the 256- and 128-wide networks; 64-wide networks (2-tile view layer) keep the round-1 dataflow
+    make_plan3<256, 10, 4, 8, 8, 1>(0),
+    make_plan3<128, 10, 4, 8, 8, 1>(0),
     make_plan<64, 10, 4, 8, 8, true, true, true>(0),
-    make_plan<256, 6, 4, 8, 8, true, true, true>(0),
-    make_plan<128, 6, 4, 8, 8, true, true, true>(0),
+    make_plan3<256, 6, 4, 8, 8, 1>(0),
+    make_plan3<128, 6, 4, 8, 8, 1>(0),
     make_plan<64, 6, 4, 8, 8, true, true, true>(0),
 #ifdef NM_ABLATIONS
-    // measured on MI355X, 2^23 points, 8x256 (profiles/r01_mlp_variants.json): v0 141.1 TFLOP/s
-    make_plan<256, 10, 4, 8, 16, true, true, true>(1),     // 16-k-step chunks: 137.6
-    make_plan<256, 10, 4, 8, 8, false, true, false>(2),    // round-1 first version (no prefetch, L2 biases): 133.7
-    make_plan<256, 10, 4, 8, 8, true, false, true>(3),     // encodings recomputed at the skip layer: ~135
-    make_plan<256, 10, 4, 8, 8, true, true, false>(4),     // prefetch only, biases from L2: 138.3
-    make_plan<256, 10, 4, 4, 8, true, true, true>(5),      // 4-wave workgroups, two per CU (decoupled barriers): 132.3
-    make_plan<256, 10, 4, 8, 8, true, true, true, true>(6),  // DMA pieces spread over the k-steps
-    make_plan<256, 10, 4, 8, 16, true, true, true, true>(7), // ... with 16-k-step chunks
+    // round 1 (profiles/r01_mlp_variants.json; all with the round-1 DMA form, ABL bit 8): v10 = round-1 production 141.1
+    make_plan<256, 10, 4, 8, 8, true, true, true, false, 8>(10),
+    make_plan<256, 10, 4, 8, 16, true, true, true, false, 8>(1),     // 16-k-step chunks: 137.6
+    make_plan<256, 10, 4, 8, 8, false, true, false, false, 8>(2),    // round-1 first version (no prefetch, L2 biases): 133.7
+    make_plan<256, 10, 4, 8, 8, true, false, true, false, 8>(3),     // encodings recomputed at the skip layer: ~135
+    make_plan<256, 10, 4, 8, 8, true, true, false, false, 8>(4),     // prefetch only, biases from L2: 138.3
+    make_plan<256, 10, 4, 4, 8, true, true, true, false, 8>(5),      // 4-wave workgroups, two per CU (decoupled barriers): 132.3
     // timing-only ablations (WRONG results): 1 = no sincos, 2 = no barrier, 4 = no weight DMA
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 1>(11),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 2>(12),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 4>(14),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 6>(16),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 7>(17),
-    // round 2: 3-slot ring, DMA two chunks ahead, operand prefetch across chunk / stage boundaries
-    make_plan3<256, 10, 4, 8, 8, 1>(20),    // + staggered DMA issue of the two waves of a SIMD
-    make_plan3<256, 10, 4, 8, 8, 0>(21),
-    make_plan3<256, 10, 4, 8, 8, 1, 1>(22),  // timing only (WRONG results): barriers do not wait for the DMA
-    make_plan3<256, 10, 4, 8, 8, 1, 2>(23),  // timing only (WRONG results): no weight DMA at all
-    make_plan3<256, 10, 4, 8, 8, 1, 3>(24),
-    make_plan3<256, 10, 4, 8, 8, 1, 4>(42),  // timing only (WRONG results): DMA instructions issued, one lane's worth of data
-    make_plan3<256, 10, 4, 8, 8, 2>(25),    // all DMA issued by the first-dispatched (older) wave of each SIMD pair
-    make_plan3<256, 10, 4, 8, 8, 3>(26),    // ... by the second-dispatched (younger) one
-    make_plan3<256, 10, 4, 8, 8, 4>(27),
-    make_plan3<256, 10, 4, 8, 8, 5>(28),    // weights staged global -> VGPR -> ds_write_b128 (no LDS-DMA instructions)    // staggered + issue priority alternating between the two waves every block
-    // 32 samples per wave (2 groups of 16), one wave per SIMD: every A-operand quad feeds 8 MFMAs
-    make_plan4<256, 10, 4, 4, 8, 2>(30),
+    // round 2 (profiles/r02_mlp_variants.json): 3-slot ring, DMA two chunks ahead, operand stream across boundaries
+    make_plan<256, 10, 4, 8, 8, true, true, true>(9),  // round-1 dataflow (2-slot ring) with the scalar-addressed DMA
+    make_plan3<256, 10, 4, 8, 8, 0>(21),        // all waves at block 0
+    make_plan3<256, 10, 4, 8, 8, 1, 8>(31),     // v20 with the round-1 DMA form (address VGPRs)
+    make_plan3<256, 10, 4, 8, 8, 1, 8 | 1>(22), // timing only (WRONG results): ... barriers do not wait for the DMA
+    make_plan3<256, 10, 4, 8, 8, 1, 2>(23),     // timing only (WRONG results): no weight DMA at all
+    make_plan3<256, 10, 4, 8, 8, 1, 4>(42),     // timing only (WRONG results): round-1 DMA form issued for one lane
 #endif
 };
 

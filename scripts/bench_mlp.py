@@ -13,8 +13,8 @@ if not os.path.exists(hip_build.ABLATION_LIB_PATH):
 _lib.LIB_PATH = hip_build.ABLATION_LIB_PATH           # explicit: nothing else in the package loads this library
 from nerfmeshes_amd import hip_ops, synthetic as S
 
-WRONG = set(range(11, 20)) | {22, 23, 24, 42, 43, 44}     # timing-only ablations
-variants = [int(v) for v in sys.argv[1:] if "," not in v] or [0]
+WRONG = set(range(11, 20)) | {22, 23, 42}     # timing-only ablations
+variants = [int(v) for v in sys.argv[1:] if "," not in v] or [0]   # 0 = production, 10 = round-1 production, 9 = round-1 dataflow + scalar DMA
 skews = [v for v in sys.argv[1:] if "," in v] or [None]
 kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
 w = S.make_scene_weights(**kw)
