@@ -234,6 +234,25 @@ int nm_encode_samples(nm_mlp* mlp, const float* d_origins, int origins_per_ray, 
                       const float* d_t, int64_t rays, int32_t samples, float* d_enc_xyz, float* d_enc_dir,
                       void* stream);
 
+/* The same with explicit row strides (floats per row >= encoding width).  With both strides 64 (the layout
+ * nm_weight_grad consumes) whole rows are written, zero padding included; otherwise the rest of a row is not touched. */
+int nm_encode_samples_strided(nm_mlp* mlp, const float* d_origins, int origins_per_ray, const float* d_dirs,
+                              const float* d_t, int64_t rays, int32_t samples, float* d_enc_xyz, int32_t stride_xyz,
+                              float* d_enc_dir, int32_t stride_dir, void* stream);
+
+/* Weight and bias gradient of one Linear from tape rows -- what autograd's addmm backward computes for every layer of
+ * FlexibleNeRFModel (src/nerf/models.py:60-80):  d_dw[o * dw_ld + dw_col0 + c] = sum_n delta[n][o] * act[n][c] for
+ * c < in_features, and (d_dbias != NULL) d_dbias[o] = sum_n delta[n][o].  d_delta (n, out_features) and d_act
+ * (n, act_stride) are row-major; n must be a multiple of 16, out_features and act_stride multiples of 64 (activation rows
+ * zero-padded beyond in_features).  Supported (out_features, act_stride): (256,256) (256,64) (128,256) (128,128)
+ * (128,64) (64,128).  fp32 MFMA, split over the samples across one workgroup per CU, order-fixed reduction of the
+ * per-workgroup partials (deterministic; no atomics).  Workspace: nm_weight_grad_workspace_bytes. */
+int nm_mlp_num_cus(const nm_mlp* mlp);
+int64_t nm_weight_grad_workspace_bytes(int32_t out_features, int32_t act_stride, int32_t num_cus);
+int nm_weight_grad(int num_cus, const float* d_delta, int32_t out_features, const float* d_act, int32_t act_stride,
+                   int32_t in_features, int64_t n, void* d_workspace, float* d_dw, int32_t dw_ld, int32_t dw_col0,
+                   float* d_dbias, void* stream);
+
 /* RaySampleInterval.forward's stratified jitter (src/nerf/modules.py:171-184): d_rand (rays,samples) in [0,1). */
 int nm_perturb_intervals(const float* d_t, const float* d_rand, int64_t rays, int32_t samples, float* d_t_out,
                          void* stream);

@@ -99,6 +99,12 @@ SIGNATURES = {
                                   c_void_p]),
     "nm_encode_samples": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p,
                                     c_void_p, c_void_p]),
+    "nm_encode_samples_strided": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p,
+                                            C.c_int32, c_void_p, C.c_int32, c_void_p]),
+    "nm_mlp_num_cus": (C.c_int, [c_void_p]),
+    "nm_weight_grad_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "nm_weight_grad": (C.c_int, [C.c_int, c_void_p, C.c_int32, c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_p, c_void_p,
+                                 C.c_int32, C.c_int32, c_void_p, c_void_p]),
     "nm_perturb_intervals": (C.c_int, [c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p, c_void_p]),
     "nm_composite_train": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int,
                                      C.POINTER(BundleOut), c_void_p]),

@@ -1,0 +1,263 @@
+// Weight gradients of the fused MLP for gfx950: dW[out][in] = sum_n delta[n][out] * act[n][in] and the bias gradients
+// db[out] = sum_n delta[n][out], for one (delta, activation) pair of tape rows -- what autograd's addmm backward does
+// for every Linear of /root/reference/src/nerf/models.py:60-80 (round 1 ran these through rocBLAS with a manual split-K
+// plus separate column sums: 35-45 % of a training iteration).
+//
+// Shape of the problem: a GEMM with a tiny output (<= 256 x 320) and a huge contraction (n = rays * samples ~ 4e5).
+// One workgroup per CU takes a contiguous range of samples and accumulates a FULL-SIZE partial dW in registers
+// (fp32 MFMA v_mfma_f32_16x16x4_f32: the contraction index of the instruction is the sample index); a second,
+// order-fixed pass sums the per-workgroup partials -- deterministic, no floating-point atomics.
+//
+// Dataflow (mirrors the forward kernel): the row-major tape rows are the streamed operands.  16 samples of delta and of
+// activation rows (16 KiB + 16 KiB for 256-wide rows) form a chunk, DMA'd HBM -> LDS THREE chunks ahead into a 4-slot
+// ring by scalar-addressed buffer_load ... lds (mlp_device.h: stream_to_lds); one barrier per chunk, in front of it a
+// COUNTED s_waitcnt vmcnt(pieces of the newest chunk): unlike the forward kernel's weights these operands come from
+// HBM, and a chunk (3.4 us of MFMAs) is not enough to cover that latency under load -- with vmcnt(0) at every barrier
+// (3-slot ring, first version) the kernel ran at 120 TFLOP/s.  From LDS every
+// lane fetches with ONE ds_read_b128 the operands of 4 output tiles: lane (k = l >> 4, i = l & 15) reads 4 consecutive
+// features 4i .. 4i+3 of sample 4*ks + k of a 64-feature block, i.e. register q is the MFMA operand of "tile q" whose
+// row/column i stands for feature 4i + q (the permutation is undone when the partial is written).  A wave owns a
+// 64 x 128 block of dW (2 blocks of 64 x 64 = 32 tiles, 128 accumulator registers): 3 ds_read_b128 per 32 MFMAs.
+// Narrow products (a 64-wide encoding operand) are split over the sample index between the wave halves instead.
+// The bias gradient is a VALU by-product: the wave that owns the first column block adds its A operands up per lane.
+//
+// Roofline: MFMA (2 * out * in FLOP per sample); HBM traffic 4 * (out + in) B per sample = 64 FLOP/B for 256 x 256,
+// i.e. 2.4 TB/s at the fp32 MFMA peak -- the two operand streams are read exactly once.
+#include "nm_internal.h"
+#include "mlp_device.h"
+
+namespace nm {
+
+struct DwArgs {
+    const float* a;          // delta rows (n_pad, AB * 64), row-major
+    const float* b;          // activation rows (n_pad, BB * 64), row-major
+    int64_t chunks;          // n_pad / 16
+    float* partial;          // (parts, AB * 64, BB * 64)
+    float* partial_bias;     // (parts, AB * 64)
+};
+
+constexpr int DW_ROWS = 16;  // samples per chunk (4 k-groups of 4)
+
+template <int AB, int BB>
+__global__ __launch_bounds__(512, 2) void dw_kernel(const DwArgs args) {
+    constexpr int NW = 8;
+    constexpr int AW = AB * 64, BW = BB * 64;
+    constexpr int A_BYTES = DW_ROWS * AW * 4, B_BYTES = DW_ROWS * BW * 4, SLOT = A_BYTES + B_BYTES;
+    constexpr int NBLK = AB * BB;
+    constexpr int BPW = NBLK >= NW ? NBLK / NW : 1;       // 64 x 64 blocks per wave
+    constexpr int KSPLIT = NBLK >= NW ? 1 : NW / NBLK;    // wave groups sharing a block, split over the k-groups
+    static_assert(NBLK >= NW ? NBLK % NW == 0 : NW % NBLK == 0, "block / wave mapping");
+    static_assert(KSPLIT <= 4 && BPW <= 2, "unsupported shape");
+    static_assert(BPW == 1 || BB % BPW == 0, "a wave's blocks share their A block");
+    constexpr int KG = 4 / KSPLIT;                        // k-groups of a chunk this wave processes
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int id0 = NBLK >= NW ? wave * BPW : wave % NBLK;
+    const int kpart = NBLK >= NW ? 0 : wave / NBLK;
+    const int ablk = id0 / BB, bblk0 = id0 % BB;
+
+    const int64_t c_lo = args.chunks * blockIdx.x / gridDim.x, c_hi = args.chunks * (blockIdx.x + 1) / gridDim.x;
+    f32x4 acc[BPW][4][4];
+#pragma unroll
+    for (int p = 0; p < BPW; ++p)
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) acc[p][qa][qb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 bias = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // every wave issues the SAME number of 1 KiB pieces per chunk (the barrier's s_waitcnt counts them): operands narrower
+    // than NW KiB per chunk are covered by letting the surplus waves repeat a piece (same bytes to the same place)
+    auto even_pieces = [&](const char* src, char* dst, int bytes) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), (short)16, 0x7fffffff, 1 << 23);
+        const int units = bytes >> 10;
+        for (int u = wave; u < ((units + NW - 1) / NW) * NW; u += NW) {
+            const int piece = u % units;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0,
+                                                     piece * 1024, 0, 0);
+        }
+    };
+    auto dma = [&](int64_t c, int slot) {                 // chunk c -> ring slot (both operands)
+        if (c >= c_hi) return;
+        char* dst = lds + slot * SLOT;
+        even_pieces(reinterpret_cast<const char*>(args.a) + c * A_BYTES, dst, A_BYTES);
+        even_pieces(reinterpret_cast<const char*>(args.b) + c * B_BYTES, dst + A_BYTES, B_BYTES);
+    };
+    // operand addresses inside a slot: k-group ks, this lane's sample 4 ks + g
+    const int a_off = g * (AW * 4) + ablk * 256 + i * 16;
+    const int b_off = A_BYTES + g * (BW * 4) + bblk0 * 256 + i * 16;
+
+    constexpr int PIECES = (A_BYTES / 1024 + NW - 1) / NW + (B_BYTES / 1024 + NW - 1) / NW;   // DMA instructions per wave per chunk
+    static_assert(PIECES >= 2 && PIECES <= 4, "counted wait below");
+    dma(c_lo, 0);
+    dma(c_lo + 1, 1);
+    dma(c_lo + 2, 2);
+    __syncthreads();
+    int slot = 0;
+    f32x4 a_next, b_next[BPW];
+    auto load_ops = [&](int s, int kg, f32x4& a, f32x4 (&b)[BPW]) {
+        const int ks = kg * KSPLIT + kpart;                                   // k-group inside the chunk
+        const char* pa = lds + s * SLOT + a_off + ks * 4 * (AW * 4);
+        const char* pb = lds + s * SLOT + b_off + ks * 4 * (BW * 4);
+        a = *reinterpret_cast<const f32x4*>(pa);
+#pragma unroll
+        for (int p = 0; p < BPW; ++p) b[p] = *reinterpret_cast<const f32x4*>(pb + p * 256);
+    };
+    if (c_lo < c_hi) load_ops(0, 0, a_next, b_next);
+
+    for (int64_t c = c_lo; c < c_hi; ++c) {
+        const int slot1 = (slot + 1) & 3;
+        const int slot3 = (slot + 3) & 3;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            // weight-stream style staggering: the two waves of a SIMD issue their DMA half a chunk apart
+            if (kg == 0 && wave < NW / 2) dma(c + 3, slot3);
+            if (kg == (KG > 1 ? KG / 2 : 0) && wave >= NW / 2) dma(c + 3, slot3);
+            const f32x4 a = a_next;
+            f32x4 b[BPW];
+#pragma unroll
+            for (int p = 0; p < BPW; ++p) b[p] = b_next[p];
+            if (kg + 1 < KG) load_ops(slot, kg + 1, a_next, b_next);
+            else load_ops(slot1, 0, a_next, b_next);         // next chunk: visible since the last barrier
+            __builtin_amdgcn_sched_barrier(0);
+            if (bblk0 == 0) bias += a;                       // column sums of delta (wave-uniform branch)
+#pragma unroll
+            for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+                for (int p = 0; p < BPW; ++p)
+#pragma unroll
+                    for (int qb = 0; qb < 4; ++qb)
+                        acc[p][qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qa], b[p][qb], acc[p][qa][qb], 0, 0, 0);
+        }
+        // chunk c + 2 (issued during chunk c - 1) must have landed before anybody reads it (from the end of chunk
+        // c + 1 on); chunk c + 3, issued during this chunk, may stay in flight across the barrier
+        if (c + 3 < c_hi) {
+            if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (PIECES == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        slot = slot1;
+    }
+
+    // ---- write this workgroup's partial (feature permutation undone: tile (qa, qb) row i' = 4g + r, column j' = i
+    //      is dW[64 ablk + 4 i' + qa][64 bblk + 4 j' + qb])
+    const int64_t part = (int64_t)blockIdx.x * KSPLIT + kpart;
+    float* out = args.partial + part * (int64_t)(AW * BW);
+#pragma unroll
+    for (int p = 0; p < BPW; ++p)
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 64 * ablk + 4 * (4 * g + r) + qa;
+                const f32x4 v = {acc[p][qa][0][r], acc[p][qa][1][r], acc[p][qa][2][r], acc[p][qa][3][r]};
+                *reinterpret_cast<f32x4*>(out + (int64_t)row * BW + 64 * (bblk0 + p) + 4 * i) = v;
+            }
+    if (bblk0 == 0) {
+        // lanes (g, i) hold the sums over samples = g (mod 4) of features 4i .. 4i+3: fold the 4 lane groups
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = bias[q];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            bias[q] = v;
+        }
+        if (g == 0) *reinterpret_cast<f32x4*>(args.partial_bias + part * AW + 64 * ablk + 4 * i) = bias;
+    }
+}
+
+// order-fixed reduction of the partials: out[o][c] = sum_p partial[p][o][c] for c < cols (padding columns dropped); the
+// threads past rows * cols reduce the bias partials.  The additions run in index order p = 0, 1, 2, ... (deterministic);
+// the loads of 16 partials are issued together so the loop is bandwidth- rather than latency-bound.
+__global__ void dw_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_bias, int parts,
+                                 int rows, int ld, int cols, float* __restrict__ out, int out_ld, int out_col0,
+                                 float* __restrict__ out_bias) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t elems = (int64_t)rows * cols;
+    const float* p;
+    int64_t stride;
+    float* dst;
+    if (t < elems) {
+        const int o = (int)(t / cols), c = (int)(t - (int64_t)o * cols);
+        p = partial + (int64_t)o * ld + c;
+        stride = (int64_t)rows * ld;
+        dst = out + (int64_t)o * out_ld + out_col0 + c;
+    } else if (out_bias && t < elems + rows) {
+        const int o = (int)(t - elems);
+        p = partial_bias + o;
+        stride = rows;
+        dst = out_bias + o;
+    } else {
+        return;
+    }
+    float s = 0.0f;
+    int k = 0;
+    for (; k + 16 <= parts; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; k < parts; ++k) s += p[k * stride];
+    *dst = s;
+}
+
+struct DwPlan {
+    int ab, bb, ksplit;
+    void (*kernel)(const DwArgs);
+};
+static const DwPlan g_dw_plans[] = {
+    {4, 4, 1, &dw_kernel<4, 4>}, {4, 1, 2, &dw_kernel<4, 1>}, {2, 4, 1, &dw_kernel<2, 4>}, {2, 1, 4, &dw_kernel<2, 1>},
+    {2, 2, 2, &dw_kernel<2, 2>}, {1, 2, 4, &dw_kernel<1, 2>},
+};
+
+}  // namespace nm
+
+using namespace nm;
+
+extern "C" int64_t nm_weight_grad_workspace_bytes(int32_t out_features, int32_t in_features, int32_t num_cus) {
+    if (out_features <= 0 || in_features <= 0 || num_cus <= 0) return 0;
+    const int64_t ab = (out_features + 63) / 64, bb = (in_features + 63) / 64;
+    return (int64_t)num_cus * 4 * (ab * 64 * bb * 64 + ab * 64) * 4;
+}
+
+// d_delta (n, out_features) and d_act (n, act_stride) row-major, n a multiple of 16, out_features and act_stride
+// multiples of 64 (act rows may carry zero padding beyond in_features).  Writes d_dw[o * dw_ld + dw_col0 + c] for
+// c < in_features and, when d_dbias != NULL, d_dbias[o] = sum_n delta[n][o].
+extern "C" int nm_weight_grad(int device_cus, const float* d_delta, int32_t out_features, const float* d_act,
+                              int32_t act_stride, int32_t in_features, int64_t n, void* d_workspace, float* d_dw,
+                              int32_t dw_ld, int32_t dw_col0, float* d_dbias, void* stream_) {
+    NM_REQUIRE(d_delta && d_act && d_workspace && d_dw && n > 0, "bad argument");
+    NM_REQUIRE(n % DW_ROWS == 0, "weight_grad: the row count must be a multiple of 16 (pad the tape with zero rows)");
+    NM_REQUIRE(out_features % 64 == 0 && act_stride % 64 == 0 && in_features >= 1 && in_features <= act_stride,
+               "weight_grad: feature counts must be multiples of 64 (pad the activation rows with zeros)");
+    const int ab = out_features / 64, bb = act_stride / 64;
+    const DwPlan* plan = nullptr;
+    for (const DwPlan& p : g_dw_plans)
+        if (p.ab == ab && p.bb == bb) plan = &p;
+    NM_REQUIRE(plan, "weight_grad: no kernel instantiated for this (out, in) block shape");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t chunks = n / DW_ROWS;
+    const int cus = device_cus > 0 ? device_cus : 256;
+    const int grid = (int)(chunks < cus ? chunks : cus);
+    const int parts = grid * plan->ksplit;
+    DwArgs a;
+    a.a = d_delta; a.b = d_act; a.chunks = chunks;
+    a.partial = static_cast<float*>(d_workspace);
+    a.partial_bias = a.partial + (int64_t)parts * out_features * act_stride;
+    const int lds_bytes = 4 * DW_ROWS * (out_features + act_stride) * 4;
+    NM_REQUIRE(lds_bytes <= 160 * 1024, "weight_grad: LDS budget exceeded");
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)plan->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(plan->kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
+    const int64_t elems = (int64_t)out_features * in_features;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((elems + out_features + 255) / 256)), dim3(256), 0, stream,
+                       a.partial, a.partial_bias, parts, out_features, act_stride, in_features, d_dw, dw_ld, dw_col0, d_dbias);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -136,6 +136,7 @@ struct EncodeArgs {
     float bands_xyz[MAX_FREQ_XYZ];
     float bands_dir[MAX_FREQ_DIR];
     float* enc_x; float* enc_d;
+    int32_t stride_x, stride_d;   // floats per output row (>= the encoding width; the tail of a row is left untouched)
 };
 
 __device__ __forceinline__ void encode_row(float* row, const float (&x)[3], int F, int include, const float* bands) {
@@ -163,8 +164,42 @@ __global__ __launch_bounds__(256) void encode_samples_kernel(const EncodeArgs ar
         p[k] = o[k] + dt;
     }
     const int dx = 6 * args.fx + (args.include_x ? 3 : 0), dd = 6 * args.fd + (args.include_d ? 3 : 0);
-    if (args.enc_x) encode_row(args.enc_x + i * dx, p, args.fx, args.include_x, args.bands_xyz);
-    if (args.enc_d) encode_row(args.enc_d + i * dd, d, args.fd, args.include_d, args.bands_dir);
+    (void)dx; (void)dd;
+    if (args.enc_x) encode_row(args.enc_x + i * args.stride_x, p, args.fx, args.include_x, args.bands_xyz);
+    if (args.enc_d) encode_row(args.enc_d + i * args.stride_d, d, args.fd, args.include_d, args.bands_dir);
+}
+
+// The same rows for the weight-gradient kernel: 64-float zero-padded rows, ONE OUTPUT ELEMENT PER THREAD so that a
+// wavefront writes 256 contiguous bytes (the row-per-thread kernel above issues 4-byte stores 256 B apart: 0.63 ms for
+// 393 216 samples; this one is bandwidth-bound).  sincosf is evaluated on the same product as encode<>() / encode_row()
+// and one of its two results kept, so the values are bit-identical to the forward kernel's.
+__global__ __launch_bounds__(256) void encode_samples64_kernel(const EncodeArgs args) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = e >> 6;
+    const int j = (int)(e & 63);
+    if (i >= args.n) return;
+    const int64_t ray = i / args.samples;
+    const float t = args.t[i];
+    const float* o = args.origins + (args.origins_per_ray ? 3 * ray : 0);
+    float p[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = args.dirs[3 * ray + k];
+        const float dt = d[k] * t;
+        p[k] = o[k] + dt;
+    }
+    auto element = [&](const float (&x)[3], int F, int include, const float* bands) -> float {
+        const int base = include ? 3 : 0;
+        if (j < base) return x[j];
+        const int a = j - base;
+        if (a >= 6 * F) return 0.0f;                       // zero padding up to 64
+        const int arg = a < 3 * F ? a : a - 3 * F;
+        float sv, cv;
+        sincosf(x[arg / F] * bands[arg % F], &sv, &cv);
+        return a < 3 * F ? sv : cv;
+    };
+    if (args.enc_x) args.enc_x[i * 64 + j] = element(p, args.fx, args.include_x, args.bands_xyz);
+    if (args.enc_d) args.enc_d[i * 64 + j] = element(d, args.fd, args.include_d, args.bands_dir);
 }
 
 // ---- plan tables -------------------------------------------------------------------------------------------
@@ -266,22 +301,43 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
     return 0;
 }
 
-int nm_encode_samples(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
-                      int64_t rays, int32_t samples, float* d_enc_xyz, float* d_enc_dir, void* stream) {
+int nm_encode_samples_strided(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs,
+                              const float* d_t, int64_t rays, int32_t samples, float* d_enc_xyz, int32_t stride_xyz,
+                              float* d_enc_dir, int32_t stride_dir, void* stream) {
     NM_REQUIRE(m && d_origins && d_dirs && d_t && rays >= 0 && samples > 0, "bad argument");
     EncodeArgs a;
     a.origins = d_origins; a.dirs = d_dirs; a.t = d_t;
     a.n = rays * samples; a.samples = samples; a.origins_per_ray = origins_per_ray;
     a.fx = m->desc.num_encoding_fn_xyz; a.fd = m->desc.num_encoding_fn_dir;
     a.include_x = m->desc.include_input_xyz; a.include_d = m->desc.include_input_dir;
+    const int dx = 6 * a.fx + (a.include_x ? 3 : 0), dd = 6 * a.fd + (a.include_d ? 3 : 0);
+    NM_REQUIRE((!d_enc_xyz || stride_xyz >= dx) && (!d_enc_dir || stride_dir >= dd), "encode_samples: row stride too small");
     for (int f = 0; f < MAX_FREQ_XYZ; ++f) a.bands_xyz[f] = m->base.bands_xyz[f];
     for (int f = 0; f < MAX_FREQ_DIR; ++f) a.bands_dir[f] = m->base.bands_dir[f];
     a.enc_x = d_enc_xyz; a.enc_d = d_enc_dir;
+    a.stride_x = stride_xyz; a.stride_d = stride_dir;
     if (a.n == 0) return 0;
-    hipLaunchKernelGGL(encode_samples_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a);
+    if (stride_xyz == 64 && stride_dir == 64 && d_enc_xyz && d_enc_dir && dx <= 64 && dd <= 64) {
+        // the weight-gradient layout: whole 64-float rows written (padding included), one element per thread
+        hipLaunchKernelGGL(encode_samples64_kernel, dim3((unsigned)((a.n * 64 + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), a);
+    } else {
+        hipLaunchKernelGGL(encode_samples_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), a);
+    }
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+int nm_encode_samples(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
+                      int64_t rays, int32_t samples, float* d_enc_xyz, float* d_enc_dir, void* stream) {
+    NM_REQUIRE(m, "bad argument");
+    const int dx = 6 * m->desc.num_encoding_fn_xyz + (m->desc.include_input_xyz ? 3 : 0);
+    const int dd = 6 * m->desc.num_encoding_fn_dir + (m->desc.include_input_dir ? 3 : 0);
+    return nm_encode_samples_strided(m, d_origins, origins_per_ray, d_dirs, d_t, rays, samples, d_enc_xyz, dx, d_enc_dir, dd,
+                                     stream);
+}
+
+int nm_mlp_num_cus(const nm_mlp* m) { return m ? m->num_cus : 0; }
 
 }  // extern "C"

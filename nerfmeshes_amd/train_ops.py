@@ -97,6 +97,30 @@ def _tn(a, b):
     return out
 
 
+_DW_SHAPES = {(256, 256), (256, 64), (128, 256), (128, 128), (128, 64), (64, 128)}     # (out, padded in) of nm_weight_grad
+_dw_ws = {}
+
+
+def _weight_grad(mlp, delta, act, in_features, out=None, col0=0, bias=True):
+    """dW = delta^T @ act[:, :in_features] (+ column sums of delta) through nm_weight_grad: fp32 MFMA, split over the
+    samples across the CUs, order-fixed reduction.  delta (n, out) / act (n, stride) contiguous, n % 16 == 0."""
+    lib = _lib.load()
+    n, o = delta.shape
+    stride = act.shape[1]
+    cus = int(lib.nm_mlp_num_cus(mlp.handle))
+    need = int(lib.nm_weight_grad_workspace_bytes(o, stride, cus))
+    key = (mlp.device, torch.cuda.current_stream(mlp.device).cuda_stream)
+    ws = _dw_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=mlp.device)
+    if out is None:
+        out = torch.empty(o, in_features, dtype=torch.float32, device=mlp.device)
+    db = torch.empty(o, dtype=torch.float32, device=mlp.device) if bias else None
+    check(lib.nm_weight_grad(cus, _ptr(delta), o, _ptr(act), stride, in_features, n, _ptr(ws), _ptr(out), out.shape[1],
+                             col0, _ptr(db), _stream()), "nm_weight_grad")
+    return out, db
+
+
 def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     """Parameter gradients of sum(radiance * grad_radiance): dict keyed like FlexibleNeRFModel.state_dict()."""
     lib = _lib.load()
@@ -111,22 +135,54 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     cd = MlpDeltas(_ptr(dh), _ptr(dfeat), _ptr(dv), _ptr(dlast))
     check(lib.nm_mlp_backward(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), _stream()),
           "nm_mlp_backward")
-    enc_x, enc_d = encode_samples(mlp, origins, dirs, t)
     h, feat, v = tape["h"], tape["feat"], tape["v"]
-    g = {"layer1.weight": _tn(dh[0], enc_x), "layer1.bias": dh[0].sum(0)}
-    for i in range(L - 1):
-        delta = dh[1 + i]
-        gw = _tn(delta, h[i])
-        if i % skip_step == 0 and i > 0 and i != L - 1:      # cat(x, xyz): models.py:64-65
-            gw = torch.cat((gw, _tn(delta, enc_x)), dim=1)
-        g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, delta.sum(0)
-    g["fc_feat.weight"], g["fc_feat.bias"] = _tn(dfeat, h[L - 1]), dfeat.sum(0)
-    # the 1-row / 3-row heads share dlast (n,4): one split-K product per operand, rows picked afterwards (rocBLAS
-    # runs a (3 x n) @ (n x 128) GEMM on a 32x16 macro tile: 1.1 ms, a third of the delta kernel)
+    dx = 6 * int(d["num_encoding_fn_xyz"]) + (3 if d.get("include_input_xyz", True) else 0)
+    dd = 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
+    is_skip = lambda i: i % skip_step == 0 and i > 0 and i != L - 1   # noqa: E731  (cat(x, xyz): models.py:64-65)
+    # hand-written weight-gradient kernel (nm_weight_grad) when the tape rows fit its tiling; the library GEMM
+    # (torch.bmm split-K, _tn) otherwise -- 64-wide networks, ragged sample counts
+    fast = n % 16 == 0 and H in (128, 256) and dx <= 64 and dd <= 64
+    g = {}
     last_sums = dlast.sum(0)
+    if fast:
+        origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
+        rays, samples = t.shape
+        enc_x, enc_d = torch.empty(n, 64, **f32), torch.empty(n, 64, **f32)      # 64-float rows, padding written by the kernel
+        check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
+                                            samples, _ptr(enc_x), 64, _ptr(enc_d), 64, _stream()), "nm_encode_samples_strided")
+        g["layer1.weight"], g["layer1.bias"] = _weight_grad(mlp, dh[0], enc_x, dx)
+        for i in range(L - 1):
+            delta = dh[1 + i]
+            if is_skip(i):
+                gw = torch.empty(H, H + dx, **f32)
+                _, gb = _weight_grad(mlp, delta, h[i], H, out=gw, col0=0)
+                _weight_grad(mlp, delta, enc_x, dx, out=gw, col0=H, bias=False)
+            else:
+                gw, gb = _weight_grad(mlp, delta, h[i], H)
+            g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, gb
+        g["fc_feat.weight"], g["fc_feat.bias"] = _weight_grad(mlp, dfeat, h[L - 1], H)
+        gw = torch.empty(H // 2, H + dd, **f32)
+        _, g["layers_dir.0.bias"] = _weight_grad(mlp, dv, feat, H, out=gw, col0=0)
+        if (H // 2, 64) in _DW_SHAPES:
+            _weight_grad(mlp, dv, enc_d, dd, out=gw, col0=H, bias=False)
+        else:
+            gw[:, H:] = _tn(dv, enc_d[:, :dd].contiguous())
+        g["layers_dir.0.weight"] = gw
+    else:
+        enc_x, enc_d = encode_samples(mlp, origins, dirs, t)
+        g.update({"layer1.weight": _tn(dh[0], enc_x), "layer1.bias": dh[0].sum(0)})
+        for i in range(L - 1):
+            delta = dh[1 + i]
+            gw = _tn(delta, h[i])
+            if is_skip(i):
+                gw = torch.cat((gw, _tn(delta, enc_x)), dim=1)
+            g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, delta.sum(0)
+        g["fc_feat.weight"], g["fc_feat.bias"] = _tn(dfeat, h[L - 1]), dfeat.sum(0)
+        g["layers_dir.0.weight"] = torch.cat((_tn(dv, feat), _tn(dv, enc_d)), dim=1)   # cat(feat, view): models.py:72
+        g["layers_dir.0.bias"] = dv.sum(0)
+    # the 1-row / 3-row heads share dlast (n,4): one split-K product per operand, rows picked afterwards (an MFMA tile
+    # would waste 12 of its 16 rows; 0.1 ms)
     g["fc_alpha.weight"], g["fc_alpha.bias"] = _tn(dlast, h[L - 1])[3:4], last_sums[3:4]
-    g["layers_dir.0.weight"] = torch.cat((_tn(dv, feat), _tn(dv, enc_d)), dim=1)   # cat(feat, view): models.py:72
-    g["layers_dir.0.bias"] = dv.sum(0)
     g["fc_rgb.weight"], g["fc_rgb.bias"] = _tn(dlast, v)[:3], last_sums[:3]
     return g
 

@@ -333,3 +333,29 @@ def test_training_step_against_the_reference_golden():
         ref = torch.from_numpy(g["grad." + name])
         assert p.grad is not None and p.grad.shape == ref.shape, name
         assert _rel(p.grad, ref) < 2e-3, (name, _rel(p.grad, ref))
+
+
+@pytest.mark.parametrize("out_f,stride,in_f", [(256, 256, 256), (256, 64, 63), (128, 256, 256), (128, 128, 128),
+                                               (128, 64, 27), (64, 128, 128)])
+@pytest.mark.parametrize("n", [16, 1040, 40000])
+def test_weight_grad_kernel_vs_fp64(n, out_f, stride, in_f):
+    """nm_weight_grad (hand-written split-over-samples fp32 MFMA GEMM + bias column sums, order-fixed reduction) vs
+    delta^T @ act in fp64, for every supported block shape; deterministic (two runs bit-identical); writes into a
+    column window of a wider matrix (the skip / view layers' cat(...) weights)."""
+    from nerfmeshes_amd import hip_ops, train_ops as T
+    kw = dict(num_layers=4, hidden_size=128, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    mlp = hip_ops.HipMLP({k: torch.as_tensor(v) for k, v in S.make_mlp_weights(3, **kw).items()}, kw, "cuda")
+    g = torch.Generator().manual_seed(n + out_f)
+    delta = torch.randn(n, out_f, generator=g) * (torch.rand(n, 1, generator=g) < 0.7)
+    act = torch.relu(torch.randn(n, stride, generator=g))
+    act[:, in_f:] = 0.0
+    dc, ac = delta.cuda().contiguous(), act.cuda().contiguous()
+    wide = torch.full((out_f, in_f + 10), 7.0, device="cuda")
+    dw, db = T._weight_grad(mlp, dc, ac, in_f)
+    dw2, db2 = T._weight_grad(mlp, dc, ac, in_f, out=wide, col0=10)
+    ref = (delta.double().t() @ act.double()[:, :in_f])
+    scale = float(ref.abs().max()) + 1e-30
+    assert float((dw.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5)
+    assert float((db.double().cpu() - delta.double().sum(0)).abs().max()) <= 2e-6 * float(delta.abs().sum(0).max() + 1)
+    assert torch.equal(wide[:, 10:], dw) and torch.equal(db2, db), "not deterministic / column window wrong"
+    assert bool((wide[:, :10] == 7.0).all()), "wrote outside its column window"
