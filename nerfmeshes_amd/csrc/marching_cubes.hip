@@ -309,101 +309,148 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 }
 
 // ---- pass 1: classify ---------------------------------------------------------------------------------
-// Brick-shaped workgroups: 32 x-groups (4 cubes each) x 8 y x MC_ZRUN z.  A thread walks MC_ZRUN cubes up the z axis
-// and keeps the sign bits of the plane below in registers, so every voxel row is fetched by two cube rows of the SAME
-// workgroup (L1 hits) instead of four rows spread over tiles that run on different XCDs -- the scan-order tiling
-// of the first version re-read the volume ~3x across L2s and ran at 0.7 TB/s.
-constexpr int MC_ZRUN = 8;
-constexpr int MC_BRICK_CUBES = MC_BLOCK * MC_ITEMS * MC_ZRUN;       // 8192
+// Two kernels (round 2; round 1 did both in one 118-VGPR kernel with a 32 KB LDS queue: 4 workgroups per CU, 0.94 TB/s,
+// 1.42x over-fetch).
+//
+// (a) mc_classify_stream -- the HBM-bound part, and nothing else.  A workgroup of 1024 threads = 128 x-groups (512
+//     voxels: a whole row of the 480^3 grid) x 8 voxel rows marches MC_ZRUN planes up the z axis: per plane every
+//     thread issues ONE 16-byte load and the workgroup as a whole reads one CONTIGUOUS 16 KB run of the volume (the 8
+//     rows are adjacent in memory), MC_AHEAD planes in flight.  Sign bits go through 1 KB of LDS per plane: a cube's
+//     corner pattern is made of its thread's bits, the next x-group's first bit, the thread row above (the 8th thread
+//     row only supplies that halo: 7 cube layers per brick) and the previous step's (kept in registers).  Voxels fetched
+//     per cube: 8/7 x 25/24 = 1.19, all of it in whole rows -- round 1's bricks (129 x 9 x 9 voxels in 516-byte
+//     row segments) measured 1.42x at 0.94 TB/s whatever the brick shape.
+//     Every load is UNCONDITIONAL (addresses clamped into the volume; clamped values only reach cubes that do not
+//     exist): loads inside divergent branches make the compiler fall back to s_waitcnt vmcnt(0) at every use.
+//     Cubes the surface cuts (index != 0, 255; ~1 %) are appended -- 64-bit (cube id | corner pattern << 40) -- to a
+//     global queue through an LDS staging buffer, one atomicAdd per flush.  The code bytes of all other cubes are a memset.
+// (b) mc_classify_cut -- one thread per queued cube: the MC33 face / interior tests (fp64), the tiling row, the number
+//     of vertices the cube creates; writes that cube's code byte.
+constexpr int MC_ZRUN = 24;
+constexpr int MC_GX = 128, MC_GY = 8;                               // thread grid: x-groups per row, voxel rows (7 cube rows + halo)
+constexpr int MC_STREAM_THREADS = MC_GX * MC_GY;
+constexpr int MC_CUBES_PER_PLANE = MC_GX * MC_ITEMS * (MC_GY - 1);  // 3584
+constexpr int MC_STAGE = 2 * 4096;                                  // LDS staging entries: flushed every 2 planes
+constexpr int MC_AHEAD = 6;
 
 struct __attribute__((packed)) McWord { uint32_t v; };              // 4 code bytes at any byte offset
 
-// sign bits of the 5 voxels row[x0 .. x0+4]; FAST: all five exist (one 16-byte + one 4-byte load, branch-free so that
-// the caller's 18 row fetches are all issued before the first use); otherwise voxels past the row end read as 0.
-// `thr` is the largest float <= iso: (double)v > iso  <=>  v > thr exactly, without 180 fp64 conversions per thread.
-template <bool FAST>
-__device__ __forceinline__ unsigned row_bits(const float* __restrict__ row, int x0, int n2, float thr) {
-    unsigned bits = 0;
-    if constexpr (FAST) {
-        struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
-        const F4 q = *reinterpret_cast<const F4*>(row + x0);
-        const float last = row[x0 + 4];
-        bits = (q.v[0] > thr ? 1u : 0u) | (q.v[1] > thr ? 2u : 0u) | (q.v[2] > thr ? 4u : 0u) | (q.v[3] > thr ? 8u : 0u) |
-               (last > thr ? 16u : 0u);
-    } else {
+// The thread rows are 8 consecutive PLANES (7 cube planes + the halo plane) and the march runs along axis 1 (rows,
+// 1920 B apart), so a workgroup stays inside 8 address windows of a few hundred KB.  (Marching along axis 0 with 8
+// adjacent rows per step -- one contiguous 16 KB run per step, 921 KB jumps between steps -- measures the same:
+// 240 vs 244 us at 480^3; what is left is the memory system's own streaming rate, a plain torch reduction over the
+// same 442 MB takes ~140 us.)
+template <bool VEC, bool XHALO>   // VEC: n2 % 4 == 0 (every x-group is one 16-byte load); XHALO: more than one brick in x
+__global__ __launch_bounds__(MC_STREAM_THREADS) void mc_classify_stream(const float* __restrict__ vol, McDims d, float thr,
+                                                                        uint64_t* __restrict__ queue,
+                                                                        unsigned long long* __restrict__ qcount) {
+    __shared__ uint8_t s_bits[2][MC_GY][MC_GX + 1];      // 4-bit sign patterns (+ the voxel behind the brick), two steps
+    __shared__ uint32_t s_q[MC_STAGE];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_base;
+    const int tx = threadIdx.x % MC_GX, tz = threadIdx.x / MC_GX;
+    const int xb = blockIdx.x * MC_GX * MC_ITEMS, z0 = blockIdx.y * (MC_GY - 1), y0 = blockIdx.z * MC_ZRUN;
+    const int x0 = xb + tx * MC_ITEMS, z = z0 + tz;
+    const int xl = min(x0, VEC ? d.n2 - 4 : d.n2 - 1);
+    const float* planep = vol + (int64_t)min(z, d.n0 - 1) * d.n1 * d.n2;
+    if (threadIdx.x == 0) s_n = 0;
+    struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+    auto fetch = [&](int l) -> F4 {
+        const float* p = planep + (int64_t)min(y0 + l, d.n1 - 1) * d.n2;
+        F4 q;
+        if constexpr (VEC) q = *reinterpret_cast<const F4*>(p + xl);
+        else {
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (x0 + k < n2) bits |= (row[x0 + k] > thr) ? (1u << k) : 0u;
-    }
-    return bits;
-}
-
-template <int BX>   // x-groups per workgroup (BX * 16 bytes contiguous per voxel row); MC_BLOCK / BX cube rows in y
-__global__ __launch_bounds__(MC_BLOCK) void mc_classify(const float* __restrict__ vol, McDims d, double iso, float thr,
-                                                        uint8_t* __restrict__ codes) {
-    constexpr int BY = MC_BLOCK / BX;
-    __shared__ uint32_t s_queue[MC_BRICK_CUBES];     // cut cubes of the brick: local id | corner pattern << 16
-    __shared__ uint32_t s_count;
-    const int tx = threadIdx.x % BX, ty = threadIdx.x / BX;
-    const int x0 = (blockIdx.x * BX + tx) * MC_ITEMS, y = blockIdx.y * BY + ty, z0 = blockIdx.z * MC_ZRUN;
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    // ---- phase A (uniform): sign patterns, zeroed code bytes, cut cubes into the LDS queue
-    if (x0 < d.c2 && y < d.c1) {
-        const int64_t s1 = d.n2, s0 = (int64_t)d.n1 * d.n2;
-        const float* base = vol + (int64_t)y * s1;
-        // all 2 x (MC_ZRUN + 1) row fetches are issued before the first use: a workgroup lives for one memory round
-        // trip instead of MC_ZRUN of them (planes past the volume are clamped and never used)
-        unsigned bits_a[MC_ZRUN + 1], bits_b[MC_ZRUN + 1];
-        if (x0 + 4 < d.n2) {
-#pragma unroll
-            for (int l = 0; l <= MC_ZRUN; ++l) {
-                const int zz = z0 + l < d.n0 ? z0 + l : d.n0 - 1;
-                bits_a[l] = row_bits<true>(base + (int64_t)zz * s0, x0, d.n2, thr);
-                bits_b[l] = row_bits<true>(base + (int64_t)zz * s0 + s1, x0, d.n2, thr);
-            }
-        } else {   // the last x-group of a row
-#pragma unroll
-            for (int l = 0; l <= MC_ZRUN; ++l) {
-                const int zz = z0 + l < d.n0 ? z0 + l : d.n0 - 1;
-                bits_a[l] = row_bits<false>(base + (int64_t)zz * s0, x0, d.n2, thr);
-                bits_b[l] = row_bits<false>(base + (int64_t)zz * s0 + s1, x0, d.n2, thr);
-            }
+            for (int k = 0; k < 4; ++k) q.v[k] = p[min(xl + k, d.n2 - 1)];
         }
-        const int valid = d.c2 - x0 < MC_ITEMS ? d.c2 - x0 : MC_ITEMS;
+        return q;
+    };
+    auto fetch_halo = [&](int l) -> float {   // the voxel behind the brick (asked for by the last x-group only; everybody loads)
+        const float* p = planep + (int64_t)min(y0 + l, d.n1 - 1) * d.n2;
+        return p[tx == MC_GX - 1 ? min(xb + MC_GX * MC_ITEMS, d.n2 - 1) : min(xl, d.n2 - 1)];
+    };
+    F4 pf[MC_AHEAD];
+    float ph[XHALO ? MC_AHEAD : 1];
 #pragma unroll
-        for (int l = 0; l < MC_ZRUN; ++l) {
-            const int z = z0 + l;
-            if (z < d.c0) {
-                uint8_t* dst = codes + ((int64_t)z * d.c1 + y) * d.c2 + x0;
-                if (valid == MC_ITEMS) reinterpret_cast<McWord*>(dst)->v = 0u;
-                else for (int k = 0; k < valid; ++k) dst[k] = 0;
+    for (int l = 0; l < MC_AHEAD; ++l) {
+        pf[l] = fetch(l);
+        if constexpr (XHALO) ph[l] = fetch_halo(l);
+    }
+    unsigned a_prev = 0, c_prev = 0;
+    auto flush = [&]() {
+        if (threadIdx.x == 0) s_base = atomicAdd(qcount, (unsigned long long)s_n);
+        __syncthreads();
+        const uint32_t cnt = s_n;
+        for (uint32_t e = threadIdx.x; e < cnt; e += MC_STREAM_THREADS) {
+            const uint32_t ent = s_q[e], local = ent & 0x1ffffu;
+            const int k = local % (MC_GX * MC_ITEMS), rz = (local / (MC_GX * MC_ITEMS)) % (MC_GY - 1), ll = local / MC_CUBES_PER_PLANE;
+            const int64_t id = ((int64_t)(z0 + rz) * d.c1 + (y0 + ll)) * d.c2 + xb + k;
+            queue[s_base + e] = (uint64_t)id | ((uint64_t)(ent >> 17) << 40);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+#pragma unroll
+    for (int l = 0; l <= MC_ZRUN; ++l) {                 // voxel row y0 + l of this thread's plane
+        const F4 q = pf[l % MC_AHEAD];
+        float hq = 0.0f;
+        if constexpr (XHALO) hq = ph[l % MC_AHEAD];
+        if (l + MC_AHEAD <= MC_ZRUN) {                   // MC_AHEAD rows in flight
+            pf[l % MC_AHEAD] = fetch(l + MC_AHEAD);
+            if constexpr (XHALO) ph[l % MC_AHEAD] = fetch_halo(l + MC_AHEAD);
+        }
+        const unsigned self4 = (q.v[0] > thr ? 1u : 0u) | (q.v[1] > thr ? 2u : 0u) | (q.v[2] > thr ? 4u : 0u) | (q.v[3] > thr ? 8u : 0u);
+        s_bits[l & 1][tz][tx] = (uint8_t)self4;
+        if (tx == MC_GX - 1) s_bits[l & 1][tz][MC_GX] = (uint8_t)((XHALO && hq > thr) ? 1u : 0u);
+        __syncthreads();
+        // staging buffer -> global queue on a FIXED schedule (a data-dependent test of s_n would race with the appends
+        // of faster threads): two steps append at most 2 * MC_CUBES_PER_PLANE <= MC_STAGE entries
+        if (l > 0 && l % 2 == 0) flush();
+        if (tz < MC_GY - 1) {
+            // corner bits of the cubes (z, y0 + l - 1, x0 + k): rows y (previous step) and y + 1 (this step) of the
+            // planes z (this thread) and z + 1 (the thread row above)
+            const unsigned b_cur = self4 | ((unsigned)(s_bits[l & 1][tz][tx + 1] & 1u) << 4);
+            const unsigned e_cur = (unsigned)(s_bits[l & 1][tz + 1][tx] & 15u) | ((unsigned)(s_bits[l & 1][tz + 1][tx + 1] & 1u) << 4);
+            const int y = y0 + l - 1;
+            if (l > 0 && z < d.c0 && y < d.c1) {
 #pragma unroll
                 for (int k = 0; k < MC_ITEMS; ++k) {
-                    const unsigned a = bits_a[l] >> k, b = bits_b[l] >> k, c = bits_a[l + 1] >> k, e = bits_b[l + 1] >> k;
+                    const unsigned a = a_prev >> k, b = b_cur >> k, c = c_prev >> k, e = e_cur >> k;
                     const unsigned index = (a & 1u) | ((a >> 1 & 1u) << 1) | ((b >> 1 & 1u) << 2) | ((b & 1u) << 3) |
                                            ((c & 1u) << 4) | ((c >> 1 & 1u) << 5) | ((e >> 1 & 1u) << 6) | ((e & 1u) << 7);
-                    if (k < valid && index != 0u && index != 255u)
-                        s_queue[atomicAdd(&s_count, 1u)] = (uint32_t)((threadIdx.x * MC_ZRUN + l) * MC_ITEMS + k) | (index << 16);
+                    if (x0 + k < d.c2 && index != 0u && index != 255u)
+                        s_q[atomicAdd(&s_n, 1u)] = (uint32_t)((l - 1) * MC_CUBES_PER_PLANE + tz * (MC_GX * MC_ITEMS) + tx * MC_ITEMS + k) | (index << 17);
                 }
             }
+            a_prev = b_cur;
+            c_prev = e_cur;
         }
     }
-    __syncthreads();   // also orders the zero stores above before the code bytes below (s_waitcnt vmcnt(0) + s_barrier)
-    // ---- phase B (dense): MC33 face / interior tests and the created-vertex count of the queued cubes
-    const uint32_t queued = s_count;
-    for (uint32_t q = threadIdx.x; q < queued; q += MC_BLOCK) {
-        const uint32_t ent = s_queue[q];
-        const int local = (int)(ent & 0xffffu), index = (int)(ent >> 16);
-        const int k = local % MC_ITEMS, l = (local / MC_ITEMS) % MC_ZRUN, t = local / (MC_ITEMS * MC_ZRUN);
-        const int x = (blockIdx.x * BX + t % BX) * MC_ITEMS + k, yy = blockIdx.y * BY + t / BX, z = z0 + l;
+    __syncthreads();
+    flush();
+}
+static_assert(MC_ZRUN * MC_CUBES_PER_PLANE <= (1 << 17) && 2 * MC_CUBES_PER_PLANE <= MC_STAGE, "local cube id is 17 bits");
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_classify_cut(const float* __restrict__ vol, McDims d, double iso,
+                                                            const uint64_t* __restrict__ queue,
+                                                            const unsigned long long* __restrict__ qcount,
+                                                            uint8_t* __restrict__ codes) {
+    const int64_t n = (int64_t)*qcount;
+    for (int64_t q = (int64_t)blockIdx.x * MC_BLOCK + threadIdx.x; q < n; q += (int64_t)gridDim.x * MC_BLOCK) {
+        const uint64_t ent = queue[q];
+        const int64_t id = (int64_t)(ent & ((uint64_t(1) << 40) - 1));
+        const int index = (int)(ent >> 40);
+        int z, y, x;
+        cube_coords(d, id, z, y, x);
         Cube c;
-        load_cube(vol, d, z, yy, x, iso, c);
+        load_cube(vol, d, z, y, x, iso, c);
         int off, nt;
         select_tiling(c, index, off, nt);
-        if (nt > 0) codes[((int64_t)z * d.c1 + yy) * d.c2 + x] = (uint8_t)pack_code(nt, count_created(off, nt, z, yy, x));
+        if (nt > 0) codes[id] = (uint8_t)pack_code(nt, count_created(off, nt, z, y, x));
     }
 }
+
 
 // per-tile (1024 cubes in scan order) sums of created vertices / triangles / active cubes, from the code bytes:
 // one wavefront per tile, 16 cubes (one 16-byte load) per lane -- a workgroup per tile is dispatch-bound (91 us)
@@ -784,15 +831,27 @@ int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, doubl
     NM_REQUIRE(d.cubes < (int64_t(1) << 40), "volume too large");
     McWorkspace ws;
     carve(d, static_cast<char*>(d_workspace), &ws);
-    constexpr int bx = 32, by = MC_BLOCK / bx;   // 64 / 128 x-groups per workgroup measured the same
-    const dim3 bricks((unsigned)(((d.c2 + MC_ITEMS - 1) / MC_ITEMS + bx - 1) / bx), (unsigned)((d.c1 + by - 1) / by),
-                      (unsigned)((d.c0 + MC_ZRUN - 1) / MC_ZRUN));
+    const dim3 bricks((unsigned)((d.c2 + MC_GX * MC_ITEMS - 1) / (MC_GX * MC_ITEMS)), (unsigned)((d.c0 + MC_GY - 2) / (MC_GY - 1)),
+                      (unsigned)((d.c1 + MC_ZRUN - 1) / MC_ZRUN));
     NM_REQUIRE(bricks.y <= 65535u && bricks.z <= 65535u, "volume too large");
-    // the (<= 3) code bytes behind the last cube share a dword with real cubes: keep them zero for the word readers
-    NM_HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t*>(ws.codes) + (d.cubes & ~int64_t(3)), 0, 8, stream));
+    // code bytes: zero everywhere (incl. the <= 3 bytes behind the last cube that share a dword with real cubes);
+    // the cut cubes' bytes are written by mc_classify_cut
+    NM_HIP_CHECK(hipMemsetAsync(ws.codes, 0, (((size_t)d.cubes + 3) & ~size_t(3)) + 8, stream));
+    NM_HIP_CHECK(hipMemsetAsync(ws.totals, 0, 256, stream));
     float thr = (float)iso;                        // largest float <= iso (exact equivalence of the sign test)
     if ((double)thr > iso) thr = nextafterf(thr, -INFINITY);
-    hipLaunchKernelGGL(mc_classify<bx>, bricks, dim3(MC_BLOCK), 0, stream, d_volume, d, iso, thr,
+    // the queue of cut cubes (worst case: every cube) lives in the first two edge->vertex volumes, which nothing
+    // touches before nm_mc_emit
+    uint64_t* queue = reinterpret_cast<uint64_t*>(ws.edge[0]);
+    unsigned long long* qcount = reinterpret_cast<unsigned long long*>(ws.totals + 8);
+    const bool vec = n2 % 4 == 0, xhalo = bricks.x > 1;
+#define NM_STREAM(V, X) hipLaunchKernelGGL((mc_classify_stream<V, X>), bricks, dim3(MC_STREAM_THREADS), 0, stream, d_volume, d, thr, queue, qcount)
+    if (vec && !xhalo) NM_STREAM(true, false);
+    else if (vec) NM_STREAM(true, true);
+    else if (!xhalo) NM_STREAM(false, false);
+    else NM_STREAM(false, true);
+#undef NM_STREAM
+    hipLaunchKernelGGL(mc_classify_cut, dim3(2048), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, queue, qcount,
                        reinterpret_cast<uint8_t*>(ws.codes));
     hipLaunchKernelGGL(mc_tile_sums, dim3((unsigned)((ws.tiles + 3) / 4)), dim3(256), 0, stream, d, ws.codes, ws.tiles,
                        ws.tile_sums);
