@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 GO = os.path.join(ROOT, "gpurun_out")
 PR = os.path.join(ROOT, "profiles")
 KERNEL = "mlp_kernel"
@@ -21,7 +21,7 @@ def mean(v):
     return sum(v) / len(v) if v else 0.0
 
 
-summary = {"tag": tag, "kernel": "nm::mlp_kernel<256,10,4,8>", "notes": []}
+summary = {"tag": tag, "kernel": "nm::mlp_kernel3<256,10,4,8,8,1> (round 1: nm::mlp_kernel<256,10,4,8,...>)", "notes": []}
 
 # ---- kernel-trace --stats
 stats = os.path.join(GO, f"prof_{tag}", "bench_kernel_stats.csv")
@@ -54,6 +54,7 @@ if os.path.isdir(pmc_dir):
         f = os.path.join(pmc_dir, d, "pmc_counter_collection.csv")
         if not os.path.exists(f):
             continue
+        os.makedirs(os.path.join(PR, f"{tag}_raw"), exist_ok=True)
         keep = []
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Kernel_Name"] and int(r["Grid_Size"]) == 524288:
@@ -86,7 +87,7 @@ if counters:
         "wait_frac_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
     }
     summary["notes"].append("PMC means are over the 18 full-size launches (9 coarse R x 64 + 9 fine R x 192 samples, "
-                            "R = 65536 rays) of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`, one counter group "
+                            "R = 65536 rays) of `bench.py --headline-only --steps 1 --warmup 0`, one counter group "
                             "per rocprofv3 run (kernel-trace only, no other trace domains).")
     json.dump({"hbm_bytes_per_launch": fetch_b + write_b, "hbm_read_bytes_per_launch": fetch_b,
                "hbm_write_bytes_per_launch": write_b, "mfma_util": summary["pmc"]["mfma_util"],
