@@ -65,6 +65,15 @@ typedef struct nm_mlp nm_mlp;
 /* Packs the weights into the MFMA operand stream and uploads them to `device`.
  * Unsupported (hidden_size, num_encoding_fn_*) combinations fail with a message. */
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
+
+/* Arithmetic of the GEMMs.  NM_PREC_F32 (default, what nm_mlp_create builds): fp32 MFMA, the reference's fp32 arithmetic
+ * up to summation order.  NM_PREC_BF16X3 (opt-in; 256-wide networks): every product is emulated by six bf16 MFMA
+ * products of a three-way split of both operands with fp32 accumulation -- fp32-class error (dropped terms <= 2^-24 of
+ * a product) at ~2.3x the throughput, but not bit-comparable with the fp32 path; inference entry points only
+ * (nm_mlp_forward_train / nm_mlp_backward refuse such a handle). */
+enum { NM_PREC_F32 = 0, NM_PREC_BF16X3 = 1 };
+int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* host_weights, int device, int precision, nm_mlp** out);
+int nm_mlp_precision(const nm_mlp* mlp);
 void nm_mlp_destroy(nm_mlp* mlp);
 /* Which tuning variant of the kernel the handle was bound to (0 = production; NM_MLP_VARIANT selects others
  * for A/B measurements) and its waves per workgroup. */

@@ -62,6 +62,8 @@ SIGNATURES = {
     "nm_abi_version": (C.c_int, []),
     "nm_device_count": (C.c_int, []),
     "nm_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpWeights), C.c_int, C.POINTER(c_void_p)]),
+    "nm_mlp_create_ex": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpWeights), C.c_int, C.c_int, C.POINTER(c_void_p)]),
+    "nm_mlp_precision": (C.c_int, [c_void_p]),
     "nm_mlp_destroy": (None, [c_void_p]),
     "nm_mlp_kernel_variant": (C.c_int, [c_void_p, C.POINTER(C.c_int)]),
     "nm_mlp_flops_per_sample": (C.c_int64, [c_void_p, C.c_int]),

@@ -12,6 +12,7 @@ static thread_local std::string g_error;
 void set_error(const std::string& msg) { g_error = msg; }
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD);
+bool has_b3_kernel(int H, int FX, int FD);
 int mlp_plan_info(const MlpPlan* p, int* nw);
 int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream);
 
@@ -62,6 +63,69 @@ static void pack_gemm(std::vector<int32_t>& out, int tensor, int ld, int rows, i
                 }
 }
 
+// ---- bf16x3 stream (mlp_device_b3.h): per (k-block m, tile nt) unit the fp32 image [lane][j = 0..7] =
+// W[16 nt + (l & 15)][column of slot (m, l >> 4, j)]; a device kernel splits it into the three bf16 planes.
+using SlotCols = std::array<int, 32>;   // source column of slot 8 g + j of one k-block (-1 = zero)
+
+static void hidden_blocks(std::vector<SlotCols>& out, int width, int col_offset) {
+    for (int m = 0; m < width / 32; ++m) {
+        SlotCols c;
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j) c[8 * g + j] = col_offset + 16 * (2 * m + j / 4) + 4 * g + (j % 4);
+        out.push_back(c);
+    }
+}
+
+// slots 2a, 2a+1 = sin, cos of argument a < 3F (reference columns base + a, base + 3F + a); then the identity coordinates
+static void encoding_blocks(std::vector<SlotCols>& out, int F, bool include_input, int col_offset, int blocks) {
+    const int base = col_offset + (include_input ? 3 : 0);
+    for (int m = 0; m < blocks; ++m) {
+        SlotCols c;
+        for (int q = 0; q < 32; ++q) {
+            const int s = 32 * m + q;
+            if (s < 6 * F) c[q] = base + ((s & 1) ? 3 * F : 0) + s / 2;
+            else if (include_input && s - 6 * F < 3) c[q] = col_offset + (s - 6 * F);
+            else c[q] = -1;
+        }
+        out.push_back(c);
+    }
+}
+
+static void pack_gemm_b3(std::vector<int32_t>& out, int tensor, int ld, int rows, int ntiles, const std::vector<SlotCols>& blocks) {
+    for (const SlotCols& c : blocks)
+        for (int nt = 0; nt < ntiles; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 16 * nt + (l & 15), k = c[8 * (l >> 4) + j];
+                    out.push_back((n < rows && k >= 0) ? (int32_t)((tensor << 24) | (int32_t)((int64_t)n * ld + k)) : -1);
+                }
+}
+
+// fp32 image [unit][lane][8] -> three planes of packed bf16 [unit][plane][lane][8]: x1 = bf16(x), x2 = bf16(x - x1), ...
+__global__ void split_b3_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int64_t units) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (unit, lane)
+    if (t >= units * 64) return;
+    const int64_t unit = t >> 6;
+    const int lane = (int)(t & 63);
+    const float* v = src + t * 8;
+    uint32_t p[3][4];
+    for (int q = 0; q < 4; ++q) {
+        const float x = v[2 * q], y = v[2 * q + 1];
+        auto pack = [](float a, float b) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            const f2 f = {a, b};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2));
+        };
+        p[0][q] = pack(x, y);
+        const float rx = x - __uint_as_float(p[0][q] << 16), ry = y - __uint_as_float(p[0][q] & 0xffff0000u);
+        p[1][q] = pack(rx, ry);
+        const float sx = rx - __uint_as_float(p[1][q] << 16), sy = ry - __uint_as_float(p[1][q] & 0xffff0000u);
+        p[2][q] = pack(sx, sy);
+    }
+    for (int k = 0; k < 3; ++k) dst[(unit * 3 + k) * 64 + lane] = uint4{p[k][0], p[k][1], p[k][2], p[k][3]};
+}
+
 static void pack_range(std::vector<int32_t>& out, int tensor, int count) {
     for (int i = 0; i < count; ++i) out.push_back((tensor << 24) | i);
 }
@@ -100,6 +164,13 @@ static int launch_gather(const nm_mlp* m, const WeightPtrs& ptrs, hipStream_t st
     const int64_t n = (int64_t)m->blob_floats;
     hipLaunchKernelGGL(gather_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m->d_index, ptrs,
                        static_cast<float*>(m->d_blob), n);
+    if (m->precision == NM_PREC_BF16X3) {
+        const int64_t nb = (int64_t)m->b3_units * 512;
+        hipLaunchKernelGGL(gather_parameters, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, m->d_index_b3, ptrs,
+                           m->d_tmp_b3, nb);
+        hipLaunchKernelGGL(split_b3_kernel, dim3((unsigned)((m->b3_units * 64 + 255) / 256)), dim3(256), 0, stream,
+                           m->d_tmp_b3, static_cast<uint4*>(m->d_stream_b3), (int64_t)m->b3_units);
+    }
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -171,7 +242,14 @@ int nm_mlp_profile_read(int64_t* launches, double* total_ms, double* total_flops
 }
 
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, nm_mlp** out) {
+    return nm_mlp_create_ex(desc, w, device, NM_PREC_F32, out);
+}
+
+int nm_mlp_precision(const nm_mlp* m) { return m ? m->precision : -1; }
+
+int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, int precision, nm_mlp** out) {
     NM_REQUIRE(desc && w && out, "null argument");
+    NM_REQUIRE(precision == NM_PREC_F32 || precision == NM_PREC_BF16X3, "unknown precision");
     const nm_mlp_desc& d = *desc;
     NM_REQUIRE(d.use_viewdirs == 1, "only use_viewdirs=True networks are implemented on the HIP path");
     NM_REQUIRE(d.num_layers >= 2 && d.num_layers <= 32, "num_layers out of range");
@@ -241,11 +319,39 @@ int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, 
     index.resize(index.size() + 1024, -1);
     pad_to(index, 64);
 
+    // opt-in bf16x3 stream: the same stages as units of (k-block, tile)
+    std::vector<int32_t> index_b3;
+    if (precision == NM_PREC_BF16X3) {
+        if (!has_b3_kernel(H, FX, FD)) {
+            set_error("precision bf16x3 is instantiated for hidden_size 256 with 6 or 10 xyz / 4 direction frequencies only");
+            return 3;
+        }
+        std::vector<SlotCols> bx, bh, bskip, bdir;
+        encoding_blocks(bx, FX, d.include_input_xyz != 0, 0, 2);
+        hidden_blocks(bh, H, 0);
+        encoding_blocks(bskip, FX, d.include_input_xyz != 0, H, 2);
+        hidden_blocks(bdir, H, 0);
+        encoding_blocks(bdir, FD, d.include_input_dir != 0, H, 1);
+        pack_gemm_b3(index_b3, T_L1W, dx, H, NT, bx);
+        for (int i = 0; i < L - 1; ++i) {
+            const bool skip = is_skip(d, i);
+            const int ld = H + (skip ? dx : 0);
+            pack_gemm_b3(index_b3, T_XYZ0 + 2 * i, ld, H, NT, bh);
+            if (skip) pack_gemm_b3(index_b3, T_XYZ0 + 2 * i, ld, H, NT, bskip);
+        }
+        pack_gemm_b3(index_b3, T_FEATW, H, H, NT, bh);
+        pack_gemm_b3(index_b3, T_DIRW, H + dd, H / 2, NTD, bdir);
+        index_b3.resize(index_b3.size() + 16 * 512, -1);      // DMA granularity / chunk padding
+    }
+
     nm_mlp* m = new nm_mlp();
     std::memset(m, 0, sizeof(*m));
     m->desc = d;
     m->device = device;
     m->plan = plan;
+    m->precision = precision;
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
     NM_HIP_CHECK(hipSetDevice(device));
     hipDeviceProp_t prop;
     NM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -255,6 +361,13 @@ int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, 
     NM_HIP_CHECK(hipMalloc(&m->d_blob, m->blob_bytes));
     NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->d_index), m->blob_bytes));
     NM_HIP_CHECK(hipMemcpy(m->d_index, index.data(), m->blob_bytes, hipMemcpyHostToDevice));
+    if (precision == NM_PREC_BF16X3) {
+        m->b3_units = index_b3.size() / 512;
+        NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->d_index_b3), index_b3.size() * 4));
+        NM_HIP_CHECK(hipMemcpy(m->d_index_b3, index_b3.data(), index_b3.size() * 4, hipMemcpyHostToDevice));
+        NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->d_tmp_b3), index_b3.size() * 4));
+        NM_HIP_CHECK(hipMalloc(&m->d_stream_b3, m->b3_units * 3072));
+    }
     const float* base = static_cast<const float*>(m->d_blob);
     MlpArgs& a = m->base;
     a.wstream = reinterpret_cast<const char*>(base);
@@ -294,6 +407,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, 
     int rc = launch_gather(m, ptrs, nullptr);
     if (rc == 0 && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("parameter gather failed"); rc = 1; }
     (void)hipFree(d_flat);
+    if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);   // leave the caller's device current
     if (rc) { nm_mlp_destroy(m); return rc; }
     *out = m;
     return 0;
@@ -314,6 +428,9 @@ void nm_mlp_destroy(nm_mlp* m) {
     if (!m) return;
     if (m->d_blob) (void)hipFree(m->d_blob);
     if (m->d_index) (void)hipFree(m->d_index);
+    if (m->d_index_b3) (void)hipFree(m->d_index_b3);
+    if (m->d_tmp_b3) (void)hipFree(m->d_tmp_b3);
+    if (m->d_stream_b3) (void)hipFree(m->d_stream_b3);
     delete m;
 }
 

@@ -31,6 +31,7 @@
 #include "nm_internal.h"
 #include "mlp_device.h"
 #include "mlp_device_r3.h"
+#include "mlp_device_b3.h"
 
 namespace nm {
 
@@ -94,6 +95,22 @@ static const MlpPlan g_plans[] = {
 #endif
 };
 
+// opt-in bf16x3 precision (mlp_device_b3.h)
+struct B3Plan {
+    int H, FX, FD;
+    void (*kernel)(const MlpArgs, const int, const int);
+};
+static const B3Plan g_b3_plans[] = {
+    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>},
+    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>},
+};
+static const B3Plan* find_b3_plan(int H, int FX, int FD) {
+    for (const B3Plan& p : g_b3_plans)
+        if (p.H == H && p.FX == FX && p.FD == FD) return &p;
+    return nullptr;
+}
+bool has_b3_kernel(int H, int FX, int FD) { return find_b3_plan(H, FX, FD) != nullptr; }
+
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
     int want = 0;
 #ifdef NM_ABLATIONS
@@ -117,6 +134,24 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     const MlpPlan* p = m->plan;
     if (args.n <= 0) return 0;
     const int L = m->desc.num_layers, H = m->desc.hidden_size;
+    if (m->precision == NM_PREC_BF16X3) {
+        const B3Plan* b = find_b3_plan(H, m->desc.num_encoding_fn_xyz, m->desc.num_encoding_fn_dir);
+        NM_REQUIRE(b && m->d_stream_b3, "no bf16x3 kernel for this network");
+        const int lds_bytes = 3 * B3_SLOT + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255);
+        NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (bf16x3 ring + bias cache): too many layers");
+        NM_HIP_CHECK(hipFuncSetAttribute((const void*)b->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        MlpArgs a = args;
+        a.wstream = static_cast<const char*>(m->d_stream_b3);
+        const int64_t wg_iters = (a.n + 127) / 128;
+        int64_t grid = wg_iters < (int64_t)m->num_cus * 4 ? wg_iters : (int64_t)m->num_cus * 4;
+        if (wg_iters > grid) {
+            const int64_t rounds = (wg_iters + grid - 1) / grid;
+            grid = (wg_iters + rounds - 1) / rounds;
+        }
+        hipLaunchKernelGGL(b->kernel, dim3((unsigned)grid), dim3(512), lds_bytes, stream, a, L, density_only);
+        NM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255) : 0);
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     static int attr_bytes[sizeof(g_plans) / sizeof(g_plans[0])] = {};

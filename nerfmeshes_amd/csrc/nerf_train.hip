@@ -250,6 +250,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
                          int64_t rays, int32_t samples, const nm_mlp_tape* tape, float* d_radiance, void* stream) {
     NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
     NM_REQUIRE(tape->d_h && tape->d_feat && tape->d_v && tape->d_mask_h && tape->d_mask_v, "incomplete tape");
+    NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
     const nm_mlp_desc& d = m->desc;
     const TrainPlan* plan = nullptr;
     for (const TrainPlan& p : g_train_plans)

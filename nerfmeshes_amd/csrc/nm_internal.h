@@ -163,4 +163,10 @@ struct nm_mlp {
     size_t blob_floats;
     int64_t flops_full, flops_density;
     int num_cus;
+    // opt-in "bf16x3" precision (mlp_device_b3.h): the same parameters as three bf16 planes per (k-block, tile) unit
+    int precision;           // NM_PREC_F32 | NM_PREC_BF16X3
+    void* d_stream_b3;       // units x 3 KiB
+    float* d_tmp_b3;         // gathered fp32 image [unit][lane][8] the planes are split from
+    int32_t* d_index_b3;
+    size_t b3_units;
 };

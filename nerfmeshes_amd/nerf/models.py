@@ -34,6 +34,8 @@ class FlexibleNeRFModel(torch.nn.Module):
                           use_viewdirs=use_viewdirs)
         self._hip = None
         self._hip_key = None
+        # arithmetic of the inference kernels: "f32" (default) or the opt-in "bf16x3" (hip_ops.HipMLP); training is fp32
+        self.precision = "f32"
 
     def _is_skip(self, i):
         return i % self.skip_step == 0 and i > 0 and i != self.num_layers - 1
@@ -47,8 +49,9 @@ class FlexibleNeRFModel(torch.nn.Module):
             raise hip_ops._lib.HipLibraryError(
                 "FlexibleNeRFModel lives on %s: move it to the MI355X (.to('cuda')); there is no CPU path" % dev)
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._hip is None or self._hip.device != dev:
-            self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev)
+        precision = "f32" if self.needs_grad() else getattr(self, "precision", "f32")
+        if self._hip is None or self._hip.device != dev or self._hip.precision != precision:
+            self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev, precision=precision)
         elif key != self._hip_key:
             train_ops.refresh(self._hip, dict(self.named_parameters()))
         self._hip_key = key

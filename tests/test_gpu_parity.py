@@ -460,3 +460,76 @@ def test_render_sweep_vs_oracle(ops, rays, nc, nf, kw):
         # (same noise floor as the reference against itself, test_reference_self_noise)
         assert (err[good] <= 2e-3).mean() >= 0.995 and err.max() < 5e-2 and np.median(err) < 1e-5, \
             (err.max(), np.median(err), (err > 2e-3).sum())
+
+
+# ---- opt-in bf16x3 precision (mlp_device_b3.h): fp32-class accuracy, its own parity budget ---------------------------
+def _b3_pair(ops):
+    kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    w = S.make_scene_weights(**kw)
+    return kw, w, ops.HipMLP(w, kw, "cuda"), ops.HipMLP(w, kw, "cuda", precision="bf16x3")
+
+
+def test_bf16x3_sample_points_error_class(ops):
+    """Six bf16 products of three-way operand splits, fp32 accumulation: the error against an fp64 evaluation of the
+    network must stay in the class of the fp32 path's own (<= 2x), on the sigma-gain-1e5 scene (cancellation-prone)."""
+    kw, w, f32, b3 = _b3_pair(ops)
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(20000, 3, generator=g) * 2 - 1) * 2.0
+    dirs = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1)
+    w64 = {k: torch.as_tensor(v).double() for k, v in w.items()}
+    ref = O.mlp_forward(w64, O.MLPSpec(**kw), pts.double(), dirs.double(), keep_graph=True)
+    scale = float(ref[:, 3].abs().max()) + 1.0
+    err = {}
+    for name, m in (("f32", f32), ("b3", b3)):
+        got = m.sample_points(pts.cuda(), dirs.cuda()).cpu().double()
+        err[name] = (float((got[:, :3] - ref[:, :3]).abs().max()), float((got[:, 3] - ref[:, 3]).abs().max()) / scale)
+    assert err["b3"][0] <= max(2 * err["f32"][0], 2e-7) and err["b3"][1] <= max(2 * err["f32"][1], 3e-6), err
+    # density-only path == the full path's sigma, bit for bit (same kernel, colour branch skipped)
+    ax = torch.linspace(-1.2, 1.2, 24)
+    full = b3.grid_query(ax, ax, ax, density_only=False)
+    assert torch.equal(full[:, 3], b3.grid_query(ax, ax, ax, density_only=True))
+
+
+def test_bf16x3_render_parity_and_mesh_topology(ops):
+    """The mode's parity budget: 1e-4 dB on the 8192-ray reference fixture (all rays); density grid within 2e-5 of the
+    fp32 path's (relative to the sigma scale); mesh topology equal up to isolated cubes."""
+    kw, w, f32, b3 = _b3_pair(ops)
+    g = load_golden("render_lego_view_8k")
+    o, d = ops.ray_bundle(g["pose"], 800, 800, S.LEGO_FOCAL_800)
+    d = d[torch.from_numpy(g["ray_index"]).cuda()].contiguous()
+    _, fb = ops.render_rays(b3, b3, o[None], d, torch.tensor([2.0]), torch.tensor([6.0]), torch.linspace(0, 1, 64),
+                            torch.linspace(0, 1, 128))
+    par = parity.psnr_parity(fb["rgb_map"].cpu(), g["fine.rgb_map"], chunk=2048)
+    print("bf16x3:", par)
+    assert par["abs_dpsnr_db"] <= 1e-4 and par["rays_over_1e-4"] <= 0.005 * par["rays"], par
+    res = 128
+    ax = torch.linspace(-1.2, 1.2, res)
+    g32 = f32.grid_query(ax, ax, ax, density_only=True).view(res, res, res)
+    g3 = b3.grid_query(ax, ax, ax, density_only=True).view(res, res, res)
+    assert float((g32 - g3).abs().max()) <= 2e-5 * (float(g32.abs().max()) + 1.0)
+    # Mesh topology is a discontinuous function of the grid: a voxel within ~3e-6 * |sigma|max of the iso level, or an
+    # MC33 face / interior test near its decision boundary, may resolve differently -- exactly as between the fp32 path
+    # and the CPU reference, whose sigma differ by the same amount.  Budget of the mode: isolated cubes only.
+    flips = int(((g32 > 32.0) != (g3 > 32.0)).sum())
+    a, b = ops.marching_cubes(g32, 32.0), ops.marching_cubes(g3, 32.0)
+    dv, df = abs(a[0].shape[0] - b[0].shape[0]), abs(a[1].shape[0] - b[1].shape[0])
+    differing = int((a[1] != b[1]).any(-1).sum()) if a[1].shape == b[1].shape else None
+    print(f"bf16x3 mesh at {res}^3: sign flips at iso {flips}, |dV| {dv}, |dF| {df}, differing faces {differing} of {a[1].shape[0]}")
+    assert flips <= 1e-5 * res ** 3 and dv <= 1e-3 * a[0].shape[0] and df <= 1e-3 * a[1].shape[0]
+
+
+def test_bf16x3_is_inference_only_and_follows_the_module(ops):
+    from nerfmeshes_amd import train_ops as T
+    from nerfmeshes_amd.nerf import FlexibleNeRFModel
+    kw, w, f32, b3 = _b3_pair(ops)
+    t = torch.rand(4, 8).sort(-1).values.cuda() + 2.0
+    with pytest.raises(Exception):
+        T.forward_train(b3, torch.zeros(1, 3).cuda(), torch.ones(4, 3).cuda(), t)
+    with pytest.raises(Exception):
+        ops.HipMLP(S.make_mlp_weights(1, hidden_size=128), dict(kw, hidden_size=128), "cuda", precision="bf16x3")
+    net = FlexibleNeRFModel(**kw).cuda().eval()
+    net.precision = "bf16x3"
+    with torch.no_grad():
+        out = net(torch.rand(100, 3).cuda(), torch.rand(100, 3).cuda())
+        assert net.hip().precision == "bf16x3" and out.shape == (100, 4)
+    assert net.hip().precision == "f32"        # with autograd on, a forward always runs the (differentiable) fp32 kernels
