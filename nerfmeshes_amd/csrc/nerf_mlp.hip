@@ -79,6 +79,7 @@ static const MlpPlan g_plans[] = {
     make_plan<256, 10, 4, 8, 8, true, false, true, false, 8>(3),     // encodings recomputed at the skip layer: ~135
     make_plan<256, 10, 4, 8, 8, true, true, false, false, 8>(4),     // prefetch only, biases from L2: 138.3
     make_plan<256, 10, 4, 4, 8, true, true, true, false, 8>(5),      // 4-wave workgroups, two per CU (decoupled barriers): 132.3
+    make_plan<256, 10, 4, 4, 8, true, true, true>(6),                // ... with the scalar-addressed DMA: 143.4 (= variant 9: decoupling buys nothing)
     // timing-only ablations (WRONG results): 1 = no sincos, 2 = no barrier, 4 = no weight DMA
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 1>(11),
     make_plan<256, 10, 4, 8, 8, true, true, true, false, 2>(12),
@@ -130,9 +131,21 @@ int mlp_plan_info(const MlpPlan* p, int* nw) {
     return p->variant;
 }
 
+// The handle's device must be current for the launch (the stream belongs to it): a model on cuda:1 used from a process
+// whose current device is cuda:0 is switched to for the call and switched back.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int want) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream) {
     const MlpPlan* p = m->plan;
     if (args.n <= 0) return 0;
+    DeviceGuard guard(m->device);
     const int L = m->desc.num_layers, H = m->desc.hidden_size;
     if (m->precision == NM_PREC_BF16X3) {
         const B3Plan* b = find_b3_plan(H, m->desc.num_encoding_fn_xyz, m->desc.num_encoding_fn_dir);
@@ -154,11 +167,12 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     }
     const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255) : 0);
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
-    static int attr_bytes[sizeof(g_plans) / sizeof(g_plans[0])] = {};
-    const int idx = (int)(p - g_plans);
-    if (attr_bytes[idx] < lds_bytes) {
+    // the dynamic-LDS attribute is per device: tracked per (device, plan)
+    static int attr_bytes[64][sizeof(g_plans) / sizeof(g_plans[0])] = {};
+    const int idx = (int)(p - g_plans), dev = (m->device >= 0 && m->device < 64) ? m->device : 0;
+    if (attr_bytes[dev][idx] < lds_bytes) {
         NM_HIP_CHECK(hipFuncSetAttribute((const void*)p->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_bytes[idx] = lds_bytes;
+        attr_bytes[dev][idx] = lds_bytes;
     }
     const int64_t wg_iters = (args.n + p->wg_samples - 1) / p->wg_samples;
     const int64_t resident = (int64_t)m->num_cus * p->wg_per_cu;   // workgroups co-resident on the chip
