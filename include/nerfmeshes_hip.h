@@ -262,6 +262,13 @@ int nm_weight_grad(int num_cus, const float* d_delta, int32_t out_features, cons
                    int32_t in_features, int64_t n, void* d_workspace, float* d_dw, int32_t dw_ld, int32_t dw_col0,
                    float* d_dbias, void* stream);
 
+/* The 4-row head gradients (fc_alpha: row 3 of dlast^T h[L-1]; fc_rgb: rows 0..2 of dlast^T v -- models.py:74-78's two
+ * Linear layers share the delta dlast (n, 4)): d_dw[r * in_features + k] = sum_n dlast[n][r] * act[n][k], d_dbias[r] =
+ * sum_n dlast[n][r] (may be NULL).  in_features 64, 128 or 256.  HBM-bound VALU kernel + the order-fixed partial reduction. */
+int64_t nm_head_grad_workspace_bytes(int32_t in_features);
+int nm_head_grad(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace,
+                 float* d_dw, float* d_dbias, void* stream);
+
 /* RaySampleInterval.forward's stratified jitter (src/nerf/modules.py:171-184): d_rand (rays,samples) in [0,1). */
 int nm_perturb_intervals(const float* d_t, const float* d_rand, int64_t rays, int32_t samples, float* d_t_out,
                          void* stream);

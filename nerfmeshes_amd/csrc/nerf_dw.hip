@@ -208,6 +208,99 @@ __global__ void dw_reduce_kernel(const float* __restrict__ partial, const float*
     *dst = s;
 }
 
+
+// ---- the 4-row heads --------------------------------------------------------------------------------------------
+// fc_alpha (1 row) and fc_rgb (3 rows) share the delta dlast (n, 4): out[r][k] = sum_n dlast[n][r] * act[n][k] for
+// act = h[L-1] (fc_alpha takes row 3) and act = v (fc_rgb takes rows 0..2).  An MFMA tile would waste 12 of its 16
+// rows and the product is HBM-bound anyway (act is read once: 2 FLOP / B), so this is a VALU kernel: a workgroup owns a
+// contiguous slice of samples, a thread four columns (one 16-byte load per row; a 256-wide row is one wavefront-wide
+// 1 KiB load, dlast[n] a broadcast 16-byte load), 16 fp32 accumulators.  The slice partials go through the same
+// order-fixed second pass as the MFMA kernel's (head_reduce_kernel: parts in index order -> deterministic).
+template <int K>
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ dlast, const float* __restrict__ act,
+                                                        int64_t n, int rows_per_part, float* __restrict__ partial,
+                                                        float* __restrict__ partial_bias) {
+    constexpr int TPR = K / 4, RPP = 256 / TPR;            // threads per row, rows per pass
+    __shared__ float4 red[RPP][4][TPR];
+    __shared__ float4 bred[RPP];
+    const int c4 = threadIdx.x % TPR, rg = threadIdx.x / TPR;
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_part;
+    const int64_t n1 = n0 + rows_per_part < n ? n0 + rows_per_part : n;
+    const float4* a4 = reinterpret_cast<const float4*>(act);
+    const float4* d4 = reinterpret_cast<const float4*>(dlast);
+    float4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fma_row = [&](const float4& x, const float4& d) {
+        acc[0].x += d.x * x.x; acc[0].y += d.x * x.y; acc[0].z += d.x * x.z; acc[0].w += d.x * x.w;
+        acc[1].x += d.y * x.x; acc[1].y += d.y * x.y; acc[1].z += d.y * x.z; acc[1].w += d.y * x.w;
+        acc[2].x += d.z * x.x; acc[2].y += d.z * x.y; acc[2].z += d.z * x.z; acc[2].w += d.z * x.w;
+        acc[3].x += d.w * x.x; acc[3].y += d.w * x.y; acc[3].z += d.w * x.z; acc[3].w += d.w * x.w;
+        bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
+    };
+    int64_t i = n0 + rg;
+    for (; i + 7 * RPP < n1; i += 8 * RPP) {
+        float4 x[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = a4[(i + u * RPP) * TPR + c4]; d[u] = d4[i + u * RPP]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fma_row(x[u], d[u]);
+    }
+    for (; i < n1; i += RPP) fma_row(a4[i * TPR + c4], d4[i]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[rg][r][c4] = acc[r];
+    if (c4 == 0) bred[rg] = bs;
+    __syncthreads();
+    if (threadIdx.x < 4 * TPR) {                           // (row r, column quad c): row groups added in index order
+        const int r = threadIdx.x / TPR, c = threadIdx.x % TPR;
+        float4 s = red[0][r][c];
+        for (int q = 1; q < RPP; ++q) { const float4 v = red[q][r][c]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4*>(partial)[((int64_t)blockIdx.x * 4 + r) * TPR + c] = s;
+    }
+    if (threadIdx.x == 0) {
+        float4 s = bred[0];
+        for (int q = 1; q < RPP; ++q) { const float4 v = bred[q]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4*>(partial_bias)[blockIdx.x] = s;
+    }
+}
+
+// out[e] = sum_p partial[p][e], e < elems (+ the 4 bias sums behind them): 4 part-groups per element added up
+// sequentially (16 loads in flight), then the 4 group sums in index order.
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ partial_bias, int parts, int elems,
+                                                          float* __restrict__ out, float* __restrict__ out_bias) {
+    __shared__ float grp[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+    const int per = (parts + 3) / 4;
+    const int p0 = pg * per, p1 = p0 + per < parts ? p0 + per : parts;
+    const float* p = nullptr;
+    int64_t stride = 0;
+    if (e < elems) { p = partial + e; stride = elems; }
+    else if (e < elems + 4) { p = partial_bias + (e - elems); stride = 4; }
+    float s = 0.0f;
+    if (p) {
+        int k = p0;
+        for (; k + 16 <= p1; k += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(k + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; k < p1; ++k) s += p[k * stride];
+    }
+    grp[pg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (pg == 0 && p) {
+        const float t = ((grp[0][threadIdx.x] + grp[1][threadIdx.x]) + grp[2][threadIdx.x]) + grp[3][threadIdx.x];
+        if (e < elems) out[e] = t;
+        else if (out_bias) out_bias[e - elems] = t;
+    }
+}
+
+constexpr int HEAD_MAX_PARTS = 512;
+
 struct DwPlan {
     int ab, bb, ksplit;
     void (*kernel)(const DwArgs);
@@ -258,6 +351,37 @@ extern "C" int nm_weight_grad(int device_cus, const float* d_delta, int32_t out_
     const int64_t elems = (int64_t)out_features * in_features;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((elems + out_features + 255) / 256)), dim3(256), 0, stream,
                        a.partial, a.partial_bias, parts, out_features, act_stride, in_features, d_dw, dw_ld, dw_col0, d_dbias);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int64_t nm_head_grad_workspace_bytes(int32_t in_features) {
+    return in_features > 0 ? (int64_t)HEAD_MAX_PARTS * 4 * (in_features + 1) * 4 : 0;
+}
+
+// d_dlast (n, 4) and d_act (n, in_features) row-major, in_features 64, 128 or 256.  Writes d_dw[r * in_features + k] =
+// sum_n dlast[n][r] * act[n][k] (4 rows) and, when d_dbias != NULL, d_dbias[r] = sum_n dlast[n][r].
+extern "C" int nm_head_grad(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace,
+                            float* d_dw, float* d_dbias, void* stream_) {
+    NM_REQUIRE(d_dlast && d_act && d_workspace && d_dw && n > 0, "bad argument");
+    NM_REQUIRE(in_features == 64 || in_features == 128 || in_features == 256,
+               "head_grad: no kernel instantiated for this activation width");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int rpp = 256 / (in_features / 4);
+    int64_t rows = (n + HEAD_MAX_PARTS - 1) / HEAD_MAX_PARTS;
+    rows = (rows + 8 * rpp - 1) / (8 * rpp) * (8 * rpp);        // whole unrolled passes
+    const int parts = (int)((n + rows - 1) / rows);
+    float* partial = static_cast<float*>(d_workspace);
+    float* partial_bias = partial + (int64_t)HEAD_MAX_PARTS * 4 * in_features;
+    if (in_features == 256)
+        hipLaunchKernelGGL(head_grad_kernel<256>, dim3(parts), dim3(256), 0, stream, d_dlast, d_act, n, (int)rows, partial, partial_bias);
+    else if (in_features == 128)
+        hipLaunchKernelGGL(head_grad_kernel<128>, dim3(parts), dim3(256), 0, stream, d_dlast, d_act, n, (int)rows, partial, partial_bias);
+    else
+        hipLaunchKernelGGL(head_grad_kernel<64>, dim3(parts), dim3(256), 0, stream, d_dlast, d_act, n, (int)rows, partial, partial_bias);
+    const int elems = 4 * in_features;
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((elems + 4 + 63) / 64), dim3(256), 0, stream, partial, partial_bias, parts,
+                       elems, d_dw, d_dbias);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }

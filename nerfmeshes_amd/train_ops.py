@@ -121,6 +121,25 @@ def _weight_grad(mlp, delta, act, in_features, out=None, col0=0, bias=True):
     return out, db
 
 
+_HEAD_WIDTHS = (64, 128, 256)
+
+
+def _head_grad(mlp, dlast, act, bias=False):
+    """(4, K) = dlast^T @ act for the heads that share dlast (n, 4) (+ its column sums): nm_head_grad, HBM-bound VALU
+    kernel with the order-fixed partial reduction."""
+    lib = _lib.load()
+    n, k = act.shape
+    need = int(lib.nm_head_grad_workspace_bytes(k))
+    key = (mlp.device, torch.cuda.current_stream(mlp.device).cuda_stream, "head")
+    ws = _dw_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=mlp.device)
+    out = torch.empty(4, k, dtype=torch.float32, device=mlp.device)
+    db = torch.empty(4, dtype=torch.float32, device=mlp.device) if bias else None
+    check(lib.nm_head_grad(_ptr(dlast), _ptr(act), k, n, _ptr(ws), _ptr(out), _ptr(db), _stream()), "nm_head_grad")
+    return out, db
+
+
 def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     """Parameter gradients of sum(radiance * grad_radiance): dict keyed like FlexibleNeRFModel.state_dict()."""
     lib = _lib.load()
@@ -143,7 +162,6 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     # (torch.bmm split-K, _tn) otherwise -- 64-wide networks, ragged sample counts
     fast = n % 16 == 0 and H in (128, 256) and dx <= 64 and dd <= 64
     g = {}
-    last_sums = dlast.sum(0)
     if fast:
         origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
         rays, samples = t.shape
@@ -180,10 +198,14 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         g["fc_feat.weight"], g["fc_feat.bias"] = _tn(dfeat, h[L - 1]), dfeat.sum(0)
         g["layers_dir.0.weight"] = torch.cat((_tn(dv, feat), _tn(dv, enc_d)), dim=1)   # cat(feat, view): models.py:72
         g["layers_dir.0.bias"] = dv.sum(0)
-    # the 1-row / 3-row heads share dlast (n,4): one split-K product per operand, rows picked afterwards (an MFMA tile
-    # would waste 12 of its 16 rows; 0.1 ms)
-    g["fc_alpha.weight"], g["fc_alpha.bias"] = _tn(dlast, h[L - 1])[3:4], last_sums[3:4]
-    g["fc_rgb.weight"], g["fc_rgb.bias"] = _tn(dlast, v)[:3], last_sums[:3]
+    # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
+    # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
+    if H in _HEAD_WIDTHS and H // 2 in _HEAD_WIDTHS:
+        (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, h[L - 1], bias=True), _head_grad(mlp, dlast, v)
+    else:
+        gh, gv, last_sums = _tn(dlast, h[L - 1]), _tn(dlast, v), dlast.sum(0)
+    g["fc_alpha.weight"], g["fc_alpha.bias"] = gh[3:4], last_sums[3:4]
+    g["fc_rgb.weight"], g["fc_rgb.bias"] = gv[:3], last_sums[:3]
     return g
 
 

@@ -359,3 +359,26 @@ def test_weight_grad_kernel_vs_fp64(n, out_f, stride, in_f):
     assert float((db.double().cpu() - delta.double().sum(0)).abs().max()) <= 2e-6 * float(delta.abs().sum(0).max() + 1)
     assert torch.equal(wide[:, 10:], dw) and torch.equal(db2, db), "not deterministic / column window wrong"
     assert bool((wide[:, :10] == 7.0).all()), "wrote outside its column window"
+
+
+@pytest.mark.parametrize("k", [64, 128, 256])
+@pytest.mark.parametrize("n", [1, 37, 4096, 131072 + 5])
+def test_head_grad_kernel_vs_fp64(n, k):
+    """nm_head_grad (fc_alpha / fc_rgb weight gradients: dlast^T @ act for the shared (n, 4) delta + its column sums)
+    vs fp64, ragged row counts included; two runs bit-identical (order-fixed reduction, no atomics)."""
+    from nerfmeshes_amd import hip_ops, train_ops as T
+    kw = dict(num_layers=4, hidden_size=128, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    mlp = hip_ops.HipMLP({k_: torch.as_tensor(v) for k_, v in S.make_mlp_weights(3, **kw).items()}, kw, "cuda")
+    g = torch.Generator().manual_seed(n + k)
+    dlast = torch.randn(n, 4, generator=g)
+    act = torch.relu(torch.randn(n, k, generator=g))
+    dc, ac = dlast.cuda().contiguous(), act.cuda().contiguous()
+    dw, db = T._head_grad(mlp, dc, ac, bias=True)
+    dw2, db2 = T._head_grad(mlp, dc, ac, bias=True)
+    dw3, none = T._head_grad(mlp, dc, ac)
+    ref = dlast.double().t() @ act.double()
+    scale = float(ref.abs().max()) + 1e-30
+    assert dw.shape == (4, k) and db.shape == (4,) and none is None
+    assert float((dw.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5)
+    assert float((db.double().cpu() - dlast.double().sum(0)).abs().max()) <= 2e-6 * float(dlast.abs().sum(0).max() + 1)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dw, dw3), "not deterministic"
