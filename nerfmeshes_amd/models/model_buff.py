@@ -67,9 +67,12 @@ class BuFFModel(BaseModel):
         batch_size = self.cfg.nerf.validation.chunksize
         batch_count = bundle.ray_targets.shape[0] / batch_size
         loss, rgb_chunks = 0.0, []
-        for i in range(0, bundle.ray_targets.shape[0], batch_size):
+        rays = bundle.ray_targets.shape[0]
+        per_ray = bundle.ray_origins.shape[0] == rays and rays > 1   # the reference passes origins unsliced (and fails here)
+        for i in range(0, rays, batch_size):
             sl = slice(i, i + batch_size)
-            out = self.forward((bundle.ray_origins, bundle.ray_directions[sl], bundle.ray_bounds))
+            origins = bundle.ray_origins[sl] if per_ray else bundle.ray_origins
+            out = self.forward((origins, bundle.ray_directions[sl], bundle.ray_bounds))
             loss += self.loss(out.rgb_map, bundle.ray_targets[sl].to(dev))
             rgb_chunks.append(out.rgb_map)
         loss /= batch_count

@@ -63,7 +63,7 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
 
 def cast_to_image(tensor):
     """(H, W, 3) float -> (3, H, W) uint8 numpy (nerf_helpers.py:155-181 family)."""
-    img = np.array((tensor.detach().cpu().clamp(0.0, 1.0) * 255).to(torch.uint8))
+    img = (tensor.detach().cpu().clamp(0.0, 1.0) * 255).to(torch.uint8).numpy()
     return np.moveaxis(img, [-1], [0])
 
 

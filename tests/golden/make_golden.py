@@ -434,6 +434,86 @@ def case_buff_train_step(name):
     print(name, "loss", res["loss"], "tensors", sum(1 for _ in m.named_parameters()))
 
 
+class _Recorder:
+    """Stands in for the TensorBoard writer: keeps what validation_step hands to add_image."""
+    def __init__(self):
+        self.images = {}
+
+    def add_image(self, tag, img, step=None):
+        self.images[tag] = np.asarray(img).copy()
+
+    def __getattr__(self, k):
+        return lambda *a, **kw: None
+
+
+def case_val_steps(name):
+    """The UNMODIFIED reference's NeRFModel.validation_step (model_nerf.py:153-222) and BuFFModel.validation_step
+    (model_buff.py:117-164) on one small image bundle each (10 x 12 rays, validation chunks of 50 -> three chunks, the
+    last ragged; float batch_count 2.4): val_loss, every logged value, and the uint8 images handed to the logger."""
+    import contextlib, io
+    nerf, models = ref_import.load()
+
+    class ToPILImage:   # torchvision is absent: its float-tensor path (functional.to_pil_image: pic.mul(255).byte(), CHW -> HWC)
+        def __call__(self, pic):
+            return np.transpose(pic.mul(255).byte().numpy(), (1, 2, 0))
+
+    sys.modules["torchvision"].transforms.ToPILImage = ToPILImage
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    H, W = 10, 12
+    g = torch.Generator().manual_seed(11)
+    res = {}
+
+    def run(tag, m, batch):
+        rec = _Recorder()
+        m.logger = type("L", (), {"experiment": rec})()
+        m.global_step = 0
+        m.eval()
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            out = m.validation_step(batch, 3)
+        res[tag + ".val_loss"] = np.float32(float(out["val_loss"]))
+        for k, v in out["log"].items():
+            res[tag + ".log." + k] = np.float32(float(v))
+        for k, v in rec.images.items():
+            res[tag + ".image." + k] = v
+        for k, p in m.named_parameters():
+            res[tag + ".param." + k] = p.detach().numpy().copy()
+        print(name, tag, "val_loss", float(out["val_loss"]), sorted(rec.images))
+
+    # NeRFModel: one origin, lego-like bounds
+    hp = S.hparams(num_coarse=16, num_fine=16, chunksize=50, **kw)
+    torch.manual_seed(7)
+    m = models.NeRFModel(hp)
+    with torch.no_grad():
+        for net in (m.model_coarse, m.model_fine):
+            net.fc_alpha.weight.mul_(40.0)
+    o = torch.tensor([0.2, -0.1, 3.5])
+    d = torch.nn.functional.normalize(torch.tensor([[0.0, 0.1, -1.0]]) + 0.3 * torch.randn(H * W, 3, generator=g), dim=-1)
+    tgt = torch.rand(H * W, 3, generator=g)
+    run("nerf", m, dict(ray_origins=o[None], ray_directions=d.view(1, H, W, 3), ray_targets=tgt.view(1, H, W, 3),
+                        ray_bounds=torch.tensor([[2.0, 6.0]]), hwf=(H, W, 100.0)))
+    res.update({"nerf.origin": o.numpy(), "nerf.directions": d.numpy(), "nerf.targets": tgt.numpy(),
+                "nerf.hparams_keys": np.array(list(hp.keys())), "nerf.hparams_vals": np.array([repr(v) for v in hp.values()])})
+
+    # BuFFModel: ONE origin (the reference passes bundle.ray_origins unsliced next to the sliced directions,
+    # model_buff.py:131, so per-ray origins cannot go through its validation_step), rays looking in, some looking away
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=32, num_fine=32, near=0.0, far=1.2, dataset_type="colmap",
+                   chunksize=50, **kw)
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.BuFFModel(hp)
+    with torch.no_grad():
+        m.model.fc_alpha.weight.mul_(60.0)
+    o = torch.tensor([1.5, -0.9, 1.1])                     # outside the tree's cube: rays looking away miss it
+    d = torch.nn.functional.normalize(-o[None] + 0.4 * torch.randn(H * W, 3, generator=g), dim=-1)
+    d[:6] = torch.nn.functional.normalize(o[None] + 0.1 * torch.randn(6, 3, generator=g), dim=-1)
+    tgt = torch.rand(H * W, 3, generator=g)
+    run("buff", m, dict(ray_origins=o[None], ray_directions=d.view(1, H, W, 3), ray_targets=tgt.view(1, H, W, 3),
+                        ray_bounds=torch.tensor([[0.0, 1.2]]), hwf=(H, W, 100.0)))
+    res.update({"buff.origin": o.numpy(), "buff.directions": d.numpy(), "buff.targets": tgt.numpy(),
+                "buff.hparams_keys": np.array(list(hp.keys())), "buff.hparams_vals": np.array([repr(v) for v in hp.values()])})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+
+
 def case_obj(name):
     """(f)-1: the reference's OBJ text writer (nerf_helpers.py:86-111) on a tiny mesh."""
     import contextlib, io
@@ -457,6 +537,8 @@ if __name__ == "__main__":
         case_buff_sampled_tree("buff_sampled_tree")
     elif "--view8k" in sys.argv:
         case_view("render_lego_view_8k", S.hparams(), 8192)
+    elif "--val-steps" in sys.argv:
+        case_val_steps("val_steps")
     elif "--obj" in sys.argv:
         case_obj("export_obj")
     elif "--buff" in sys.argv:

@@ -19,6 +19,11 @@ def golden_hparams(g):
     return {str(k): ast.literal_eval(str(v)) for k, v in zip(g["hparams_keys"], g["hparams_vals"])}
 
 
+def golden_part(g, prefix):
+    """The entries `prefix.*` of a fixture that holds several cases, with the prefix removed."""
+    return {k[len(prefix) + 1:]: g[k] for k in g.files if k.startswith(prefix + ".")}
+
+
 def mlp_kwargs(hp, part):
     keys = ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz", "num_encoding_fn_dir")
     return {k: hp[f"models.{part}.{k}"] for k in keys}

@@ -409,3 +409,56 @@ def test_buff_training_step_against_the_reference_golden(pkg):
         err = float((p.grad.cpu() - ref).abs().max() / ref.abs().max())
         assert err < 2e-3, (name, err)
     assert model.tree.counter == int(g["counter"]) and float(model.tree.memm.max()) > 0.0
+
+
+class _Recorder:
+    def __init__(self):
+        self.images = {}
+
+    def add_image(self, tag, img, step=None):
+        self.images[tag] = np.asarray(img).copy()
+
+
+def _load_params(model, g):
+    state = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("param."):
+            state[k[len("param."):]] = torch.from_numpy(v)
+    model.load_state_dict(state)
+    return model.cuda().eval()
+
+
+def test_validation_steps_against_the_reference_golden(pkg):
+    """NeRFModel.validation_step and BuFFModel.validation_step on the MI355X against the UNMODIFIED reference's
+    (tests/golden/val_steps.npz): val_loss (float batch_count over three chunks, the last ragged), every logged value,
+    and the uint8 images handed to the logger (at most one grey level off on < 1 % of the pixels)."""
+    from tests.helpers import golden_part
+    from nerfmeshes_amd import models
+    G = load_golden("val_steps")
+    H, W = 10, 12
+    cases = (("nerf", models.NeRFModel, "origin", (2.0, 6.0)), ("buff", models.BuFFModel, "origin", (0.0, 1.2)))
+    for tag, cls, okey, bounds in cases:
+        g = golden_part(G, tag)
+        model = _load_params(cls(golden_hparams(g)), g)
+        rec = _Recorder()
+        model.logger = type("L", (), {"experiment": rec})()
+        model.global_step = 0
+        batch = dict(ray_origins=torch.from_numpy(g[okey])[None], ray_directions=torch.from_numpy(g["directions"]).view(1, H, W, 3),
+                     ray_targets=torch.from_numpy(g["targets"]).view(1, H, W, 3), ray_bounds=torch.tensor([list(bounds)]),
+                     hwf=(H, W, 100.0))
+        with torch.no_grad():
+            out = model.validation_step(batch, 3)
+        ref = float(g["val_loss"])
+        assert abs(float(out["val_loss"]) - ref) < 1e-4 * ref, (tag, float(out["val_loss"]), ref)
+        logged = {k[len("log."):] for k in g if k.startswith("log.")}
+        assert set(out["log"]) == logged, (tag, set(out["log"]) ^ logged)
+        for k in logged:
+            r = float(g["log." + k])
+            assert abs(float(out["log"][k]) - r) < 2e-4 * max(1.0, abs(r)), (tag, k, float(out["log"][k]), r)
+        images = {k[len("image."):]: v for k, v in g.items() if k.startswith("image.")}
+        assert set(rec.images) == set(images), (tag, set(rec.images) ^ set(images))
+        for k, r in images.items():
+            got = rec.images[k]
+            assert got.shape == r.shape and got.dtype == np.uint8, (tag, k)
+            diff = np.abs(got.astype(int) - r.astype(int))
+            assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (tag, k, int(diff.max()), float((diff > 0).mean()))

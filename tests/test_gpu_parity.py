@@ -80,6 +80,17 @@ def _fine_samples_without_last(sorted_all, coarse_t):
     return np.asarray(out, dtype=np.float32)
 
 
+def _last_fine_sample(sorted_all, coarse_t):
+    """The largest resampled depth (the u == 1.0 sample) of every ray, by the same multiset difference."""
+    out = []
+    for row, tc in zip(np.asarray(sorted_all), np.asarray(coarse_t)):
+        row = list(row)
+        for v in tc:
+            row.remove(v)
+        out.append(max(row))
+    return np.asarray(out, dtype=np.float64)
+
+
 MLP_CONFIGS = [
     dict(),                                                        # 8x256, F=10/4 (lego)
     dict(hidden_size=128),                                         # nerf-colmap-fern.yml
@@ -206,6 +217,20 @@ def test_sample_pdf_vs_oracle(ops, coarse, fine):
     binw = 4.0 / (coarse - 1)
     _close(a[71:], b[71:], 1e-3 * binw, what="fine depths (well conditioned)")
     _close(a[:71], b[:71], 2e-2 * binw, what="fine depths (clamped bins)")
+    # ... and the excluded u == 1.0 sample is not free either: it can only land where the cdf is within rounding of 1,
+    # i.e. between the bin edge in front of the first cdf entry >= 1 - 4 ulp (fp64 cdf) and bins[-1]; when no earlier
+    # entry is that close it IS bins[-1] or bins[-2] (modules.py:243-246).  Holds for the oracle's sample too.
+    bins = (0.5 * (t[:, 1:] + t[:, :-1])).double().numpy()
+    wd = w[:, 1:-1].double().numpy() + 1e-5
+    cdf = np.concatenate([np.zeros((rays, 1)), np.cumsum(wd / wd.sum(-1, keepdims=True), -1)], -1)
+    first = (cdf >= 1.0 - 4 * 6e-8).argmax(-1)
+    lower = bins[np.arange(rays), np.maximum(first - 1, 0)]
+    for name, arr in (("hip", got), ("oracle", ref)):
+        last = _last_fine_sample(arr, t)
+        assert np.all(last >= lower - 1e-6) and np.all(last <= bins[:, -1] + 1e-6), f"{name}: u == 1 sample outside the cdf == 1 plateau"
+        tight = first >= bins.shape[1] - 1                      # plateau = the last bin only
+        on_edge = np.minimum(np.abs(last - bins[:, -1]), np.abs(last - bins[:, -2])) <= 1e-6
+        assert np.all(on_edge[tight & (wd[:, -1] / wd.sum(-1) < 1e-5)]), f"{name}: u == 1 sample not on bins[-1] / bins[-2]"
 
 
 def _render_case(ops, case):

@@ -363,3 +363,73 @@ def test_buff_training_step_loss_and_gradients_match_reference():
     for k, v in w.items():
         ref = torch.from_numpy(g["grad.model." + k])
         assert float((v.grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
+
+
+def _uint8_image(rgb, h, w):
+    """What the reference's cast_to_image hands to the logger (nerf_helpers.py:155-170; torchvision's ToPILImage on a
+    float tensor is mul(255).byte()): (3, H, W) uint8."""
+    return np.moveaxis((rgb.reshape(h, w, 3) * 255).to(torch.uint8).numpy(), -1, 0)
+
+
+def test_validation_steps_match_reference():
+    """The oracle chain reproduces the UNMODIFIED reference's NeRFModel.validation_step and BuFFModel.validation_step
+    (fixture val_steps.npz): val_loss with the float batch_count over three chunks (the last ragged), the logged
+    PSNRs, and the uint8 images given to the logger."""
+    from tests.helpers import golden_part
+    G = load_golden("val_steps")
+    H, W, chunk = 10, 12, 50
+    # ---- NeRFModel
+    g = golden_part(G, "nerf")
+    hp = golden_hparams(g)
+    sc, sf, rs = specs_from_hparams(hp)
+    wc = {k[len("param.model_coarse."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.model_coarse.")}
+    wf = {k[len("param.model_fine."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.model_fine.")}
+    o, d, tgt = torch.from_numpy(g["origin"])[None], torch.from_numpy(g["directions"]), torch.from_numpy(g["targets"])
+    assert int(hp["nerf.validation.chunksize"]) == chunk and d.shape[0] == H * W
+    batch_count = d.shape[0] / chunk
+    closs, floss, rc, rf = 0, 0, [], []
+    for s in range(0, d.shape[0], chunk):
+        c, f = O.render(wc, wf, sc, sf, rs, o, d[s:s + chunk], 2.0, 6.0)
+        closs = closs + torch.nn.functional.mse_loss(c["rgb_map"], tgt[s:s + chunk])
+        floss = floss + torch.nn.functional.mse_loss(f["rgb_map"], tgt[s:s + chunk])
+        rc.append(c["rgb_map"]); rf.append(f["rgb_map"])
+    closs, floss = closs / batch_count, floss / batch_count
+    assert abs(float(closs + floss) - float(g["val_loss"])) <= 1e-6
+    assert abs(float(O.mse2psnr(closs)) - float(g["log.validation/coarse_psnr"])) <= 1e-4
+    assert abs(float(O.mse2psnr(floss)) - float(g["log.validation/fine_psnr"])) <= 1e-4
+    assert abs(float(floss) - float(g["log.validation/fine_loss"])) <= 1e-6
+    # the aliasing quirk again (model_nerf.py:183,207): the logged coarse_loss is the total
+    assert abs(float(g["log.validation/coarse_loss"]) - float(g["val_loss"])) <= 1e-7
+    for tag, rgb in (("validation/rgb_coarse/3", torch.cat(rc)), ("validation/rgb_fine/3", torch.cat(rf))):
+        ref = g["image." + tag]
+        got = _uint8_image(rgb, H, W)
+        assert ref.shape == (3, H, W) and ref.dtype == np.uint8
+        assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and (got != ref).mean() < 0.01, tag
+    assert np.array_equal(g["image.validation/img_target/3"], _uint8_image(tgt, H, W))
+    # ---- BuFFModel
+    g = golden_part(G, "buff")
+    hp = golden_hparams(g)
+    sc, _, rs = specs_from_hparams(hp)
+    rs = O.RenderSpec(num_coarse=rs.num_coarse, num_fine=0)
+    w = {k[len("param.model."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.model.")}
+    o, d, tgt = torch.from_numpy(g["origin"])[None], torch.from_numpy(g["directions"]), torch.from_numpy(g["targets"])
+    near, far = float(hp["dataset.near"]), float(hp["dataset.far"])
+    voxels = O.buff_initial_voxels(near, far, int(hp["tree.subdivision_outer_count"]))
+    loss, chunks, missed = 0, [], 0
+    for s in range(0, d.shape[0], chunk):
+        dd = d[s:s + chunk]
+        z, _, mask = O.buff_intersect(voxels, o.expand(dd.shape[0], 3), dd, near, far, rs.num_coarse)
+        t = torch.where(mask[:, None], z, O.coarse_intervals(near, far, rs.num_coarse, dd.shape[0]))
+        missed += int((~mask).sum())
+        pts = O.ray_points(t, dd, o).reshape(-1, 3)
+        dirs = dd[:, None, :].expand(-1, t.shape[1], -1).reshape(-1, 3)
+        rad = O.mlp_forward(w, sc, pts, dirs).reshape(dd.shape[0], -1, 4)
+        rgb = O.composite(rad, t, dd, rs)["rgb_map"]
+        loss = loss + torch.nn.functional.mse_loss(rgb, tgt[s:s + chunk])
+        chunks.append(rgb)
+    loss = loss / (d.shape[0] / chunk)
+    assert 0 < missed < d.shape[0]
+    assert abs(float(loss) - float(g["val_loss"])) <= 1e-6
+    assert abs(float(O.mse2psnr(loss)) - float(g["log.validation/psnr"])) <= 1e-4
+    got, ref = _uint8_image(torch.cat(chunks), H, W), g["image.validation/rgb_coarse/3"]
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and (got != ref).mean() < 0.01
