@@ -313,50 +313,71 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 // 1.42x over-fetch).
 //
 // (a) mc_classify_stream -- the HBM-bound part, and nothing else.  A workgroup of 1024 threads = 128 x-groups (512
-//     voxels: a whole row of the 480^3 grid) x 8 voxel rows marches MC_ZRUN planes up the z axis: per plane every
-//     thread issues ONE 16-byte load and the workgroup as a whole reads one CONTIGUOUS 16 KB run of the volume (the 8
-//     rows are adjacent in memory), MC_AHEAD planes in flight.  Sign bits go through 1 KB of LDS per plane: a cube's
-//     corner pattern is made of its thread's bits, the next x-group's first bit, the thread row above (the 8th thread
-//     row only supplies that halo: 7 cube layers per brick) and the previous step's (kept in registers).  Voxels fetched
-//     per cube: 8/7 x 25/24 = 1.19, all of it in whole rows -- round 1's bricks (129 x 9 x 9 voxels in 516-byte
-//     row segments) measured 1.42x at 0.94 TB/s whatever the brick shape.
-//     Every load is UNCONDITIONAL (addresses clamped into the volume; clamped values only reach cubes that do not
-//     exist): loads inside divergent branches make the compiler fall back to s_waitcnt vmcnt(0) at every use.
-//     Cubes the surface cuts (index != 0, 255; ~1 %) are appended -- 64-bit (cube id | corner pattern << 40) -- to a
-//     global queue through an LDS staging buffer, one atomicAdd per flush.  The code bytes of all other cubes are a memset.
-// (b) mc_classify_cut -- one thread per queued cube: the MC33 face / interior tests (fp64), the tiling row, the number
-//     of vertices the cube creates; writes that cube's code byte.
-constexpr int MC_ZRUN = 24;
-constexpr int MC_GX = 128, MC_GY = 8;                               // thread grid: x-groups per row, voxel rows (7 cube rows + halo)
+//     voxels: a whole row of the 480^3 grid) x 8 adjacent rows marches `zrun` planes up axis 0: per plane every thread
+//     issues ONE 16-byte load (the workgroup: one contiguous 15 KB run), MC_AHEAD planes in flight.  Voxels fetched
+//     per cube: 8/7 x 25/24 = 1.19, all of it in whole rows -- round 1's bricks (129 x 9 x 9 voxels in 516-byte row
+//     segments) measured 1.42x whatever the brick shape.  Every load is UNCONDITIONAL (addresses clamped into the
+//     volume; clamped values only reach cubes that do not exist): loads inside divergent branches make the compiler
+//     fall back to s_waitcnt vmcnt(0) at every use.
+//     Per voxel the only work is the sign test: 4 v_cmp per lane and step, whose 64 results per wavefront land in a
+//     scalar register pair.  "Which cubes does the surface cut" -- the 8 corner bits are neither all 0 nor all 1 -- is
+//     bit-parallel logic on those 64-bit masks, and ONE wavefront does it for the whole workgroup: the 16 waves leave
+//     their 4 masks in LDS (32 B each), and after the step's barrier the last wave combines the masks of every
+//     wave-row (its own row and the one above, this step and the previous one, the neighbour wave's first column)
+//     (lane = wave-row x column, 56 lanes) into cut masks with a dozen 64-bit VALU operations -- one pass.  The
+//     owners pick their cut masks up after the NEXT barrier and append the (few) cut cubes lane-parallel to an LDS
+//     staging buffer; a per-wave-row flag lets the ~90 % of wavefront rows that do not touch the surface skip that
+//     with one scalar branch.
+//     History of this kernel at 480^3 (tests/tools/membw.hip streams the same bytes in the same workgroup shape,
+//     barrier per step included, in 76 us; this kernel with the logic removed: 97 us): 8-bit pattern assembled per
+//     cube on the VALU (~30 ops / cube) 244 us; mask logic on the scalar unit of every wave (~60 s_and / s_or per
+//     wave and step: the CU's one scalar ALU becomes the bottleneck) 154 us; one logic wave per workgroup: see
+//     DESIGN.md 3.3.
+//     The staging buffer goes to the global queue (one atomicAdd) at the end of the march, earlier only if it could
+//     overflow.  The code bytes of all other cubes are a memset.
+// (b) mc_classify_cut -- one thread per queued cube: corner pattern, the MC33 face / interior tests (fp64), the tiling
+//     row, the number of vertices the cube creates; writes that cube's code byte.
+constexpr int MC_ZRUN_MIN = 8, MC_ZRUN_MAX = 24;                    // planes per march: chosen per launch (mc_pick_zrun)
+constexpr int MC_GX = 128, MC_GY = 8;                               // thread grid: x-groups per row, rows (7 cube rows + halo)
 constexpr int MC_STREAM_THREADS = MC_GX * MC_GY;
-constexpr int MC_CUBES_PER_PLANE = MC_GX * MC_ITEMS * (MC_GY - 1);  // 3584
-constexpr int MC_STAGE = 2 * 4096;                                  // LDS staging entries: flushed every 2 planes
-constexpr int MC_AHEAD = 6;
+constexpr int MC_CUBES_PER_PLANE = MC_GX * MC_ITEMS * (MC_GY - 1);  // 3584 cubes per step of the march
+constexpr int MC_STAGE = 12288;                                     // LDS staging entries (48 KB)
+constexpr int MC_FLUSH_AT = MC_STAGE - 2 * MC_CUBES_PER_PLANE;      // see the flush decision below
+constexpr int MC_AHEAD = 6;                                         // even: the LDS double buffers are indexed by the ring slot's parity
+constexpr bool MC_MARCH0 = true;   // march along axis 0, thread rows = adjacent rows of axis 1 (false: the other way round; same speed)
+constexpr int MC_LOGIC_WAVE = MC_STREAM_THREADS / 64 - 1;           // second half of the halo row: owns no cubes
+static_assert(MC_GX == 128 && MC_ITEMS == 4 && 8 * (MC_GY - 1) <= 64 && MC_AHEAD % 2 == 0, "two wavefronts per row, four voxels per lane");
 
 struct __attribute__((packed)) McWord { uint32_t v; };              // 4 code bytes at any byte offset
 
-// The thread rows are 8 consecutive PLANES (7 cube planes + the halo plane) and the march runs along axis 1 (rows,
-// 1920 B apart), so a workgroup stays inside 8 address windows of a few hundred KB.  (Marching along axis 0 with 8
-// adjacent rows per step -- one contiguous 16 KB run per step, 921 KB jumps between steps -- measures the same:
-// 240 vs 244 us at 480^3; what is left is the memory system's own streaming rate, a plain torch reduction over the
-// same 442 MB takes ~140 us.)
+// Sign masks of one row as a wavefront sees it: mask j, bit L = voxel 4 L + j of the wave's 256-voxel span; "column 4"
+// (voxel 4 L + 4) is column 0 shifted down one lane with the neighbour wave's / halo voxel's bit on top.
 template <bool VEC, bool XHALO>   // VEC: n2 % 4 == 0 (every x-group is one 16-byte load); XHALO: more than one brick in x
-__global__ __launch_bounds__(MC_STREAM_THREADS) void mc_classify_stream(const float* __restrict__ vol, McDims d, float thr,
+__global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const float* __restrict__ vol, McDims d, float thr,
                                                                         uint64_t* __restrict__ queue,
-                                                                        unsigned long long* __restrict__ qcount) {
-    __shared__ uint8_t s_bits[2][MC_GY][MC_GX + 1];      // 4-bit sign patterns (+ the voxel behind the brick), two steps
+                                                                        unsigned long long* __restrict__ qcount, const int zrun) {
+    __shared__ uint64_t s_m[2][MC_GY][2][4];             // sign masks   [step parity][row][x half][column]
+    __shared__ uint64_t s_cut[2][MC_GY - 1][2][4];       // cut masks    [step parity][cube row][x half][column]
+    __shared__ uint32_t s_some[2][MC_GY - 1][2];         // any bit set in the 4 cut masks
+    __shared__ uint64_t s_prev[2 * (MC_GY - 1)][2][5];   // logic wave: [wave-row][AND, OR][column] of the previous step
+    __shared__ uint32_t s_h[2][MC_GY];                   // the voxel behind the brick
     __shared__ uint32_t s_q[MC_STAGE];
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_n, s_snap[2];
     __shared__ unsigned long long s_base;
-    const int tx = threadIdx.x % MC_GX, tz = threadIdx.x / MC_GX;
-    const int xb = blockIdx.x * MC_GX * MC_ITEMS, z0 = blockIdx.y * (MC_GY - 1), y0 = blockIdx.z * MC_ZRUN;
-    const int x0 = xb + tx * MC_ITEMS, z = z0 + tz;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xh = wave & 1, tz = wave >> 1, tx = xh * 64 + lane;
+    // thread rows along axis R (origin r0), the march along axis M (origin m0): (R, M) = (1, 0) or (0, 1)
+    const int xb = blockIdx.x * MC_GX * MC_ITEMS, r0 = blockIdx.y * (MC_GY - 1), m0 = blockIdx.z * zrun;
+    const int nr = MC_MARCH0 ? d.n1 : d.n0, nm = MC_MARCH0 ? d.n0 : d.n1, cr = MC_MARCH0 ? d.c1 : d.c0, cm = MC_MARCH0 ? d.c0 : d.c1;
+    const int64_t sr = MC_MARCH0 ? (int64_t)d.n2 : (int64_t)d.n1 * d.n2, sm = MC_MARCH0 ? (int64_t)d.n1 * d.n2 : (int64_t)d.n2;
+    const int x0 = xb + tx * MC_ITEMS, r = r0 + tz;
     const int xl = min(x0, VEC ? d.n2 - 4 : d.n2 - 1);
-    const float* planep = vol + (int64_t)min(z, d.n0 - 1) * d.n1 * d.n2;
-    if (threadIdx.x == 0) s_n = 0;
+    const float* rowp = vol + (int64_t)min(r, nr - 1) * sr;
+    if (threadIdx.x == 0) { s_n = 0; s_snap[0] = s_snap[1] = 0; }
     struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
     auto fetch = [&](int l) -> F4 {
-        const float* p = planep + (int64_t)min(y0 + l, d.n1 - 1) * d.n2;
+        const float* p = rowp + (int64_t)min(m0 + l, nm - 1) * sm;
         F4 q;
         if constexpr (VEC) q = *reinterpret_cast<const F4*>(p + xl);
         else {
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(MC_STREAM_THREADS) void mc_classify_stream(const fl
         return q;
     };
     auto fetch_halo = [&](int l) -> float {   // the voxel behind the brick (asked for by the last x-group only; everybody loads)
-        const float* p = planep + (int64_t)min(y0 + l, d.n1 - 1) * d.n2;
+        const float* p = rowp + (int64_t)min(m0 + l, nm - 1) * sm;
         return p[tx == MC_GX - 1 ? min(xb + MC_GX * MC_ITEMS, d.n2 - 1) : min(xl, d.n2 - 1)];
     };
     F4 pf[MC_AHEAD];
@@ -376,61 +397,117 @@ __global__ __launch_bounds__(MC_STREAM_THREADS) void mc_classify_stream(const fl
         pf[l] = fetch(l);
         if constexpr (XHALO) ph[l] = fetch_halo(l);
     }
-    unsigned a_prev = 0, c_prev = 0;
-    auto flush = [&]() {
+    auto flush = [&]() {                                 // entered by every wave, or by none
         if (threadIdx.x == 0) s_base = atomicAdd(qcount, (unsigned long long)s_n);
         __syncthreads();
         const uint32_t cnt = s_n;
         for (uint32_t e = threadIdx.x; e < cnt; e += MC_STREAM_THREADS) {
-            const uint32_t ent = s_q[e], local = ent & 0x1ffffu;
-            const int k = local % (MC_GX * MC_ITEMS), rz = (local / (MC_GX * MC_ITEMS)) % (MC_GY - 1), ll = local / MC_CUBES_PER_PLANE;
-            const int64_t id = ((int64_t)(z0 + rz) * d.c1 + (y0 + ll)) * d.c2 + xb + k;
-            queue[s_base + e] = (uint64_t)id | ((uint64_t)(ent >> 17) << 40);
+            const uint32_t local = s_q[e];
+            const int k = local % (MC_GX * MC_ITEMS), rr = (local / (MC_GX * MC_ITEMS)) % (MC_GY - 1), ll = local / MC_CUBES_PER_PLANE;
+            const int cz = MC_MARCH0 ? m0 + ll : r0 + rr, cy = MC_MARCH0 ? r0 + rr : m0 + ll;
+            queue[s_base + e] = (uint64_t)(((int64_t)cz * d.c1 + cy) * d.c2 + xb + k);
         }
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     };
+    // owners: append the cut cubes of march step `lc` (cubes between voxel planes lc and lc + 1) from the cut masks
+    auto append = [&](int lc) {
+        if (tz >= MC_GY - 1) return;
+        const int par = (lc + 1) & 1;                    // written by the logic wave in iteration lc + 1
+        if (__builtin_amdgcn_readfirstlane((int)s_some[par][tz][xh]) == 0) return;   // scalar branch: nothing cut here
+        const uint32_t base = (uint32_t)(lc * MC_CUBES_PER_PLANE + tz * (MC_GX * MC_ITEMS) + tx * MC_ITEMS);
 #pragma unroll
-    for (int l = 0; l <= MC_ZRUN; ++l) {                 // voxel row y0 + l of this thread's plane
-        const F4 q = pf[l % MC_AHEAD];
+        for (int j = 0; j < 4; ++j)
+            if (((s_cut[par][tz][xh][j] >> lane) & 1u) && x0 + j < d.c2) s_q[atomicAdd(&s_n, 1u)] = base + j;
+    };
+    // logic wave: lane = 4 k + column, k = 2 cube row + x half (56 lanes)
+    const int kk = lane >> 2, kcol = lane & 3, krow = min(kk >> 1, MC_GY - 2), khalf = kk & 1;
+    const bool k_exists = r0 + krow < cr;
+    // (that state -- 10 masks per lane -- lives in LDS, not in registers every wave would have to reserve: at 64 VGPRs
+    // two workgroups share a CU)
+    __syncthreads();
+    // the march: an outer loop over groups of MC_AHEAD planes (not unrolled: the fully unrolled loop made the register
+    // allocator spill the planes in flight at 64 VGPRs), the ring slot of a plane is its position in the group
+#pragma unroll 1
+    for (int l0 = 0; l0 <= zrun; l0 += MC_AHEAD) {
+#pragma unroll
+      for (int u = 0; u < MC_AHEAD; ++u) {
+        const int l = l0 + u;                            // voxel plane m0 + l
+        if (l > zrun) break;
+        const F4 q = pf[u];
         float hq = 0.0f;
-        if constexpr (XHALO) hq = ph[l % MC_AHEAD];
-        if (l + MC_AHEAD <= MC_ZRUN) {                   // MC_AHEAD rows in flight
-            pf[l % MC_AHEAD] = fetch(l + MC_AHEAD);
-            if constexpr (XHALO) ph[l % MC_AHEAD] = fetch_halo(l + MC_AHEAD);
+        if constexpr (XHALO) hq = ph[u];
+        if (l + MC_AHEAD <= zrun) {                      // MC_AHEAD planes in flight
+            pf[u] = fetch(l + MC_AHEAD);
+            if constexpr (XHALO) ph[u] = fetch_halo(l + MC_AHEAD);
         }
-        const unsigned self4 = (q.v[0] > thr ? 1u : 0u) | (q.v[1] > thr ? 2u : 0u) | (q.v[2] > thr ? 4u : 0u) | (q.v[3] > thr ? 8u : 0u);
-        s_bits[l & 1][tz][tx] = (uint8_t)self4;
-        if (tx == MC_GX - 1) s_bits[l & 1][tz][MC_GX] = (uint8_t)((XHALO && hq > thr) ? 1u : 0u);
-        __syncthreads();
-        // staging buffer -> global queue on a FIXED schedule (a data-dependent test of s_n would race with the appends
-        // of faster threads): two steps append at most 2 * MC_CUBES_PER_PLANE <= MC_STAGE entries
-        if (l > 0 && l % 2 == 0) flush();
-        if (tz < MC_GY - 1) {
-            // corner bits of the cubes (z, y0 + l - 1, x0 + k): rows y (previous step) and y + 1 (this step) of the
-            // planes z (this thread) and z + 1 (the thread row above)
-            const unsigned b_cur = self4 | ((unsigned)(s_bits[l & 1][tz][tx + 1] & 1u) << 4);
-            const unsigned e_cur = (unsigned)(s_bits[l & 1][tz + 1][tx] & 15u) | ((unsigned)(s_bits[l & 1][tz + 1][tx + 1] & 1u) << 4);
-            const int y = y0 + l - 1;
-            if (l > 0 && z < d.c0 && y < d.c1) {
+        uint64_t b[4];
 #pragma unroll
-                for (int k = 0; k < MC_ITEMS; ++k) {
-                    const unsigned a = a_prev >> k, b = b_cur >> k, c = c_prev >> k, e = e_cur >> k;
-                    const unsigned index = (a & 1u) | ((a >> 1 & 1u) << 1) | ((b >> 1 & 1u) << 2) | ((b & 1u) << 3) |
-                                           ((c & 1u) << 4) | ((c >> 1 & 1u) << 5) | ((e >> 1 & 1u) << 6) | ((e & 1u) << 7);
-                    if (x0 + k < d.c2 && index != 0u && index != 255u)
-                        s_q[atomicAdd(&s_n, 1u)] = (uint32_t)((l - 1) * MC_CUBES_PER_PLANE + tz * (MC_GX * MC_ITEMS) + tx * MC_ITEMS + k) | (index << 17);
-                }
-            }
-            a_prev = b_cur;
-            c_prev = e_cur;
+        for (int j = 0; j < 4; ++j) b[j] = __ballot(q.v[j] > thr);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_m[u & 1][tz][xh][j] = b[j];
         }
+        if constexpr (XHALO) {
+            const uint64_t hm = __ballot(hq > thr);
+            if (xh == 1 && lane == 0) s_h[u & 1][tz] = (uint32_t)(hm >> 63);
+        }
+        // Flush decision, identical in every wave: thread 0's snapshot of the fill level, taken BEFORE this barrier
+        // (it counts every append up to two iterations back, possibly some of the previous one's), read after it.
+        // Without a flush the buffer holds at most snapshot + 2 steps' worth of appends at the next decision.
+        if (threadIdx.x == 0) s_snap[u & 1] = s_n;
+        __syncthreads();
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_snap[u & 1]) > (uint32_t)MC_FLUSH_AT) flush();
+        if (l >= 2) append(l - 2);                       // masks the logic wave wrote during the previous iteration
+        if (wave == MC_LOGIC_WAVE) {
+            // lane (k, j), k = wave-row (krow, khalf), j = column: the cut mask of the 64 cubes 4 L + j of that wave-row
+            // from columns j and j + 1 of two rows (krow, krow + 1) and two planes (the previous step's AND / OR per
+            // column are kept in s_prev; every lane reads before any lane writes: one wavefront, LDS in program order)
+            const int par = u & 1;
+            uint64_t cut = 0;
+            if (lane < 8 * (MC_GY - 1)) {
+                const int jn = (kcol + 1) & 3;
+                const uint64_t own = s_m[par][krow][khalf][kcol], up = s_m[par][krow + 1][khalf][kcol];
+                const uint64_t own_n = s_m[par][krow][khalf][jn], up_n = s_m[par][krow + 1][khalf][jn];
+                const uint64_t and_c = own & up, or_c = own | up;
+                uint64_t and_n = own_n & up_n, or_n = own_n | up_n;
+                if (kcol == 3) {   // column 4 = column 0 one lane up; the top bit: next wave of the row / the voxel behind the brick
+                    uint64_t nb_own, nb_up;
+                    if (khalf == 0) { nb_own = s_m[par][krow][1][0] & 1u; nb_up = s_m[par][krow + 1][1][0] & 1u; }
+                    else { nb_own = XHALO ? s_h[par][krow] : 0u; nb_up = XHALO ? s_h[par][krow + 1] : 0u; }
+                    and_n = (and_n >> 1) | ((nb_own & nb_up) << 63);
+                    or_n = (or_n >> 1) | ((nb_own | nb_up) << 63);
+                }
+                const uint64_t all1 = s_prev[kk][0][kcol] & and_c & s_prev[kk][0][kcol + 1] & and_n;
+                const uint64_t any1 = s_prev[kk][1][kcol] | or_c | s_prev[kk][1][kcol + 1] | or_n;
+                if (l > 0 && k_exists && m0 + l - 1 < cm) cut = any1 & ~all1;      // cubes of step l - 1
+                s_prev[kk][0][kcol] = and_c;
+                s_prev[kk][1][kcol] = or_c;
+                if (kcol == 3) { s_prev[kk][0][4] = and_n; s_prev[kk][1][4] = or_n; }
+                s_cut[par][krow][khalf][kcol] = cut;     // (lanes past the end of a row hold copies of its last voxels; append() masks them)
+            }
+            const uint64_t nonzero = __ballot(cut != 0);
+            if (lane < 2 * (MC_GY - 1)) s_some[par][lane >> 1][lane & 1] = (uint32_t)((nonzero >> (4 * lane)) & 15u);
+        }
+      }
     }
+    __syncthreads();                                     // the logic wave's last masks
+    append(zrun - 1);
     __syncthreads();
     flush();
 }
-static_assert(MC_ZRUN * MC_CUBES_PER_PLANE <= (1 << 17) && 2 * MC_CUBES_PER_PLANE <= MC_STAGE, "local cube id is 17 bits");
+static_assert(MC_FLUSH_AT > 0 && (int64_t)MC_ZRUN_MAX * MC_CUBES_PER_PLANE < (int64_t(1) << 32), "staging buffer / local id");
+
+// Planes per march: 24 (halo planes cost 25/24; 1380 workgroups at 480^3), fewer for volumes that would not give every
+// CU its two workgroups.  (Choosing zrun to make the launch a whole number of "rounds" -- 22 at 480^3 -- measures
+// slower, 124.5 vs 121 us: workgroups do not run in lockstep rounds, the extra halo planes are what counts.)
+static int mc_pick_zrun(int64_t bricks_xy, int c_march, int num_cus) {
+    const int64_t slots = 2 * (int64_t)(num_cus > 0 ? num_cus : 256);
+    int z = 24;
+    while (z > MC_ZRUN_MIN && bricks_xy * ((c_march + z - 1) / z) < slots) --z;
+    return z;
+}
 
 __global__ __launch_bounds__(MC_BLOCK) void mc_classify_cut(const float* __restrict__ vol, McDims d, double iso,
                                                             const uint64_t* __restrict__ queue,
@@ -438,15 +515,13 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_cut(const float* __restr
                                                             uint8_t* __restrict__ codes) {
     const int64_t n = (int64_t)*qcount;
     for (int64_t q = (int64_t)blockIdx.x * MC_BLOCK + threadIdx.x; q < n; q += (int64_t)gridDim.x * MC_BLOCK) {
-        const uint64_t ent = queue[q];
-        const int64_t id = (int64_t)(ent & ((uint64_t(1) << 40) - 1));
-        const int index = (int)(ent >> 40);
+        const int64_t id = (int64_t)queue[q];
         int z, y, x;
         cube_coords(d, id, z, y, x);
         Cube c;
         load_cube(vol, d, z, y, x, iso, c);
         int off, nt;
-        select_tiling(c, index, off, nt);
+        select_tiling(c, index_of(c), off, nt);
         if (nt > 0) codes[id] = (uint8_t)pack_code(nt, count_created(off, nt, z, y, x));
     }
 }
@@ -831,8 +906,18 @@ int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, doubl
     NM_REQUIRE(d.cubes < (int64_t(1) << 40), "volume too large");
     McWorkspace ws;
     carve(d, static_cast<char*>(d_workspace), &ws);
-    const dim3 bricks((unsigned)((d.c2 + MC_GX * MC_ITEMS - 1) / (MC_GX * MC_ITEMS)), (unsigned)((d.c0 + MC_GY - 2) / (MC_GY - 1)),
-                      (unsigned)((d.c1 + MC_ZRUN - 1) / MC_ZRUN));
+    const int c_rows = MC_MARCH0 ? d.c1 : d.c0, c_march = MC_MARCH0 ? d.c0 : d.c1;
+    static int cus_of_device[64] = {};
+    int dev = 0;
+    NM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && cus_of_device[dev] == 0) {
+        hipDeviceProp_t prop;
+        NM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus_of_device[dev] = prop.multiProcessorCount;
+    }
+    const unsigned bx = (unsigned)((d.c2 + MC_GX * MC_ITEMS - 1) / (MC_GX * MC_ITEMS)), by = (unsigned)((c_rows + MC_GY - 2) / (MC_GY - 1));
+    const int zrun = mc_pick_zrun((int64_t)bx * by, c_march, dev >= 0 && dev < 64 ? cus_of_device[dev] : 0);
+    const dim3 bricks(bx, by, (unsigned)((c_march + zrun - 1) / zrun));
     NM_REQUIRE(bricks.y <= 65535u && bricks.z <= 65535u, "volume too large");
     // code bytes: zero everywhere (incl. the <= 3 bytes behind the last cube that share a dword with real cubes);
     // the cut cubes' bytes are written by mc_classify_cut
@@ -845,7 +930,7 @@ int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, doubl
     uint64_t* queue = reinterpret_cast<uint64_t*>(ws.edge[0]);
     unsigned long long* qcount = reinterpret_cast<unsigned long long*>(ws.totals + 8);
     const bool vec = n2 % 4 == 0, xhalo = bricks.x > 1;
-#define NM_STREAM(V, X) hipLaunchKernelGGL((mc_classify_stream<V, X>), bricks, dim3(MC_STREAM_THREADS), 0, stream, d_volume, d, thr, queue, qcount)
+#define NM_STREAM(V, X) hipLaunchKernelGGL((mc_classify_stream<V, X>), bricks, dim3(MC_STREAM_THREADS), 0, stream, d_volume, d, thr, queue, qcount, zrun)
     if (vec && !xhalo) NM_STREAM(true, false);
     else if (vec) NM_STREAM(true, true);
     else if (!xhalo) NM_STREAM(false, false);
