@@ -16,5 +16,7 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
   name=$(echo $group | cut -d' ' -f1)
   rocprofv3 --pmc $group --kernel-trace -d $R/gpurun_out/pmc_$tag/$name -o pmc --output-format csv -- python $R/bench.py --headline-only --steps 1 --warmup 0 > $R/gpurun_out/pmc_$tag/$name.log 2>&1
 done
-cd $R && python scripts/bench_configs.py > gpurun_out/configs_$tag.json 2>/dev/null; python tests/tools/bench_mesh.py --reps 5 > gpurun_out/mesh_$tag.json 2>/dev/null; python tests/tools/bench_dw.py > gpurun_out/dw_$tag.json 2>/dev/null
+cd $R && python scripts/bench_configs.py > gpurun_out/configs_$tag.json 2>/dev/null; python tests/tools/bench_mesh.py --reps 5 > gpurun_out/mesh_$tag.json 2>/dev/null; python tests/tools/bench_dw.py > gpurun_out/dw_$tag.json 2>/dev/null; python tests/tools/bench_shapes.py 2>/dev/null | tail -1 > gpurun_out/shapes_$tag.json; python tests/tools/bench_b3.py > gpurun_out/b3_$tag.json 2>/dev/null
+bash tests/tools/prof_mc.sh > gpurun_out/mc_$tag.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_train_$tag -o t --output-format csv -- python $R/tests/tools/train_probe.py 20 > $R/gpurun_out/train_$tag.json 2>/dev/null)
 ls $R/gpurun_out/prof_$tag $R/gpurun_out/pmc_$tag
