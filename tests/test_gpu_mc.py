@@ -47,7 +47,10 @@ def test_mc_golden_set_bitwise(ops):
         _check(ops, vol, iso, (g[f"verts_{i}"], g[f"faces_{i}"], g[f"normals_{i}"], g[f"values_{i}"]), f"golden {i}")
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 2), (2, 9, 3), (17, 5, 33), (64, 64, 64), (33, 130, 77), (160, 160, 160)])
+@pytest.mark.parametrize("shape", [(2, 2, 2), (2, 9, 3), (17, 5, 33), (64, 64, 64), (33, 130, 77), (160, 160, 160),
+                                   # rows wider than one 512-voxel brick (the classify kernel's x-halo path), 16-byte loads and scalar ones,
+                                   # and more planes than one march (26 > 24)
+                                   (3, 9, 700), (4, 5, 515), (26, 10, 1032)])
 @pytest.mark.parametrize("kind", ["noise", "ties", "smooth"])
 def test_mc_vs_oracle_bitwise(ops, shape, kind):
     rng = np.random.default_rng(hash((shape, kind)) % (2 ** 32))
