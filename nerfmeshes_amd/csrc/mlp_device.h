@@ -240,40 +240,43 @@ __device__ __forceinline__ uint64_t positive_mask(const float (&op)[COUNT]) {
     return m;
 }
 
-// The sample a lane evaluates: position p and view direction d, by input mode.
-__device__ __forceinline__ void fetch_sample(const MlpArgs& args, int64_t sidx, float (&p)[3], float (&d)[3]) {
+// The sample a lane evaluates: position p and view direction d, by input mode.  Returned BY VALUE as six scalars: with
+// `float (&p)[3], (&d)[3]` out-parameters filled inside the mode branches, hipcc kept p[2] and d[2] in scratch memory
+// (an alloca it could not promote) -- 8 B per lane and tile stored through to HBM, three times the kernel's useful
+// output in WRITE_SIZE.
+struct SamplePD { float px, py, pz, dx, dy, dz; };
+
+__device__ __forceinline__ SamplePD fetch_sample(const MlpArgs& args, int64_t sidx) {
+    SamplePD s;
     if (args.mode == MODE_POINTS) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { p[i] = args.a[3 * sidx + i]; d[i] = args.b[3 * sidx + i]; }
+        s.px = args.a[3 * sidx]; s.py = args.a[3 * sidx + 1]; s.pz = args.a[3 * sidx + 2];
+        s.dx = args.b[3 * sidx]; s.dy = args.b[3 * sidx + 1]; s.dz = args.b[3 * sidx + 2];
     } else if (args.mode == MODE_RAYS) {
         const int64_t ray = sidx / args.samples;
         const float t = args.c[sidx];
         const float* o = args.a + (args.origins_per_ray ? 3 * ray : 0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            d[i] = args.b[3 * ray + i];
-            const float dt = d[i] * t;   // -ffp-contract=off: two roundings, as torch (model_helpers.py:33)
-            p[i] = o[i] + dt;
-        }
+        s.dx = args.b[3 * ray]; s.dy = args.b[3 * ray + 1]; s.dz = args.b[3 * ray + 2];
+        // -ffp-contract=off: two roundings, as torch (model_helpers.py:33)
+        const float tx = s.dx * t, ty = s.dy * t, tz = s.dz * t;
+        s.px = o[0] + tx; s.py = o[1] + ty; s.pz = o[2] + tz;
     } else if (args.mode == MODE_VIEW) {
         const int64_t ray = sidx / args.samples;
         const float t = args.c[sidx];
-        float o[3];
+        float o[3], d[3];
         nm_gen_ray(args.gen, ray, o, d);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float dt = d[i] * t;
-            p[i] = o[i] + dt;
-        }
+        s.dx = d[0]; s.dy = d[1]; s.dz = d[2];
+        const float tx = d[0] * t, ty = d[1] * t, tz = d[2] * t;
+        s.px = o[0] + tx; s.py = o[1] + ty; s.pz = o[2] + tz;
     } else {
         const int64_t flat = args.first + sidx;
         const int64_t plane = (int64_t)args.n1 * args.n2;
         const int64_t i0 = flat / plane;
         const int64_t rem = flat - i0 * plane;
         const int i1 = (int)(rem / args.n2), i2 = (int)(rem - (int64_t)i1 * args.n2);
-        p[0] = args.a[i0]; p[1] = args.b[i1]; p[2] = args.c[i2];
-        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];   // mesh_nerf.py:45: sample_points(samples, samples)
+        s.px = args.a[i0]; s.py = args.b[i1]; s.pz = args.c[i2];
+        s.dx = s.px; s.dy = s.py; s.dz = s.pz;   // mesh_nerf.py:45: sample_points(samples, samples)
     }
+    return s;
 }
 
 // ---- the fused forward kernel (TAPE: also records the activations the backward pass needs) ---------------
@@ -313,8 +316,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
         const int64_t sidx = valid ? sample : args.n - 1;
 
         // ---- prologue: fetch the sample
-        float p[3], d[3];
-        fetch_sample(args, sidx, p, d);
+        const SamplePD smp = fetch_sample(args, sidx);
+        const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
         const float dummy[1] = {0.0f};
         float encx_keep[KEEP_ENC ? N::EX : 1];
         if constexpr (KEEP_ENC) encode<FX, N::EX, ABL>(encx_keep, p, args.bands_xyz, g);

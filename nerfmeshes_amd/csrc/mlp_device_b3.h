@@ -198,8 +198,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         const bool has_next = it + gridDim.x < wg_iters;
         const int64_t sample = (it * NW + wave) * 16 + col;
         const bool valid = sample < args.n;
-        float p[3], d[3];
-        fetch_sample(args, valid ? sample : args.n - 1, p, d);
+        const SamplePD smp = fetch_sample(args, valid ? sample : args.n - 1);
+        const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
         Split3 encx[KBX];
 #pragma unroll
         for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, args.bands_xyz, m, g, encx[m]);

@@ -143,8 +143,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
         const int64_t sample = (it * NW + wave) * 16 + col;
         const bool valid = sample < args.n;
         const int64_t sidx = valid ? sample : args.n - 1;
-        float p[3], d[3];
-        fetch_sample(args, sidx, p, d);
+        const SamplePD smp = fetch_sample(args, sidx);
+        const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
         const float dummy[1] = {0.0f};
         float encx[N::EX];
         encode<FX, N::EX, 0>(encx, p, args.bands_xyz, g);
