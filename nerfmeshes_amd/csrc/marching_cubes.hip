@@ -343,7 +343,8 @@ constexpr int MC_STREAM_THREADS = MC_GX * MC_GY;
 constexpr int MC_CUBES_PER_PLANE = MC_GX * MC_ITEMS * (MC_GY - 1);  // 3584 cubes per step of the march
 constexpr int MC_STAGE = 12288;                                     // LDS staging entries (48 KB)
 constexpr int MC_FLUSH_AT = MC_STAGE - 2 * MC_CUBES_PER_PLANE;      // see the flush decision below
-constexpr int MC_AHEAD = 6;                                         // even: the LDS double buffers are indexed by the ring slot's parity
+constexpr int MC_AHEAD = 4;   // even (LDS double buffers are indexed by the ring slot's parity).  6 needs 67 VGPRs: 3 spills, one
+                              // of them reloaded -- behind an s_waitcnt vmcnt(0), i.e. behind all its prefetches -- by the logic wave every step
 constexpr bool MC_MARCH0 = true;   // march along axis 0, thread rows = adjacent rows of axis 1 (false: the other way round; same speed)
 constexpr int MC_LOGIC_WAVE = MC_STREAM_THREADS / 64 - 1;           // second half of the halo row: owns no cubes
 static_assert(MC_GX == 128 && MC_ITEMS == 4 && 8 * (MC_GY - 1) <= 64 && MC_AHEAD % 2 == 0, "two wavefronts per row, four voxels per lane");
