@@ -389,6 +389,45 @@ def case_train_step(name):
     print(name, "loss", float(out["loss"]), "tensors", sum(1 for _ in m.named_parameters()))
 
 
+def case_train_step_full(name):
+    """(f)-2 at BASELINE's full training shape: the UNMODIFIED reference's NeRFModel.training_step on 2048 rays of a
+    bench view, 8x256 coarse + fine, 64 + 128 samples (one 2048-ray chunk, train() mode, perturb off, noise 0), then
+    loss.backward() -- 524 288 MLP evaluations through torch autograd on the CPU (~20 GB of activations, minutes).
+    The 48 gradient tensors (1.19 M values) are stored as digests (tests/helpers.py::grad_digest), the weights as the
+    scene seed."""
+    import time
+    from tests.helpers import grad_digest
+    nerf, models = ref_import.load()
+    hp = S.hparams(train_noise_std=0.0)
+    m = models.NeRFModel(hp)
+    w = gen_weights(S.SCENE_SEED, 0, 0, **mlp_kwargs(hp, "coarse"))
+    load_weights(m, "model_coarse.", w)
+    load_weights(m, "model_fine.", w)
+    m.train()
+    m.trainer = type("T", (), {"optimizers": [type("O", (), {"param_groups": [{"lr": 5e-3}]})()]})()
+    rays = 2048
+    o, d, idx = lego_rays(rays, view=0, stride=311)
+    target = torch.rand(rays, 3, generator=torch.Generator().manual_seed(11))
+    batch = dict(ray_origins=o[None], ray_directions=d[None], ray_targets=target[None], ray_bounds=torch.tensor([[2.0, 6.0]]))
+    t0 = time.perf_counter()
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    res = dict(origin=o.reshape(3).numpy(), directions=d.numpy(), targets=target.numpy(), ray_index=idx.numpy(),
+               loss=np.float64(float(out["loss"])), seed=S.SCENE_SEED, reference_seconds=np.float64(dt),
+               hparams_keys=np.array(list(hp.keys())), hparams_vals=np.array([repr(v) for v in hp.values()]))
+    for k, v in out["log"].items():
+        res["log." + k] = np.float32(float(v))
+    names = []
+    for k, p in m.named_parameters():
+        names.append(k)
+        for field, v in grad_digest(k, p.grad).items():
+            res[f"grad.{field}.{k}"] = v
+    res["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print(name, "loss", float(out["loss"]), "tensors", len(names), f"{dt:.1f} s")
+
+
 def case_buff_train_step(name):
     """(f)-3: the UNMODIFIED reference's BuFFModel.training_step (model_buff.py:79-124; TensorBoard loggers stubbed) on
     a fixed per-ray-origin batch, then loss.backward(): loss, logged values, the gradient of all 16 tensors."""
@@ -545,6 +584,8 @@ if __name__ == "__main__":
         case_buff("buff_fern")
     elif "--buff-tree" in sys.argv:
         case_buff_tree("buff_tree")
+    elif "--train-step-full" in sys.argv:
+        case_train_step_full("train_step_full")
     elif "--train-step" in sys.argv:
         case_train_step("train_step")
     elif "--buff-train-step" in sys.argv:

@@ -1,6 +1,7 @@
 """Shared helpers for the parity tests (test infrastructure)."""
 import ast
 import os
+import zlib
 
 import numpy as np
 
@@ -66,3 +67,41 @@ def well_conditioned_rays(g):
         return np.ones(g["coarse.acc_map"].shape, dtype=bool)
     acc = g["coarse.acc_map"]
     return ~((acc > 0) & (acc < 5e-3))    # exactly-empty rays (all coarse weights 0) are perfectly stable
+
+
+def grad_digest(name, grad):
+    """Compact fingerprint of one gradient tensor (a 1.19 M-parameter gradient set would be a 4.8 MB fixture): fp64 sum,
+    L2 norm, largest magnitude, the projection onto a standard-normal vector seeded by the tensor's NAME (numpy PCG64),
+    and <= 512 evenly strided entries.  An error vector e moves the projection by ~ |e|_2 * N(0, 1), the sum by
+    <= |e|_2 * sqrt(n), and shows up entry by entry in the sample.  Shared by tests/golden/make_golden.py (reference
+    side) and tests/test_gpu_train.py (HIP side)."""
+    g = np.asarray(grad.detach().cpu().numpy() if hasattr(grad, "detach") else grad, dtype=np.float64).reshape(-1)
+    n = g.size
+    vec = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()))).standard_normal(n)
+    idx = np.unique(np.linspace(0, n - 1, min(n, 512)).astype(np.int64))
+    return {"sum": np.float64(g.sum()), "l2": np.float64(np.sqrt((g * g).sum())), "max": np.float64(np.abs(g).max()),
+            "proj": np.float64((g * vec).sum()), "sample": g[idx].astype(np.float32), "numel": np.int64(n)}
+
+
+def check_grad_digests(g, grads, tol, dump=None):
+    """Compare gradient tensors with the digests of a `*_full` fixture (tests/helpers.py::grad_digest): every strided
+    sample entry within tol * max|g|, the name-seeded random projection within 4 tol * |g|_2 (an error vector e moves
+    it by ~ |e|_2 N(0,1)), the L2 norm within tol.  Returns the worst relative errors (sample, projection, norm)."""
+    worst = [0.0, 0.0, 0.0]
+    report = {}
+    for name in (str(n) for n in g["names"]):
+        got = grad_digest(name, grads[name])
+        ref = {f: g[f"grad.{f}.{name}"] for f in ("sum", "l2", "max", "proj", "sample", "numel")}
+        assert int(got["numel"]) == int(ref["numel"]), name
+        e_sample = float(np.abs(got["sample"].astype(np.float64) - ref["sample"].astype(np.float64)).max() / ref["max"])
+        e_proj = float(abs(got["proj"] - ref["proj"]) / ref["l2"])
+        e_l2 = float(abs(got["l2"] - ref["l2"]) / ref["l2"])
+        report[name] = (e_sample, e_proj, e_l2)
+        worst = [max(a, b) for a, b in zip(worst, (e_sample, e_proj, e_l2))]
+    if dump:
+        import json
+        with open(dump, "w") as f:
+            json.dump({"worst": worst, "per_tensor": report}, f, indent=1)
+    for name, (e_sample, e_proj, e_l2) in report.items():
+        assert e_sample <= tol and e_proj <= 4 * tol and e_l2 <= tol, (name, e_sample, e_proj, e_l2, tol)
+    return worst

@@ -11,6 +11,9 @@ from tests.helpers import O, S
 
 pytestmark = pytest.mark.gpu
 
+# worst relative error of a gradient entry / projection / norm against the reference's full-size training step
+FULL_SIZE_GRAD_TOL = 2e-3
+
 SHAPES = [
     dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
     dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4),
@@ -333,6 +336,41 @@ def test_training_step_against_the_reference_golden():
         ref = torch.from_numpy(g["grad." + name])
         assert p.grad is not None and p.grad.shape == ref.shape, name
         assert _rel(p.grad, ref) < 2e-3, (name, _rel(p.grad, ref))
+
+
+def test_full_size_training_step_against_the_reference_golden():
+    """NeRFModel.training_step at BASELINE's training shape -- 2048 rays, 8x256 coarse + fine, 64 + 128 samples: 524 288
+    MLP evaluations, three 128-sample tiles per persistent workgroup, split-over-samples weight-gradient GEMMs -- against
+    the UNMODIFIED reference's training_step + loss.backward() at that size (fixture tests/golden/train_step_full.npz:
+    loss, logged values, digests of all 48 gradient tensors; tests/helpers.py::grad_digest).  The same fixture pins the
+    oracle's autograd on the CPU to 1e-5 (tests/test_oracle_golden.py)."""
+    import os
+    from tests.helpers import check_grad_digests, gen_weights, golden_hparams, load_golden, mlp_kwargs
+    from nerfmeshes_amd import models
+    g = load_golden("train_step_full")
+    hp = golden_hparams(g)
+    model = models.NeRFModel(hp)
+    w = gen_weights(int(g["seed"]), 0, 0, **mlp_kwargs(hp, "coarse"))
+    state = model.state_dict()
+    for prefix in ("model_coarse.", "model_fine."):
+        for k, v in w.items():
+            assert state[prefix + k].shape == v.shape, k
+            state[prefix + k] = torch.from_numpy(np.array(v))
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    batch = dict(ray_origins=torch.from_numpy(g["origin"])[None, None], ray_directions=torch.from_numpy(g["directions"])[None],
+                 ray_targets=torch.from_numpy(g["targets"])[None], ray_bounds=torch.tensor([[2.0, 6.0]]))
+    out = model.training_step(batch, 0)
+    out["loss"].backward()
+    ref_loss = float(g["loss"])
+    assert abs(float(out["loss"].detach()) - ref_loss) < 1e-4 * ref_loss, (float(out["loss"].detach()), ref_loss)
+    for key in ("train/loss", "train/coarse_loss", "train/coarse_psnr", "train/fine_loss", "train/fine_psnr"):
+        ref = float(g["log." + key])
+        assert abs(float(out["log"][key]) - ref) < 2e-4 * max(1.0, abs(ref)), (key, float(out["log"][key]), ref)
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    dump = os.environ.get("NM_TEST_DUMP_DIR")
+    check_grad_digests(g, grads, tol=FULL_SIZE_GRAD_TOL, dump=os.path.join(dump, "train_step_full_errors.json") if dump else None)
 
 
 @pytest.mark.parametrize("out_f,stride,in_f", [(256, 256, 256), (256, 64, 63), (128, 256, 256), (128, 128, 128),

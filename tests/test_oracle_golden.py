@@ -292,17 +292,11 @@ def _train_step_golden():
     return g, hp, params, grads
 
 
-def test_training_step_loss_and_gradients_match_reference():
-    """(f)-2: autograd over the oracle chain reproduces the UNMODIFIED reference's training_step -- loss (with its
-    float batch_count over a ragged second chunk) and the gradient of all 32 tensors.  This pins the ground truth the
-    GPU gradient tests (tests/test_gpu_train.py) are measured against."""
-    g, hp, params, grads = _train_step_golden()
+def _oracle_training_step(hp, wc, wf, o, d, tgt):
+    """NeRFModel.training_step (model_nerf.py:88-151) as autograd over the oracle chain: chunks of nerf.train.chunksize,
+    FLOAT batch_count; returns (loss, coarse_loss / batch_count, fine_loss / batch_count)."""
     sc, sf, rs = specs_from_hparams(hp)
     rs = O.RenderSpec(num_coarse=rs.num_coarse, num_fine=rs.num_fine, training=True)
-    w = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    wc = {k[len("model_coarse."):]: v for k, v in w.items() if k.startswith("model_coarse.")}
-    wf = {k[len("model_fine."):]: v for k, v in w.items() if k.startswith("model_fine.")}
-    o, d, tgt = torch.from_numpy(g["origin"])[None], torch.from_numpy(g["directions"]), torch.from_numpy(g["targets"])
     chunk = int(hp["nerf.train.chunksize"])
     batch_count = d.shape[0] / chunk
     coarse_loss, fine_loss = 0, 0
@@ -321,18 +315,54 @@ def test_training_step_loss_and_gradients_match_reference():
         bf = O.composite(net(wf, sf, t_f), t_f, dd, rs)
         coarse_loss = coarse_loss + torch.nn.functional.mse_loss(bc["rgb_map"], tt)
         fine_loss = fine_loss + torch.nn.functional.mse_loss(bf["rgb_map"], tt)
-    loss = coarse_loss / batch_count + fine_loss / batch_count
+    return coarse_loss / batch_count + fine_loss / batch_count, coarse_loss / batch_count, fine_loss / batch_count
+
+
+def test_training_step_loss_and_gradients_match_reference():
+    """(f)-2: autograd over the oracle chain reproduces the UNMODIFIED reference's training_step -- loss (with its
+    float batch_count over a ragged second chunk) and the gradient of all 32 tensors.  This pins the ground truth the
+    GPU gradient tests (tests/test_gpu_train.py) are measured against."""
+    g, hp, params, grads = _train_step_golden()
+    w = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    wc = {k[len("model_coarse."):]: v for k, v in w.items() if k.startswith("model_coarse.")}
+    wf = {k[len("model_fine."):]: v for k, v in w.items() if k.startswith("model_fine.")}
+    o, d, tgt = torch.from_numpy(g["origin"])[None], torch.from_numpy(g["directions"]), torch.from_numpy(g["targets"])
+    loss, coarse_loss, fine_loss = _oracle_training_step(hp, wc, wf, o, d, tgt)
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6 * float(g["loss"])
     # reference quirk (model_nerf.py:127-137): `loss = coarse_loss` aliases the tensor and `loss += fine_loss` adds in
     # place, so the LOGGED train/coarse_loss is the total loss, while train/coarse_psnr was taken before the add
     assert abs(float(g["log.train/coarse_loss"]) - float(g["loss"])) <= 1e-7
-    assert abs(float(O.mse2psnr((coarse_loss / batch_count).detach())) - float(g["log.train/coarse_psnr"])) <= 1e-4
-    assert abs(float((fine_loss / batch_count).detach()) - float(g["log.train/fine_loss"])) <= 1e-6
+    assert abs(float(O.mse2psnr(coarse_loss.detach())) - float(g["log.train/coarse_psnr"])) <= 1e-4
+    assert abs(float(fine_loss.detach()) - float(g["log.train/fine_loss"])) <= 1e-6
     for k, ref in grads.items():
         got = w[k].grad
         assert got is not None and got.shape == ref.shape, k
         assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
+
+
+def test_full_size_training_step_matches_reference():
+    """(f)-2 at BASELINE's training shape: 2048 rays x (64 + 192) evaluations of the 8x256 networks -- autograd over the
+    oracle chain against the UNMODIFIED reference's training_step + backward (fixture train_step_full.npz: loss, logged
+    values, digests of the 48 gradient tensors).  ~20 GB of CPU activations, ~20 s; skipped on hosts without the memory."""
+    import psutil
+    if psutil.virtual_memory().available < 40 << 30:
+        pytest.skip("needs ~20 GB of host memory for the autograd tape of 524 288 MLP evaluations")
+    from tests.helpers import gen_weights, mlp_kwargs
+    g = load_golden("train_step_full")
+    hp = golden_hparams(g)
+    base = gen_weights(int(g["seed"]), 0, 0, **mlp_kwargs(hp, "coarse"))
+    wc = {k: torch.from_numpy(np.array(v)).requires_grad_(True) for k, v in base.items()}
+    wf = {k: torch.from_numpy(np.array(v)).requires_grad_(True) for k, v in base.items()}
+    o, d, tgt = torch.from_numpy(g["origin"])[None], torch.from_numpy(g["directions"]), torch.from_numpy(g["targets"])
+    loss, coarse_loss, fine_loss = _oracle_training_step(hp, wc, wf, o, d, tgt)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6 * float(g["loss"])
+    assert abs(float(fine_loss.detach()) - float(g["log.train/fine_loss"])) <= 1e-6
+    grads = {"model_coarse." + k: v.grad for k, v in wc.items() if v.grad is not None}
+    grads.update({"model_fine." + k: v.grad for k, v in wf.items() if v.grad is not None})
+    from tests.helpers import check_grad_digests
+    check_grad_digests(g, grads, tol=1e-5)
 
 
 def test_buff_training_step_loss_and_gradients_match_reference():
