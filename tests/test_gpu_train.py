@@ -12,7 +12,7 @@ from tests.helpers import O, S
 pytestmark = pytest.mark.gpu
 
 # worst relative error of a gradient entry / projection / norm against the reference's full-size training step
-FULL_SIZE_GRAD_TOL = 2e-3
+FULL_SIZE_GRAD_TOL = 1e-3   # measured worst: entry 1.6e-4, projection 1.7e-4, norm 5.8e-5 (profiles/r02_raw/train_step_full_errors.json)
 
 SHAPES = [
     dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
