@@ -350,6 +350,13 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
 
+    # stdout carries the ONE JSON line and nothing else: whatever native libraries print there (RCCL's version banner
+    # at communicator creation / teardown, which lands AFTER the line) is sent to stderr by pointing fd 1 at fd 2 and
+    # keeping the real stdout for the final write
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -484,7 +491,8 @@ def main():
             except Exception as e:  # the headline line must not depend on a secondary figure
                 out[name] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -61,7 +61,9 @@ def test_bench_rccl_leg_on_one_rank():
     and the line says how many ranks the collective saw."""
     r = _torchrun(1, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "1", "--headline-only")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    printed = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, f"stdout must carry the ONE JSON line only (RCCL prints its banner there): {printed}"
+    line = json.loads(printed[0])
     assert line["n_gpus"] == 1 and line["rccl"]["backend"] == "nccl" and line["rccl"]["ranks_in_all_gather"] == 1
     assert line["rccl"]["slots_match_rank_checksums"] is True
     assert line["value"] > 1e5 and 0.5 < line["roofline"]["frac"] < 1.0
