@@ -32,7 +32,6 @@ Weights are passed as a plain dict keyed exactly like the reference
 `FlexibleNeRFModel.state_dict()` (`layer1.weight`, `layers_xyz.3.bias`, ...).
 """
 from dataclasses import dataclass
-import math
 
 import numpy as np
 import torch

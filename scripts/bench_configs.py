@@ -6,7 +6,7 @@ Prints one JSON object."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from nerfmeshes_amd import hip_ops, models, synthetic as S
 
 

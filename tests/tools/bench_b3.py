@@ -3,7 +3,7 @@ Prints one JSON object (kept under profiles/)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from nerfmeshes_amd import hip_ops, synthetic as S
 from oracle import nerf_oracle as O, parity
 from tests.helpers import load_golden

@@ -1,7 +1,7 @@
 """Find the rays where HIP and oracle renders differ most and explain why (debug aid, GPU box)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
+import torch
 from nerfmeshes_amd import hip_ops as ops, synthetic as S
 from oracle import nerf_oracle as O
 torch.set_num_threads(32)

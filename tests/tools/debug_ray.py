@@ -1,6 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
+import torch
 from nerfmeshes_amd import hip_ops as ops, synthetic as S
 from oracle import nerf_oracle as O
 from tests.helpers import golden_hparams, golden_weights, load_golden, specs_from_hparams
