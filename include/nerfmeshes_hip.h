@@ -324,6 +324,20 @@ int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const float* d_ori
                          const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,
                          int32_t samples, int32_t tie_order, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream);
 
+/* The `tree.use_random_sampling` branch of the same function (src/nerf/tree.py:280-297, :337-341) as a function of the
+ * draws: d_u_pick (rays,samples) DOUBLE = the uniforms torch.multinomial(weights, samples, replacement=True) consumes
+ * (weights 1 for crossed voxels, 1e-12 otherwise: an inverse-CDF pick among the crossed voxels in index order, decided
+ * in fp32 as ATen does), d_u_pos (rays,samples) float = torch.rand_like(values_min) (the position inside the drawn
+ * voxel's [t_enter, t_exit]).  Outputs as above; given the reference's own draws they equal its output bit for bit on
+ * every ray that crosses a voxel (one exception: a draw u below the 1e-12 weights' own share, u < 1.7e-9, selects a
+ * NON-crossed voxel in the reference and the first crossed one here).  Rows of rays that cross nothing are zero-filled (d_mask 0): the reference samples
+ * arbitrary voxels there, its caller overwrites those depths (src/models/model_buff.py:53) and nothing reads the ids.
+ * Synchronises the stream (overflow check). */
+int nm_buff_intersect_random(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                             const float* d_dirs, float near_, float far_, const double* d_u_pick,
+                             const float* d_u_pos, int64_t rays, int32_t samples, float* d_z, int64_t* d_idx,
+                             uint8_t* d_mask, void* stream);
+
 /* TreeSampling.ray_batch_integration (src/nerf/tree.py:177-206), training-time tree maintenance: the samples of
  * the rays that hit the tree -- d_idx / d_weights / d_mask_weights, `count` elements each (= indices[mask],
  * weights[mask], mask_weights[mask] flattened) -- update the running voxel weights d_memm (nvox,) in place:

@@ -120,6 +120,8 @@ SIGNATURES = {
                                     C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_buff_intersect_ex": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
                                        C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nm_buff_intersect_random": (C.c_int, [c_void_p, C.c_int32, c_void_p, C.c_int, c_void_p, C.c_float, C.c_float, c_void_p,
+                                           c_void_p, C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_np_stats_workspace_bytes": (C.c_int64, [C.c_int64]),
     "nm_np_stats": (C.c_int, [c_void_p, C.c_int64, c_void_p, c_float_p, c_void_p]),
     "nm_tree_workspace_bytes": (C.c_int64, [C.c_int32]),

@@ -159,6 +159,109 @@ __global__ __launch_bounds__(256) void buff_intersect_kernel(const float* __rest
 }
 
 
+// ---- `tree.use_random_sampling` branch (tree.py:280-297, :337-341) as a function of the draws -------------------------
+// The reference gives crossed voxels weight 1 and all others 1e-12, draws S voxels per ray with
+// torch.multinomial(weights, S, replacement=True) and a depth uniformly inside each drawn voxel's [t_enter, t_exit].
+// torch.multinomial with replacement is an inverse-CDF sampler (ATen/native/cpu/MultinomialKernel.cpp): the fp32
+// running sum of the row divided by its total, one double u per sample, lower-bound search for the first category
+// whose cumulative probability is >= u.  The running sum is the number of crossed voxels so far (1e-12 is absorbed
+// once the sum reaches 1), so the draw is the c-th crossed voxel in index order with c the smallest count whose
+// fp32 quotient c / K is >= u.  The draws are the caller's (u_pick (R,S) double, u_pos (R,S) float: torch's
+// generator), the arithmetic is the reference's: given the reference's own draws the depths and voxel ids are its
+// output bit for bit (tests/golden/buff_random.npz) -- except for a draw below the cumulative share of the 1e-12
+// weights in front of the first crossed voxel (u < 1.7e-9), where the reference returns a voxel the ray does not cross
+// and this kernel the first crossed one.  Rows of rays that cross nothing are zero-filled: the
+// reference samples arbitrary voxels there, BuFFModel.forward overwrites those depths and nothing reads the ids.
+__global__ __launch_bounds__(256) void buff_random_kernel(const float* __restrict__ voxels, int nvox,
+                                                          const float* __restrict__ origins, int origins_per_ray,
+                                                          const float* __restrict__ dirs, float near_, float far_,
+                                                          const double* __restrict__ u_pick, const float* __restrict__ u_pos,
+                                                          int64_t rays, int samples, float* __restrict__ z_out,
+                                                          int64_t* __restrict__ idx_out, uint8_t* __restrict__ mask_out,
+                                                          int* __restrict__ overflow) {
+    __shared__ float h_tmin[4][BUFF_MAX_HITS], h_tmax[4][BUFF_MAX_HITS];
+    __shared__ int h_id[4][BUFF_MAX_HITS];
+    __shared__ float p_z[4][BUFF_MAX_SAMPLES];
+    __shared__ int p_vid[4][BUFF_MAX_SAMPLES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + wv; ray < rays; ray += (int64_t)gridDim.x * 4) {
+        const float* o = origins + (origins_per_ray ? 3 * ray : 0);
+        float inv[3], org[3];
+        int sgn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            org[a] = o[a];
+            inv[a] = 1.0f / dirs[3 * ray + a];
+            sgn[a] = inv[a] < 0.0f ? 1 : 0;
+        }
+        // ---- slab test over all boxes (the expressions of buff_intersect_kernel), crossed ones compacted in index order
+        int K = 0;
+        for (int base = 0; base < nvox; base += 64) {
+            const int n = base + lane;
+            bool valid = false;
+            float tmin = 0.0f, tmax = 0.0f;
+            if (n < nvox) {
+                const float* b = voxels + 6 * (int64_t)n;
+                float lo_t[3], hi_t[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    lo_t[a] = (b[3 * sgn[a] + a] - org[a]) * inv[a];
+                    hi_t[a] = (b[3 * (1 - sgn[a]) + a] - org[a]) * inv[a];
+                }
+                valid = (lo_t[0] <= hi_t[1]) && (lo_t[1] <= hi_t[0]);
+                tmin = lo_t[1] > lo_t[0] ? lo_t[1] : lo_t[0];
+                tmax = hi_t[1] < hi_t[0] ? hi_t[1] : hi_t[0];
+                valid = valid && (tmin <= hi_t[2]) && (lo_t[2] <= tmax);
+                tmin = lo_t[2] > tmin ? lo_t[2] : tmin;
+                tmax = hi_t[2] < tmax ? hi_t[2] : tmax;
+                valid = valid && (tmin >= near_) && (tmax <= far_);
+            }
+            const unsigned long long bal = __ballot(valid);
+            if (valid) {
+                const int pos = K + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < BUFF_MAX_HITS) { h_tmin[wv][pos] = tmin; h_tmax[wv][pos] = tmax; h_id[wv][pos] = n; }
+            }
+            K += __popcll(bal);
+        }
+        if (K > BUFF_MAX_HITS) { if (lane == 0) atomicExch(overflow, 1); K = BUFF_MAX_HITS; }
+        __builtin_amdgcn_wave_barrier();
+        // ---- draw: voxel by inverse CDF over the crossed ones, depth uniformly inside it
+        for (int j = lane; j < samples; j += 64) {
+            float z = 0.0f;
+            int vid = 0;
+            if (K > 0) {
+                const double u = u_pick[ray * samples + j];
+                const float fk = (float)K;
+                int lo = 1, hi = K;                   // smallest count c with fp32(c / K) >= u; fp32(K / K) = 1 > u
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((double)((float)mid / fk) < u) lo = mid + 1; else hi = mid;
+                }
+                const float a = h_tmin[wv][lo - 1], b = h_tmax[wv][lo - 1];
+                z = a + (b - a) * u_pos[ray * samples + j];       // two roundings after the subtraction, as torch
+                vid = h_id[wv][lo - 1];
+            }
+            p_z[wv][j] = z;
+            p_vid[wv][j] = vid;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- ascending sort of the depths (stable; the reference's unstable sort differs only on exact ties)
+        for (int j = lane; j < samples; j += 64) {
+            const float zj = p_z[wv][j];
+            int rank = 0;
+            for (int k = 0; k < samples; ++k) {
+                const float zk = p_z[wv][k];
+                rank += (zk < zj || (zk == zj && k < j)) ? 1 : 0;
+            }
+            z_out[ray * samples + rank] = zj;
+            idx_out[ray * samples + rank] = p_vid[wv][j];
+        }
+        if (lane == 0) mask_out[ray] = K > 0 ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
 // ---- opt-in: voxel ids with the reference's OWN tie order ---------------------------------------------------------
 // The reference calls torch.sort three times with its unstable default (tree.py:300, :306, :335).  On the CPU build it
 // was written against (and the golden vectors were generated with: torch 2.10, tests/golden/make_golden.py) that is
@@ -530,4 +633,30 @@ extern "C" int nm_buff_intersect(const float* d_voxels, int32_t nvox, const floa
                                  int32_t samples, float* d_z, int64_t* d_idx, uint8_t* d_mask, void* stream_) {
     return nm_buff_intersect_ex(d_voxels, nvox, d_origins, origins_per_ray, d_dirs, near_, far_, d_u, rays, samples,
                                 NM_TIES_STABLE, d_z, d_idx, d_mask, stream_);
+}
+
+extern "C" int nm_buff_intersect_random(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
+                                        const float* d_dirs, float near_, float far_, const double* d_u_pick,
+                                        const float* d_u_pos, int64_t rays, int32_t samples, float* d_z, int64_t* d_idx,
+                                        uint8_t* d_mask, void* stream_) {
+    NM_REQUIRE(d_voxels && d_origins && d_dirs && d_u_pick && d_u_pos && d_z && d_idx && d_mask, "bad argument");
+    NM_REQUIRE(nvox > 0 && samples > 0 && samples <= BUFF_MAX_SAMPLES, "buff_intersect_random: samples must be in [1, 512]");
+    if (rays <= 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int* d_overflow = overflow_flag();
+    NM_REQUIRE(d_overflow != nullptr, "buff_intersect_random: cannot allocate the overflow flag");
+    const int64_t blocks = (rays + 3) / 4;
+    hipLaunchKernelGGL(buff_random_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, d_voxels,
+                       nvox, d_origins, origins_per_ray, d_dirs, near_, far_, d_u_pick, d_u_pos, rays, samples, d_z, d_idx,
+                       d_mask, d_overflow);
+    NM_HIP_CHECK(hipGetLastError());
+    int h = 0;
+    NM_HIP_CHECK(hipMemcpyAsync(&h, d_overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+    NM_HIP_CHECK(hipStreamSynchronize(stream));
+    if (h) {
+        NM_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
+        set_error("buff_intersect_random: a ray crosses more than 512 voxels (BUFF_MAX_HITS)");
+        return 4;
+    }
+    return 0;
 }

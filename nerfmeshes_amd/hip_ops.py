@@ -326,6 +326,33 @@ def buff_intersect(voxels, origins, dirs, near, far, samples, ids="stable"):
     return z, idx, mask.bool()
 
 
+def buff_intersect_random(voxels, origins, dirs, near, far, u_pick, u_pos):
+    """TreeSampling.batch_ray_voxel_intersect with `tree.use_random_sampling` (tree.py:280-297) on the GPU
+    (nm_buff_intersect_random), as a function of the draws: u_pick (R,S) float64 -- what torch.multinomial consumes,
+    one double per sample -- and u_pos (R,S) float32 (torch.rand_like).  Returns (z (R,S) f32 sorted, voxel ids (R,S)
+    i64, ray_mask (R,) bool); rows of rays that cross no voxel are zero-filled (the caller overwrites them)."""
+    lib = _lib.load()
+    voxels = _dev32(voxels, name="voxels")
+    dev = voxels.device
+    origins, dirs = _dev32(origins, dev, "origins").reshape(-1, 3), _dev32(dirs, dev, "dirs").reshape(-1, 3)
+    rays = dirs.shape[0]
+    if not (isinstance(u_pick, torch.Tensor) and u_pick.is_cuda):
+        raise _lib.HipLibraryError("u_pick must live in GPU memory; there is no CPU path")
+    u_pick = u_pick.detach().to(device=dev, dtype=torch.float64).contiguous()
+    u_pos = _dev32(u_pos, dev, "u_pos")
+    if u_pick.dim() != 2 or u_pick.shape[0] != rays or tuple(u_pos.shape) != tuple(u_pick.shape):
+        raise ValueError(f"u_pick / u_pos must both be (rays, samples) = ({rays}, S); got {tuple(u_pick.shape)}, {tuple(u_pos.shape)}")
+    samples = u_pick.shape[1]
+    z = torch.empty(rays, samples, dtype=torch.float32, device=dev)
+    idx = torch.empty(rays, samples, dtype=torch.int64, device=dev)
+    mask = torch.empty(rays, dtype=torch.uint8, device=dev)
+    check(lib.nm_buff_intersect_random(_ptr(voxels), voxels.shape[0], _ptr(origins),
+                                       int(origins.shape[0] == rays and rays > 1), _ptr(dirs), float(near), float(far),
+                                       _ptr(u_pick), _ptr(u_pos), rays, samples, _ptr(z), _ptr(idx), _ptr(mask), _stream()),
+          "nm_buff_intersect_random")
+    return z, idx, mask.bool()
+
+
 def tree_integrate(memm, counter, indices, weights, mask_weights):
     """TreeSampling.ray_batch_integration's arithmetic (nm_tree_integrate): updates `memm` (N,) in place from the
     (K,S) voxel ids / weights / visibility masks of the rays that hit the tree."""

@@ -117,7 +117,13 @@ class TreeSampling:
     def batch_ray_voxel_intersect(self, origins, dirs, near, far, samples_count=64):
         """(z_vals (R,S) f32, voxel indices (R,S) i64, ray_mask (R,) bool) -- tree.py:215-343."""
         if self.config.tree.use_random_sampling:
-            raise NotImplementedError("tree.use_random_sampling (multinomial branch) is not implemented on the HIP path")
+            # tree.py:280-297: voxels drawn with torch.multinomial (one double per sample from the generator), depths
+            # with torch.rand_like; here the draws come from torch's generator of the voxels' device
+            dev = self.voxels.device
+            shape = (dirs.reshape(-1, 3).shape[0], int(samples_count))
+            u_pick = torch.rand(shape, dtype=torch.float64, device=dev)
+            u_pos = torch.rand(shape, dtype=torch.float32, device=dev)
+            return hip_ops.buff_intersect_random(self.voxels, origins, dirs, float(near), float(far), u_pick, u_pos)
         return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count),
                                       ids=getattr(self, "tie_order", "stable"))
 

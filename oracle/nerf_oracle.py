@@ -402,6 +402,58 @@ def buff_intersect(voxels, origins, dirs, near, far, samples_count, ties="stable
     return z, vox.gather(-1, zorder), ray_mask
 
 
+def _buff_slab_test(voxels, origins, dirs, near, far):
+    """The slab test both sampler branches share (tree.py:226-271): (tmin, tmax, mask), each (R,N)."""
+    voxels, origins, dirs = _t(voxels), _t(origins), _t(dirs)
+    R, N = dirs.shape[0], voxels.shape[0]
+    inv = 1 / dirs
+    signs = (inv < 0).long()
+    b = voxels.transpose(0, 1)
+    ax = torch.arange(3)
+
+    def pick(s):
+        return b[s[:, None, :].expand(R, N, 3), torch.arange(N)[None, :, None].expand(R, N, 3), ax[None, None, :].expand(R, N, 3)]
+
+    o = origins[:, None, :]
+    tvmin = (pick(signs) - o) * inv[:, None, :]
+    tvmax = (pick(1 - signs) - o) * inv[:, None, :]
+    mask = (tvmin[..., 0] <= tvmax[..., 1]) & (tvmin[..., 1] <= tvmax[..., 0])
+    tmin = torch.where(tvmin[..., 1] > tvmin[..., 0], tvmin[..., 1], tvmin[..., 0])
+    tmax = torch.where(tvmax[..., 1] < tvmax[..., 0], tvmax[..., 1], tvmax[..., 0])
+    mask = mask & (tmin <= tvmax[..., 2]) & (tvmin[..., 2] <= tmax)
+    tmin = torch.where(tvmin[..., 2] > tmin, tvmin[..., 2], tmin)
+    tmax = torch.where(tvmax[..., 2] < tmax, tvmax[..., 2], tmax)
+    mask = mask & (tmin >= near) & (tmax <= far)
+    return tmin, tmax, mask
+
+
+def buff_intersect_random(voxels, origins, dirs, near, far, u_pick, u_pos):
+    """TreeSampling.batch_ray_voxel_intersect, `tree.use_random_sampling` branch (tree.py:280-297, :337-341), as a
+    function of the draws: u_pick (R,S) float64 = what `torch.multinomial(weights, S, replacement=True)` draws,
+    u_pos (R,S) float32 = `torch.rand_like(values_min)`.
+    torch.multinomial with replacement on the CPU (ATen/native/cpu/MultinomialKernel.cpp) is an inverse-CDF sampler:
+    per row the fp32 running sum of the weights divided by its total (last entry forced to 1), then per sample ONE
+    double from the generator and a lower-bound search -- the first category whose cumulative probability is >= u.
+    With weights 1 (crossed voxel) / 1e-12 (others) the running sum is the count of crossed voxels so far (1e-12 is
+    absorbed once the sum is >= 1), so the pick is the ceil(u K)-th crossed voxel in index order, decided in fp32
+    (`count / K` rounded).  Under one seed the reference's draws ARE `torch.rand(R * S, dtype=float64)` followed by
+    `torch.rand(R, S)`: tests/golden/buff_random.npz pins this function to the unmodified reference bit for bit.
+    Returns (z (R,S), voxel ids (R,S) int64, ray_mask (R,)); rows of rays that cross no voxel are unspecified (the
+    reference samples all voxels there and BuFFModel.forward overwrites those rows, model_buff.py:51-53)."""
+    tmin, tmax, mask = _buff_slab_test(voxels, origins, dirs, near, far)
+    ray_mask = mask.sum(-1) > 0
+    weights = torch.ones_like(tmin)
+    weights[~mask] = 1e-12
+    cum = torch.cumsum(weights, -1)                    # fp64 accumulation rounded per element: the counts, exactly
+    cum = cum / cum[..., -1:]
+    cum[..., -1] = 1.0
+    pick = torch.searchsorted(cum.double(), torch.as_tensor(np.asarray(u_pick), dtype=torch.float64).contiguous(), right=False).clamp_(max=tmin.shape[1] - 1)
+    vmin, vmax = tmin.gather(-1, pick), tmax.gather(-1, pick)
+    z = vmin + (vmax - vmin) * _t(u_pos)
+    z, order = torch.sort(z, dim=-1, stable=True)
+    return z, pick.gather(-1, order), ray_mask
+
+
 def buff_integrate(memm, counter, indices, weights, mask_weights):
     """(f)-3: TreeSampling.ray_batch_integration (tree.py:177-206): returns the updated voxel weights.
     indices (K,S) int64, weights / mask_weights (K,S): the rays that hit the tree."""

@@ -235,6 +235,41 @@ def case_buff(name):
     print(name, "hit rays", int(mask.sum()), "/", n, "acc", float(bundle.acc_map.mean()))
 
 
+def case_buff_random(name):
+    """R9, `tree.use_random_sampling` branch (tree.py:280-297): the UNMODIFIED reference's batch_ray_voxel_intersect
+    under torch.manual_seed(77), next to the draws it consumed -- torch.multinomial (with replacement, CPU) takes one
+    double per sample from the generator and `torch.rand_like` continues the stream, so under the same seed they are
+    torch.rand(R * S, dtype=float64) followed by torch.rand(R, S)."""
+    nerf, models = ref_import.load()
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2,
+                   dataset_type="colmap")
+    hp["tree.use_random_sampling"] = True
+    m = models.BuFFModel(hp).eval()
+    g = torch.Generator().manual_seed(22)
+    n, samples = 96, 192
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * (0.75 + 0.5 * torch.rand(n, 1, generator=g))
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 0.9
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    d[:6] = torch.nn.functional.normalize(o[:6], dim=-1)            # looking away: no voxel hit
+    torch.manual_seed(77)
+    u_pick = torch.rand(n * samples, dtype=torch.float64).reshape(n, samples)
+    u_pos = torch.rand(n, samples)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        z, idx, mask = m.tree.batch_ray_voxel_intersect(o, d, 0.0, 1.2, samples_count=samples)
+    torch.manual_seed(78)                                           # shared origin (1,3), as eval_nerf feeds it
+    u_pick1 = torch.rand(n * samples, dtype=torch.float64).reshape(n, samples)
+    u_pos1 = torch.rand(n, samples)
+    torch.manual_seed(78)
+    with torch.no_grad():
+        z1, idx1, mask1 = m.tree.batch_ray_voxel_intersect(o[30:31], d, 0.0, 1.2, samples_count=samples)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), origins=o.numpy(), directions=d.numpy(),
+                        voxels=m.tree.voxels.numpy(), u_pick=u_pick.numpy(), u_pos=u_pos.numpy(), z=z.numpy(),
+                        idx=idx.numpy(), mask=mask.numpy(), u_pick_shared=u_pick1.numpy(), u_pos_shared=u_pos1.numpy(),
+                        z_shared=z1.numpy(), idx_shared=idx1.numpy(), mask_shared=mask1.numpy())
+    print(name, "hit rays", int(mask.sum()), "/", n, "shared-origin hit rays", int(mask1.sum()))
+
+
 def case_buff_tree(name):
     """(f)-3: the reference's training-time tree maintenance -- three ray_batch_integration steps on the fresh
     12^3 tree, then two consolidate() rounds (filter by tree.eps, subdivide under tree.max_voxel_count)."""
@@ -582,6 +617,8 @@ if __name__ == "__main__":
         case_obj("export_obj")
     elif "--buff" in sys.argv:
         case_buff("buff_fern")
+    elif "--buff-random" in sys.argv:
+        case_buff_random("buff_random")
     elif "--buff-tree" in sys.argv:
         case_buff_tree("buff_tree")
     elif "--train-step-full" in sys.argv:

@@ -70,6 +70,68 @@ def test_buff_intersect_vs_oracle(pkg, rays, samples, nvox_side):
         assert np.array_equal(z2.cpu().numpy(), zr.numpy()) and np.array_equal(i2.cpu().numpy(), ir.numpy())
 
 
+def test_buff_random_branch_vs_reference_golden_and_oracle(pkg):
+    """R9 `tree.use_random_sampling` (tree.py:280-297) on the GPU: given the draws the UNMODIFIED reference consumed
+    (tests/golden/buff_random.npz) nm_buff_intersect_random returns its depths and voxel ids bit for bit on every ray
+    that crosses a voxel, zero-filled rows and mask 0 elsewhere; on a larger seeded problem it equals the oracle."""
+    g = load_golden("buff_random")
+    vox = torch.from_numpy(g["voxels"]).cuda()
+    d = torch.from_numpy(g["directions"]).cuda()
+    for o, suffix in ((g["origins"], ""), (g["origins"][30:31], "_shared")):
+        z, idx, mask = pkg["ops"].buff_intersect_random(vox, torch.from_numpy(o).cuda(), d, 0.0, 1.2,
+                                                        torch.from_numpy(g["u_pick" + suffix]).cuda(),
+                                                        torch.from_numpy(g["u_pos" + suffix]).cuda())
+        hit = g["mask" + suffix]
+        assert np.array_equal(mask.cpu().numpy(), hit)
+        assert np.array_equal(z.cpu().numpy()[hit], g["z" + suffix][hit]), "depths must be bit-identical"
+        assert np.array_equal(idx.cpu().numpy()[hit], g["idx" + suffix][hit]), "voxel ids must equal the reference's"
+        assert not z.cpu().numpy()[~hit].any() and not idx.cpu().numpy()[~hit].any()
+    gen = torch.Generator().manual_seed(8)
+    rays, samples = 2500, 65
+    voxels = O.buff_initial_voxels(0.0, 1.2, 7)
+    o = torch.nn.functional.normalize(torch.randn(rays, 3, generator=gen), dim=-1) * (0.7 + 0.6 * torch.rand(rays, 1, generator=gen))
+    dd = torch.nn.functional.normalize((torch.rand(rays, 3, generator=gen) - 0.5) - o, dim=-1)
+    u_pick = torch.rand(rays, samples, dtype=torch.float64, generator=gen)
+    u_pick[:, :4] = torch.tensor([1e-7, 1.0 - 2.0 ** -53, 0.5, 1.0 / 3.0], dtype=torch.float64)   # edges of the CDF, every ray
+    u_pos = torch.rand(rays, samples, generator=gen)
+    zo, io, mo = O.buff_intersect_random(voxels, o, dd, 0.0, 1.2, u_pick, u_pos)
+    z, idx, mask = pkg["ops"].buff_intersect_random(voxels.cuda(), o.cuda(), dd.cuda(), 0.0, 1.2, u_pick.cuda(), u_pos.cuda())
+    hit = mo.numpy()
+    assert 0 < int(hit.sum()) and np.array_equal(mask.cpu().numpy(), hit)
+    assert np.array_equal(z.cpu().numpy()[hit], zo.numpy()[hit])
+    assert np.array_equal(idx.cpu().numpy()[hit], io.numpy()[hit])
+
+
+def test_buff_model_with_random_sampling(pkg):
+    """BuFFModel with tree.use_random_sampling: forward runs on the HIP path (the draws come from torch's device
+    generator: reproducible under torch.manual_seed), every depth of a ray that hits the tree lies inside the voxel it is
+    attributed to, rays that miss fall back to the uniform intervals (model_buff.py:53)."""
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=96, num_fine=64, near=0.0, far=1.2, dataset_type="colmap")
+    hp["tree.use_random_sampling"] = True
+    model = pkg["models"].BuFFModel(hp).cuda().eval()
+    gen = torch.Generator().manual_seed(3)
+    rays = 333
+    o = torch.nn.functional.normalize(torch.randn(rays, 3, generator=gen), dim=-1) * (0.75 + 0.5 * torch.rand(rays, 1, generator=gen))
+    d = torch.nn.functional.normalize((torch.rand(rays, 3, generator=gen) - 0.5) * 0.9 - o, dim=-1)
+    o[:5] = torch.nn.functional.normalize(o[:5], dim=-1) * 1.3    # outside the voxel cube's circumsphere (0.6 sqrt 3) ...
+    d[:5] = torch.nn.functional.normalize(o[:5], dim=-1)          # ... looking away: these rays cross nothing
+    torch.manual_seed(11)
+    z, idx, mask = model.tree.batch_ray_voxel_intersect(o.cuda(), d.cuda(), 0.0, 1.2, samples_count=96)
+    torch.manual_seed(11)
+    z2, idx2, _ = model.tree.batch_ray_voxel_intersect(o.cuda(), d.cuda(), 0.0, 1.2, samples_count=96)
+    assert torch.equal(z, z2) and torch.equal(idx, idx2)
+    assert not bool(mask[:5].any()) and int(mask.sum()) > 200
+    tmin, tmax, hits = O._buff_slab_test(model.tree.voxels.cpu(), o, d, 0.0, 1.2)
+    m = mask.cpu()
+    assert torch.equal(m, hits.sum(-1) > 0)
+    lo, hi = tmin.gather(-1, idx.cpu()), tmax.gather(-1, idx.cpu())
+    assert bool(((z.cpu() >= lo) & (z.cpu() <= hi) & hits.gather(-1, idx.cpu()))[m].all())
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+    with torch.no_grad():
+        bundle = model.query((o.cuda(), d.cuda(), torch.tensor([0.0, 1.2])))
+    assert bundle.rgb_map.shape == (rays, 3) and bool(torch.isfinite(bundle.rgb_map).all())
+
+
 def test_buff_sampled_tree_reference_tie_order(pkg):
     """R9 end to end on the GPU: BuFFModel.forward in train mode with tree.tie_order = "reference" samples (nm_buff_intersect_ex,
     NM_TIES_REFERENCE), renders and integrates three ray batches; memm after every step and the consolidated voxel set

@@ -182,6 +182,56 @@ def test_export_obj_text_matches_reference(tmp_path):
     assert out.read_text() == ref
 
 
+def test_buff_random_branch_matches_reference():
+    """R9, `tree.use_random_sampling` (tree.py:280-297): given the draws the UNMODIFIED reference consumed under
+    torch.manual_seed(77 / 78) -- torch.rand(R * S, float64) for torch.multinomial, then torch.rand(R, S) -- the oracle
+    reproduces its depths and voxel ids bit for bit on every ray that crosses a voxel (both origin layouts); rows of
+    rays that cross nothing are unspecified (the reference samples arbitrary voxels, its caller overwrites them)."""
+    g = load_golden("buff_random")
+    for o, suffix in ((g["origins"], ""), (g["origins"][30:31], "_shared")):
+        z, idx, mask = O.buff_intersect_random(g["voxels"], o, g["directions"], 0.0, 1.2, g["u_pick" + suffix], g["u_pos" + suffix])
+        hit = g["mask" + suffix]
+        assert 0 < int(hit.sum()) < hit.size
+        assert np.array_equal(mask.numpy(), hit)
+        assert np.array_equal(z.numpy()[hit], g["z" + suffix][hit]), "depths must be bit-identical"
+        assert np.array_equal(idx.numpy()[hit], g["idx" + suffix][hit]), "voxel ids must be identical"
+        # every sample lies inside the voxel it is attributed to (unlike the deterministic branch's reference ids)
+        tmin, tmax, _ = O._buff_slab_test(g["voxels"], o, g["directions"], 0.0, 1.2)
+        lo, hi = tmin.gather(-1, idx), tmax.gather(-1, idx)
+        assert bool(((z >= lo) & (z <= hi))[torch.from_numpy(hit)].all())
+
+
+def test_multinomial_is_an_inverse_cdf_over_float64_draws():
+    """What oracle.buff_intersect_random (and the HIP kernel) rest on, pinned against torch itself: on the CPU
+    torch.multinomial(weights, S, replacement=True) under a seed picks, per sample, the first category whose fp32
+    cumulative probability is >= the next float64 of torch.rand under the same seed; torch.rand_like continues the
+    generator's stream afterwards."""
+    g = torch.Generator().manual_seed(4)
+    rows, cats, samples = 23, 1728, 48
+    hit = torch.rand(rows, cats, generator=g) < 0.02
+    hit[5] = False
+    hit[5, 1000] = True
+    hit[6] = True
+    weights = torch.ones(rows, cats)
+    weights[~hit] = 1e-12
+    torch.manual_seed(99)
+    picked = torch.multinomial(weights, samples, replacement=True)
+    after = torch.rand(rows, samples)
+    torch.manual_seed(99)
+    u = torch.rand(rows * samples, dtype=torch.float64).reshape(rows, samples)
+    assert torch.equal(torch.rand(rows, samples), after)
+    cum = torch.cumsum(weights, -1)
+    cum = cum / cum[:, -1:]
+    cum[:, -1] = 1.0
+    assert torch.equal(torch.searchsorted(cum.double(), u, right=False), picked)
+    count = hit.sum(-1, keepdim=True)
+    assert bool(hit.gather(-1, picked).all()), "a 1e-12 category was drawn"
+    # ... which is the ceil(u K)-th crossed voxel, decided on the fp32 quotient count / K (what the kernel evaluates)
+    rank = hit.long().cumsum(-1).gather(-1, picked)                     # 1-based rank of the pick among the crossed
+    q = lambda c: (c.float() / count.float()).double()
+    assert bool((q(rank) >= u).all()) and bool(((rank == 1) | (q(rank - 1) < u)).all())
+
+
 def test_buff_tree_maintenance_matches_reference(capsys):
     """(f)-3: oracle integration == the reference's memm after each step (same torch ops: exact); the host-side
     consolidate() of the product mirror reproduces the reference's voxel sets over two refinement rounds."""
