@@ -34,3 +34,33 @@ def test_no_cpu_fallback_in_product():
                 code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
                 code = re.sub(r'"""[\s\S]*?"""', "", code)
                 assert not bad.search(code), f"{f} references the oracle"
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Error convention of the boundary (int status, 0 = ok, + nm_last_error()): bad arguments are
+    rejected BEFORE any HIP call, so the checks run on a host without a GPU -- null buffers, sizes the kernels do not
+    support, and skimage's own message for a volume smaller than 2x2x2 (what the Python shim turns into its ValueError)."""
+    import ctypes as C
+    lib = _lib.load()
+    null = C.c_void_p(None)
+    one = C.c_void_p(8)                       # never dereferenced: validation fails first
+
+    def err():
+        return (lib.nm_last_error() or b"").decode()
+
+    v, f = C.c_int64(), C.c_int64()
+    assert lib.nm_mc_count(null, 4, 4, 4, 0.5, one, C.byref(v), C.byref(f), null) == 2 and "bad argument" in err()
+    assert lib.nm_mc_count(one, 1, 4, 4, 0.5, one, C.byref(v), C.byref(f), null) == 2
+    assert "Input array must be at least 2x2x2." in err()
+    assert lib.nm_mc_workspace_bytes(1, 4, 4) == 0 and lib.nm_mc_workspace_bytes(480, 480, 480) > 480 ** 3
+    assert lib.nm_buff_intersect_ex(null, 8, one, 0, one, 0.0, 1.0, one, 4, 16, 0, one, one, one, null) == 2
+    assert lib.nm_buff_intersect_ex(one, 8, one, 0, one, 0.0, 1.0, one, 4, 513, 0, one, one, one, null) == 2
+    assert "samples must be in [1, 512]" in err()
+    assert lib.nm_buff_intersect_ex(one, 8, one, 0, one, 0.0, 1.0, one, 4, 16, 7, one, one, one, null) == 2
+    assert "unknown tie order" in err()
+    assert lib.nm_buff_intersect_random(one, 8, one, 0, one, 0.0, 1.0, null, one, 4, 16, one, one, one, null) == 2
+    assert lib.nm_buff_intersect_random(one, 8, one, 0, one, 0.0, 1.0, one, one, 4, 0, one, one, one, null) == 2
+    assert lib.nm_tree_integrate(one, one, one, 10, 0, 1, one, one, null) == 2 and "bad sizes" in err()
+    assert lib.nm_export_obj(None, 3, None, 0, None, 0, None, 0, b"/nonexistent-dir/x.obj") == 2 and "null array" in err()
+    ok = (C.c_float * 3)(1.0, 2.0, 3.0)
+    assert lib.nm_export_obj(ok, 1, None, 0, None, 0, None, 0, b"/nonexistent-dir/x.obj") == 6 and "cannot open" in err()
