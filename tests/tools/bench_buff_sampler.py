@@ -1,0 +1,49 @@
+"""Time of the two branches of the BuFF voxel sampler on config 5's geometry (504x378 view of the 12^3 tree, 192 samples,
+65 536 rays per call): the deterministic placement (nm_buff_intersect, both tie orders) and the
+`tree.use_random_sampling` branch (nm_buff_intersect_random, draws included and excluded).  Prints one JSON object."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from nerfmeshes_amd import hip_ops, synthetic as S  # noqa: E402
+from nerfmeshes_amd.nerf import CfgNode  # noqa: E402
+from nerfmeshes_amd.nerf.tree import TreeSampling  # noqa: E402
+from nerfmeshes_amd.models.model_helpers import nest_dict  # noqa: E402
+
+dev = torch.device("cuda")
+hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2, dataset_type="colmap")
+tree = TreeSampling(CfgNode(nest_dict(hp, sep=".")), dev)
+o, d = hip_ops.ray_bundle(S.pose_spherical(30.0, -20.0, 1.0), 378, 504, 0.8 * 504, device=dev)
+rays, samples = 65536, 192
+d = d[:rays].contiguous()
+o = o[None].contiguous()
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return min(a.elapsed_time(b) for a, b in ev)
+
+
+u_pick = torch.rand(rays, samples, dtype=torch.float64, device=dev)
+u_pos = torch.rand(rays, samples, device=dev)
+out = {
+    "rays": rays, "samples": samples, "voxels": int(tree.voxels.shape[0]),
+    "deterministic_stable_ms": timed(lambda: hip_ops.buff_intersect(tree.voxels, o, d, 0.0, 1.2, samples)),
+    "random_given_draws_ms": timed(lambda: hip_ops.buff_intersect_random(tree.voxels, o, d, 0.0, 1.2, u_pick, u_pos)),
+    "random_draws_ms": timed(lambda: (torch.rand(rays, samples, dtype=torch.float64, device=dev),
+                                      torch.rand(rays, samples, device=dev))),
+}
+z, idx, mask = hip_ops.buff_intersect_random(tree.voxels, o, d, 0.0, 1.2, u_pick, u_pos)
+out["rays_hitting_tree"] = float(mask.float().mean())
+print(json.dumps(out))
