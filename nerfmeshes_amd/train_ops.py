@@ -5,11 +5,13 @@ What `loss.backward()` does in the reference's `NeRFModel.training_step`
 
 * `mlp_rays`       -- FlexibleNeRFModel.forward over ray samples as a `torch.autograd.Function`:
                       forward = the fused HIP kernel recording a tape, backward = the HIP delta kernel +
-                      one rocBLAS GEMM per weight matrix (dW = delta^T @ activation rows).
+                      the hand-written weight-gradient kernels (dW = delta^T @ activation rows: nm_weight_grad for
+                      the 128- / 256-wide layers, nm_head_grad for fc_alpha / fc_rgb); 64-wide networks and sample
+                      counts that are not a multiple of 16 take a library GEMM (torch.bmm split-K, `_tn`).
 * `composite`      -- VolumeRenderer.forward (noise + ReLU + alpha compositing) with a HIP backward.
 * `perturb_intervals`, `sample_pdf_rand` -- the stochastic depth samplers; random numbers are torch's.
 
-torch is plumbing (device memory, autograd bookkeeping, the optimizer, the BLAS handle); there is no CPU path.
+torch is plumbing (device memory, autograd bookkeeping, the optimizer); there is no CPU path.
 """
 import ctypes as C
 
