@@ -1,19 +1,27 @@
-"""Test-set render loop with the reference's bookkeeping (mirror of /root/reference/src/eval_nerf.py:23-105):
-per view, chunks of `cfg.nerf.validation.chunksize` rays through `model.query`, the per-view loss
-`sum(mse(chunk)) / (num_rays / chunksize)` (a FLOAT batch count -- the reference's quirk), dataset loss = mean
-over views, PSNR = -10 log10(loss).
+"""Test-set evaluation with the reference's entry points (mirror of /root/reference/src/eval_nerf.py):
 
-The reference couples this loop to `BlenderDataset` (file I/O, out of scope); here the views come from any
-iterable of `(c2w pose, height, width, focal, targets | None)` -- e.g. `synthetic_views()` -- and ray
-directions are generated on the GPU.  `--gpus N` semantics: launch under torch.distributed.run; views are
-sharded round-robin over ranks and the per-view losses all-gathered."""
+* `eval_nerf(model, config_args, cfg, device)` (eval_nerf.py:23-105) -- `BlenderDataset(cfg, TEST)` through a
+  `DataLoader(batch_size=1)`, per image chunks of `cfg.nerf.validation.chunksize` rays through `model.query`, the
+  per-image loss `sum(mse(chunk)) / (num_rays / chunksize)` (a FLOAT batch count -- the reference's quirk), dataset
+  loss = mean over images, PSNR = -10 log10(loss); `--save-images`, `--save-disparity`, `--synthesis-images`.
+* the same command line (`--log-checkpoint --checkpoint --save-dir --save-images --save-disparity --synthesis-images`).
+
+Additions: `--views N` evaluates N synthetic orbit views instead of a dataset (`eval_views`; nothing to read from disk,
+ray directions generated on the GPU); under `torch.distributed.run` the images are dealt round-robin to the ranks and
+the per-image losses all-gathered (`--gpus`-style scaling: launch one process per GPU)."""
 import argparse
+import os
+from pathlib import Path
 
 import torch
+import torch.nn.functional as F
+from torch.utils.data import DataLoader
 
 from . import hip_ops, models, synthetic
+from .data.data_helpers import DataBundle
+from .data.datasets import BlenderDataset, DatasetType
 from .lightning_modules import PathParser
-from .nerf.nerf_helpers import mse2psnr
+from .nerf.nerf_helpers import batchify, cast_to_disparity_image, cast_to_pil_image, mse2psnr
 
 
 def synthetic_views(count, height=800, width=800, focal=synthetic.LEGO_FOCAL_800, with_targets=True):
@@ -47,8 +55,84 @@ def render_view(model, pose, height, width, focal, bounds, chunksize, device="cu
     return torch.cat(rgb, 0), torch.cat(disp, 0)
 
 
-def eval_nerf(model, views, cfg, device="cuda", chunksize=None):
-    """Returns (per-view losses, dataset loss, dataset PSNR, last rgb map)."""
+def _imwrite(path, image):
+    try:
+        import imageio
+        imageio.imwrite(path, image)
+    except ImportError:
+        from PIL import Image
+        Image.fromarray(image).save(path)
+
+
+def eval_nerf(model, config_args, cfg, device):
+    """eval_nerf.py:23-105, call for call: dataset -> DataLoader -> `DataBundle.deserialize(...).to_ray_batch()` ->
+    `batchify(directions, targets)` -> `model.query((origins, directions_chunk, bounds))` (bounds stay on the host, as
+    the reference passes them) -> loss bookkeeping / image files.  Returns the dataset loss (None with
+    `--synthesis-images`; the reference returns nothing and prints it)."""
+    from . import dist as nd
+    rank, world = nd.world()
+    dataset = BlenderDataset(cfg, type=DatasetType.TEST)
+    if config_args.synthesis_images:
+        dataset.synthesis()
+    data_loader = DataLoader(dataset, batch_size=1)
+    root_dir = Path(config_args.save_dir) / cfg.experiment.id
+    images_dir, targets_dir, disparity_dir = root_dir / "images", root_dir / "targets", root_dir / "disparity"
+    if config_args.save_images:
+        os.makedirs(images_dir, exist_ok=True)
+        os.makedirs(targets_dir, exist_ok=True)
+    if config_args.save_disparity:
+        os.makedirs(disparity_dir, exist_ok=True)
+    score = not config_args.synthesis_images
+    losses = []
+    for img_nr, ray_batch in enumerate(data_loader):
+        if img_nr % world != rank:                 # images are independent: round-robin over the ranks
+            continue
+        bundle = DataBundle.deserialize(ray_batch).to_ray_batch()
+        batch_size = cfg.nerf.validation.chunksize
+        batch_count = bundle.ray_directions.shape[0] / batch_size          # float (eval_nerf.py:57)
+        loss, rgb_map, disp_map = 0, [], []
+        origins = bundle.ray_origins.to(device)
+        per_ray = origins.shape[0] == bundle.ray_directions.shape[0] and origins.shape[0] > 1      # NDC caches
+        chunks = batchify(bundle.ray_directions, bundle.ray_targets, origins if per_ray else None,
+                          batch_size=batch_size, device=device, progress=False)
+        for ray_directions, ray_targets, ray_origins in chunks:
+            out = model.query((ray_origins if per_ray else origins, ray_directions, bundle.ray_bounds))
+            rgb_map.append(out.rgb_map)
+            disp_map.append(out.disp_map)
+            if score:
+                loss += F.mse_loss(out.rgb_map, ray_targets)
+        if score:
+            loss /= batch_count
+            losses.append(loss)
+        rgb_map, disp_map = torch.cat(rgb_map, 0), torch.cat(disp_map, 0)
+        height, width = int(bundle.hwf[0]), int(bundle.hwf[1])
+        if config_args.save_images:
+            _imwrite(os.path.join(images_dir, f"{img_nr:04d}.png"), cast_to_pil_image(rgb_map.view(height, width, 3)))
+            if score:
+                _imwrite(os.path.join(targets_dir, f"{img_nr:04d}.png"),
+                         cast_to_pil_image(bundle.ray_targets.view(height, width, 3)))
+        if config_args.save_disparity:
+            _imwrite(os.path.join(disparity_dir, f"{img_nr:04d}.png"),
+                     cast_to_disparity_image(disp_map.view(height, width), white_background=True))
+        if score:
+            print(f"[EVAL] Iter: {img_nr} Loss MSE {loss} / PSNR: {mse2psnr(loss)}")
+    if not score:
+        return None
+    if world > 1:
+        counts = nd.round_robin_counts(len(dataset), world)
+        mine = torch.stack(losses).to(device).float() if losses else torch.empty(0, dtype=torch.float32, device=device)
+        flat = nd.all_gather_rows(mine, counts)
+        starts = [sum(counts[:r]) for r in range(world)]
+        losses = [flat[starts[i % world] + i // world] for i in range(len(dataset))]     # back to image order
+    total_loss = torch.stack(losses).mean()
+    print(f"Dataset loss MSE: {total_loss} / PSNR: {mse2psnr(total_loss)}")
+    return total_loss
+
+
+def eval_views(model, views, cfg, device="cuda", chunksize=None):
+    """The same bookkeeping over an iterable of `(c2w pose, height, width, focal, targets | None)` -- e.g.
+    `synthetic_views()` -- with ray directions generated on the GPU.  Returns (per-view losses, dataset loss, dataset
+    PSNR, last rgb map)."""
     chunksize = chunksize or cfg.nerf.validation.chunksize
     bounds = torch.tensor([cfg.dataset.near, cfg.dataset.far], dtype=torch.float32)
     from . import dist as nd
@@ -87,23 +171,40 @@ def eval_nerf(model, views, cfg, device="cuda", chunksize=None):
     return losses, total, (mse2psnr(total) if total is not None else None), rgb
 
 
-def main(argv=None):
+def build_parser():
     p = argparse.ArgumentParser()
-    p.add_argument("--log-checkpoint", type=str, default=None)
-    p.add_argument("--checkpoint", type=str, default="model_last.ckpt")
-    p.add_argument("--views", type=int, default=4, help="synthetic orbit views to render")
-    p.add_argument("--chunksize", type=int, default=None)
-    args = p.parse_args(argv)
+    p.add_argument("--log-checkpoint", type=str, default=None,
+                   help="Training log path with the config and checkpoints to load existent configuration.")
+    p.add_argument("--checkpoint", type=str, default="model_last.ckpt",
+                   help="Load existent configuration from the latest checkpoint by default.")
+    p.add_argument("--save-dir", type=str, default=".", help="Save assets to this directory, if specified.")
+    p.add_argument("--save-images", action="store_true", default=False, help="Save view images.")
+    p.add_argument("--save-disparity", action="store_true", default=False, help="Save disparity images.")
+    p.add_argument("--synthesis-images", action="store_true", default=False,
+                   help="Synthesis new views 360 degrees around the neural scene.")
+    p.add_argument("--views", type=int, default=0,
+                   help="(addition) evaluate this many synthetic orbit views instead of the dataset of the config")
+    p.add_argument("--chunksize", type=int, default=None, help="(addition) override cfg.nerf.validation.chunksize")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("eval_nerf needs a MI355X: the HIP path has no CPU fallback")
     from . import dist as nd
     rank, world, device = nd.init_from_env()          # one process per GPU under torch.distributed.run
     pp = PathParser()
     cfg, _ = pp.parse(None, args.log_checkpoint, None, args.checkpoint)
+    if args.chunksize:
+        cfg.nerf.validation.chunksize = args.chunksize
+    print(f"Loading model from {pp.checkpoint_path}")
     model = getattr(models, cfg.experiment.model).load_from_checkpoint(pp.checkpoint_path).eval().to(device)
     try:
         with torch.no_grad():
-            return eval_nerf(model, synthetic_views(args.views), cfg, device, args.chunksize)
+            if args.views > 0:
+                return eval_views(model, synthetic_views(args.views), cfg, device, args.chunksize)
+            return eval_nerf(model, args, cfg, device)
     finally:
         nd.shutdown()
 

@@ -1,0 +1,358 @@
+"""Stand-ins for the slice of `pytorch_lightning` (0.8.x API) the reference's scripts use, for environments where it is
+not installed: `/root/reference/src/train_nerf.py:6-9,68-101` builds a `Trainer` with a `ModelCheckpoint`, a
+`TensorBoardLogger` and the `LoggerCallback`, then calls `trainer.fit(model)`; `models/model_base.py:17` derives from
+`LightningModule`.  With the real package importable none of this is used (`models.model_base` and
+`lightning_modules` import it first); `compat.install()` registers these classes under the `pytorch_lightning` module
+names only when the import fails.
+
+Scope: the hook ORDER and the state the reference's hooks read -- `setup('fit')` -> `configure_optimizers` -> restore
+-> per epoch `train_dataloader` batches through `training_step` / `backward` / `optimizer.step` / per-step scheduler,
+`callback_metrics`, `batch_idx`, `current_epoch`, `global_step`, `min/max_steps`, `check_val_every_n_epoch`, validation
+loop -> `validation_epoch_end`, `ModelCheckpoint(save_last, save_top_k, monitor, prefix)` file names, the checkpoint
+dictionary keys.  It is single-process per GPU: under `torch.distributed.run` every rank runs this loop and the
+gradients are averaged with `nerfmeshes_amd.dist.all_reduce_gradients` (the reference passes `gpus=` to Lightning's
+DDP, train_nerf.py:35-37,79).  No loggers beyond a metrics file, no profilers, no precision plugins.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+import yaml
+
+__version__ = "0.8.5-nerfmeshes_amd"
+
+
+def seed_everything(seed=None):
+    seed = int(seed if seed is not None else 0)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return seed
+
+
+class Callback:
+    """Hook names of pytorch_lightning.callbacks.Callback that the loop below fires."""
+
+    def on_fit_start(self, trainer, pl_module=None): pass
+    def on_fit_end(self, trainer, pl_module=None): pass
+    def on_sanity_check_start(self, trainer, pl_module): pass
+    def on_train_start(self, trainer, pl_module): pass
+    def on_train_end(self, trainer, pl_module): pass
+    def on_train_epoch_start(self, trainer, pl_module): pass
+    def on_train_batch_end(self, trainer, pl_module, batch, batch_idx, dataloader_idx): pass
+    def on_validation_start(self, trainer, pl_module): pass
+    def on_validation_batch_end(self, trainer, pl_module, batch, batch_idx, dataloader_idx): pass
+    def on_validation_epoch_end(self, trainer, pl_module): pass
+    def on_validation_end(self, trainer, pl_module): pass
+
+
+class LightningModule(torch.nn.Module):
+    """The LightningModule surface `BaseModel` relies on: `.device`, `.hparams`, `.trainer`, `.logger`, `.global_step`,
+    checkpoint hooks and `load_from_checkpoint` over the Lightning checkpoint layout."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.trainer = None
+        self.logger = None
+        self._global_step = 0
+
+    @property
+    def global_step(self):
+        return self.trainer.global_step if self.trainer is not None else self._global_step
+
+    @global_step.setter
+    def global_step(self, value):
+        self._global_step = int(value)
+
+    @property
+    def device(self):
+        for t in list(self.parameters()) + list(self.buffers()):
+            return t.device
+        return torch.device("cpu")
+
+    def setup(self, stage): pass
+    def on_save_checkpoint(self, checkpoint): pass
+    def on_load_checkpoint(self, checkpoint): pass
+
+    def save_checkpoint(self, path):
+        ckpt = {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams), "epoch": 0,
+                "global_step": self.global_step, "pytorch-lightning_version": __version__}
+        self.on_save_checkpoint(ckpt)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(ckpt, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        hparams = ckpt.get("hyper_parameters")
+        if not hparams:  # Lightning also writes <version>/hparams.yaml next to checkpoints/
+            side = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(checkpoint_path))), "hparams.yaml")
+            with open(side) as fh:
+                hparams = yaml.safe_load(fh)
+        model = cls(dict(hparams), **kwargs)
+        model.load_state_dict(ckpt["state_dict"])
+        model.on_load_checkpoint(ckpt)
+        return model
+
+
+class _Experiment:
+    """What `logger.experiment` (a SummaryWriter) is asked to do by the reference: accepted and dropped, except scalars."""
+
+    def __init__(self, sink):
+        self._sink = sink
+
+    def add_scalar(self, tag, value, step=None):
+        self._sink({tag: float(value)}, step)
+
+    def __getattr__(self, name):                 # add_image / add_text / add_mesh / add_histogram ...
+        return lambda *a, **k: None
+
+
+class TensorBoardLogger:
+    """Directory layout of pytorch_lightning.loggers.TensorBoardLogger (`<save_dir>/<name>/version_N`, `hparams.yaml`
+    inside); scalars go to `metrics.jsonl` instead of an event file (tensorboard is not installed offline)."""
+
+    NAME_HPARAMS_FILE = "hparams.yaml"
+
+    def __init__(self, save_dir, name="default", version=None, **kwargs):
+        self.save_dir, self.name = str(save_dir), name
+        self._version = version
+        self._experiment = None
+
+    @property
+    def root_dir(self):
+        return os.path.join(self.save_dir, self.name)
+
+    @property
+    def version(self):
+        if self._version is None:
+            taken = [int(d.split("_")[1]) for d in (os.listdir(self.root_dir) if os.path.isdir(self.root_dir) else [])
+                     if d.startswith("version_") and d.split("_")[1].isdigit()]
+            self._version = max(taken) + 1 if taken else 0
+        return self._version
+
+    @property
+    def log_dir(self):
+        v = self.version
+        return os.path.join(self.root_dir, v if isinstance(v, str) else f"version_{v}")
+
+    @property
+    def experiment(self):
+        if self._experiment is None:
+            os.makedirs(self.log_dir, exist_ok=True)
+            self._experiment = _Experiment(self.log_metrics)
+        return self._experiment
+
+    def log_hyperparams(self, params):
+        os.makedirs(self.log_dir, exist_ok=True)
+        with open(os.path.join(self.log_dir, self.NAME_HPARAMS_FILE), "w") as fh:
+            yaml.safe_dump({k: (v.item() if hasattr(v, "item") else v) for k, v in dict(params).items()}, fh)
+
+    def log_metrics(self, metrics, step=None):
+        os.makedirs(self.log_dir, exist_ok=True)
+        row = {k: (float(v) if hasattr(v, "__float__") else v) for k, v in metrics.items()}
+        with open(os.path.join(self.log_dir, "metrics.jsonl"), "a") as fh:
+            fh.write(json.dumps({"step": step, **row}) + "\n")
+
+    def save(self): pass
+    def finalize(self, status=None): pass
+
+
+class ModelCheckpoint(Callback):
+    """File naming of Lightning 0.8's ModelCheckpoint as the reference configures it (train_nerf.py:65-66:
+    `filepath=<checkpoint_dir>, save_top_k=3, save_last=True, monitor="val_loss", mode="min", prefix="model_"`):
+    after every validation `<prefix>epoch=<E>.ckpt` for the best `save_top_k` scores and `<prefix>last.ckpt`."""
+
+    def __init__(self, filepath=None, monitor="val_loss", verbose=False, save_last=False, save_top_k=1, mode="min",
+                 prefix="", period=1, **kwargs):
+        self.dirpath = str(filepath) if filepath is not None else None
+        self.monitor, self.verbose, self.save_last, self.save_top_k = monitor, verbose, save_last, save_top_k
+        self.sign = 1.0 if mode == "min" else -1.0
+        self.prefix = prefix
+        self.best_k = {}                        # path -> score
+        self.best_model_path, self.best_model_score = "", None
+
+    def on_validation_end(self, trainer, pl_module):
+        if self.dirpath is None or trainer.global_rank != 0:
+            return
+        os.makedirs(self.dirpath, exist_ok=True)
+        score = trainer.callback_metrics.get(self.monitor)
+        if score is not None and self.save_top_k != 0:
+            score = float(score)
+            path = os.path.join(self.dirpath, f"{self.prefix}epoch={trainer.current_epoch}.ckpt")
+            worst = max(self.best_k.items(), key=lambda kv: self.sign * kv[1]) if self.best_k else None
+            if self.save_top_k < 0 or len(self.best_k) < self.save_top_k or self.sign * score < self.sign * worst[1]:
+                if 0 < self.save_top_k <= len(self.best_k):
+                    self.best_k.pop(worst[0])
+                    if os.path.exists(worst[0]):
+                        os.remove(worst[0])
+                self.best_k[path] = score
+                trainer.save_checkpoint(path)
+                self.best_model_path, self.best_model_score = min(self.best_k.items(), key=lambda kv: self.sign * kv[1])
+                if self.verbose:
+                    print(f"Epoch {trainer.current_epoch}: {self.monitor} reached {score:.5f}, saving model to {path}")
+        if self.save_last:
+            trainer.save_checkpoint(os.path.join(self.dirpath, f"{self.prefix}last.ckpt"))
+
+
+class ModelSummary:
+    def __init__(self, model, mode="top"):
+        self.model = model
+
+    def __str__(self):
+        rows = [f"{n:40s} {sum(p.numel() for p in m.parameters(recurse=False)):>10d}" for n, m in self.model.named_modules() if n]
+        return "\n".join(rows)
+
+
+class AdvancedProfiler:
+    def __init__(self, *args, **kwargs): pass
+
+
+class Trainer:
+    def __init__(self, logger=None, checkpoint_callback=None, callbacks=None, resume_from_checkpoint=None, gpus=None,
+                 default_root_dir=None, max_steps=None, min_steps=None, max_epochs=1000, min_epochs=1,
+                 check_val_every_n_epoch=1, num_sanity_val_steps=0, accumulate_grad_batches=1, deterministic=False,
+                 precision=32, **kwargs):
+        if precision != 32:
+            raise ValueError("nerfmeshes_amd trains in fp32 (the reference's default, train_nerf.py:38-41)")
+        self.logger = logger
+        self.checkpoint_callback = checkpoint_callback if isinstance(checkpoint_callback, ModelCheckpoint) else None
+        self.callbacks = list(callbacks or [])
+        self.resume_from_checkpoint = resume_from_checkpoint
+        self.default_root_dir = default_root_dir
+        self.max_steps, self.min_steps, self.max_epochs, self.min_epochs = max_steps, min_steps, max_epochs, min_epochs
+        self.check_val_every_n_epoch = check_val_every_n_epoch
+        self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
+        self.global_step, self.current_epoch, self.batch_idx = 0, 0, 0
+        self.global_rank, self.world_size = 0, 1
+        self.callback_metrics = {}
+        self.optimizers, self.lr_schedulers = [], []
+        self.train_dataloader, self.val_dataloaders = None, []
+        self.model = None
+
+    # ---- checkpoint I/O (keys of a Lightning checkpoint; `state_dict` / `hyper_parameters` are what loading needs)
+    def save_checkpoint(self, path):
+        model = self.model
+        # written after the epoch's last optimizer step: `global_step` steps and `current_epoch + 1` epochs are done
+        ckpt = {"epoch": self.current_epoch + 1, "global_step": self.global_step,
+                "pytorch-lightning_version": __version__, "state_dict": model.state_dict(),
+                "optimizer_states": [o.state_dict() for o in self.optimizers],
+                "lr_schedulers": [s["scheduler"].state_dict() for s in self.lr_schedulers],
+                "hparams_name": "cfg", "hyper_parameters": dict(model.hparams)}
+        if self.checkpoint_callback is not None:
+            ckpt["checkpoint_callback_best_model_score"] = self.checkpoint_callback.best_model_score
+            ckpt["checkpoint_callback_best_model_path"] = self.checkpoint_callback.best_model_path
+        model.on_save_checkpoint(ckpt)
+        tmp = path + ".part"
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)
+
+    def _restore(self, model):
+        path = self.resume_from_checkpoint
+        if not path:
+            return
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["state_dict"])
+        model.on_load_checkpoint(ckpt)
+        for opt, state in zip(self.optimizers, ckpt.get("optimizer_states", [])):
+            opt.load_state_dict(state)
+        for sch, state in zip(self.lr_schedulers, ckpt.get("lr_schedulers", [])):
+            sch["scheduler"].load_state_dict(state)
+        self.global_step, self.current_epoch = int(ckpt.get("global_step", 0)), int(ckpt.get("epoch", 0))
+
+    def _fire(self, hook, *args):
+        for cb in self.callbacks + ([self.checkpoint_callback] if self.checkpoint_callback else []):
+            fn = getattr(cb, hook, None)
+            if fn is not None:
+                fn(self, self.model, *args)
+
+    @staticmethod
+    def _to_device(batch, device):
+        if isinstance(batch, torch.Tensor):
+            return batch.to(device)
+        if isinstance(batch, dict):
+            return {k: Trainer._to_device(v, device) for k, v in batch.items()}
+        if isinstance(batch, (list, tuple)):
+            return type(batch)(Trainer._to_device(v, device) for v in batch)
+        return batch
+
+    @staticmethod
+    def _metrics(out):
+        m = dict(out.get("log", {}))
+        m.update({k: v for k, v in out.items() if k not in ("log", "progress_bar") and torch.is_tensor(v) and v.numel() == 1})
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in m.items()}
+
+    def _validate(self, model, device):
+        if not self.val_dataloaders:
+            return
+        was_training = model.training
+        model.eval()
+        self._fire("on_validation_start")
+        outputs = []
+        with torch.no_grad():
+            for loader_idx, loader in enumerate(self.val_dataloaders):
+                for batch_idx, batch in enumerate(loader):
+                    outputs.append(model.validation_step(self._to_device(batch, device), batch_idx))
+                    self._fire("on_validation_batch_end", batch, batch_idx, loader_idx)
+            if outputs and hasattr(model, "validation_epoch_end"):
+                self.callback_metrics.update(self._metrics(model.validation_epoch_end(outputs)))
+        self._fire("on_validation_epoch_end")
+        self._fire("on_validation_end")
+        model.train(was_training)
+
+    def fit(self, model):
+        from . import dist as nd
+        rank, world, device = nd.init_from_env()
+        self.global_rank, self.world_size = rank, world
+        self.model = model
+        model.trainer, model.logger = self, self.logger
+        model.to(device)
+        model.setup("fit")                       # BaseModel.setup: datasets + min/max steps + validation period
+        if self.logger is not None and rank == 0:
+            self.logger.log_hyperparams(model.hparams)
+        conf = model.configure_optimizers()
+        if isinstance(conf, (list, tuple)) and len(conf) == 2 and isinstance(conf[0], (list, tuple)):
+            self.optimizers, scheds = list(conf[0]), list(conf[1])
+        else:
+            self.optimizers, scheds = [conf] if not isinstance(conf, (list, tuple)) else list(conf), []
+        self.lr_schedulers = [s if isinstance(s, dict) else {"scheduler": s, "interval": "epoch", "frequency": 1} for s in scheds]
+        self._restore(model)
+        self.train_dataloader = model.train_dataloader()
+        val = model.val_dataloader() if hasattr(model, "val_dataloader") else None
+        self.val_dataloaders = [] if val is None else (list(val) if isinstance(val, (list, tuple)) else [val])
+        self._fire("on_fit_start")
+        self._fire("on_train_start")
+        model.train()
+        optimizer = self.optimizers[0]
+        done = False
+        while not done and self.current_epoch < (self.max_epochs or 1 << 62):
+            self._fire("on_train_epoch_start")
+            for self.batch_idx, batch in enumerate(self.train_dataloader):
+                batch = self._to_device(batch, device)
+                out = model.training_step(batch, self.batch_idx)
+                (out["loss"] / self.accumulate_grad_batches).backward()
+                if (self.batch_idx + 1) % self.accumulate_grad_batches == 0:
+                    nd.all_reduce_gradients(model.parameters())
+                    optimizer.step()
+                    optimizer.zero_grad(set_to_none=True)
+                    for s in self.lr_schedulers:
+                        if s.get("interval") == "step":
+                            s["scheduler"].step()
+                self.callback_metrics.update(self._metrics(out))
+                self._fire("on_train_batch_end", batch, self.batch_idx, 0)
+                self.global_step += 1
+                if self.max_steps is not None and self.global_step >= self.max_steps:
+                    done = True
+                    break
+            for s in self.lr_schedulers:
+                if s.get("interval", "epoch") == "epoch":
+                    s["scheduler"].step()
+            every = max(1, int(self.check_val_every_n_epoch or 1))
+            if (self.current_epoch + 1) % every == 0 or done:
+                self._validate(model, device)
+            self.current_epoch += 1
+        self._fire("on_train_end")
+        self._fire("on_fit_end")
+        return 1

@@ -15,9 +15,8 @@ try:  # pragma: no cover - not installed offline
     from pytorch_lightning.loggers import TensorBoardLogger
     HPARAMS_FILE = TensorBoardLogger.NAME_HPARAMS_FILE
 except Exception:  # noqa: BLE001
-    Callback = object
-    TensorBoardLogger = None
-    HPARAMS_FILE = "hparams.yaml"
+    from .lightning_compat import Callback, TensorBoardLogger   # same directory layout, scalars to metrics.jsonl
+    HPARAMS_FILE = TensorBoardLogger.NAME_HPARAMS_FILE
 
 
 class LoggerCallback(Callback):
@@ -123,8 +122,6 @@ class PathParser:
         self.log_root_dir = str(self.root_path / self.exp_name)
         logger = None
         if create_logger:
-            if TensorBoardLogger is None:
-                raise RuntimeError("create_logger=True needs pytorch_lightning (TensorBoardLogger)")
             os.makedirs(Path(self.log_root_dir) / self.log_name, exist_ok=True)
             logger = TensorBoardLogger(self.log_root_dir, self.log_name, version=self.log_version)
             self.log_dir = Path(logger.log_dir)

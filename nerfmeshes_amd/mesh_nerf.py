@@ -20,6 +20,14 @@ from .lightning_modules import PathParser
 from .nerf.nerf_helpers import batchify, export_obj
 
 
+def create_mesh(vertices, faces_idx):
+    """mesh_nerf.py:14-24: the mesh centred and scaled into the unit sphere as a pytorch3d `Meshes` (only the chamfer
+    branch of `validation_epoch_end` uses it; needs pytorch3d)."""
+    from pytorch3d.structures import Meshes
+    vertices = vertices - vertices.mean(0)
+    return Meshes(verts=[vertices / max(vertices.abs().max(0)[0])], faces=[faces_idx])
+
+
 def _nums(nums):
     assert isinstance(nums, (tuple, list, int)), "Nums arg should be either iterable or int."
     if isinstance(nums, int):

@@ -1,60 +1,21 @@
 """BaseModel: the reference's Lightning base class surface (/root/reference/src/models/model_base.py:17-187)
-over the HIP hot path.  `pytorch_lightning` is used when importable (train_nerf.py wiring); otherwise a thin
-torch.nn.Module stand-in provides `.device`, `.hparams` and `load_from_checkpoint` with the same checkpoint
-layout (`state_dict`, `hyper_parameters`, plus BuFF's `tree`)."""
-import os
-
+over the HIP hot path.  `pytorch_lightning` is used when importable (train_nerf.py wiring); otherwise
+`nerfmeshes_amd.lightning_compat.LightningModule` provides `.device`, `.hparams`, `.trainer` and `load_from_checkpoint`
+with the same checkpoint layout (`state_dict`, `hyper_parameters`, plus BuFF's `tree`)."""
 import torch
-import yaml
+from torch.utils.data import DataLoader
 
+from ..data.datasets import BlenderDataset, ColmapDataset, DatasetType
 from ..nerf import CfgNode, VolumeRenderer, mse2psnr
 from .model_helpers import flatten_dict, nest_dict
 
 try:  # pragma: no cover - not installed offline
     import pytorch_lightning as pl
     _Base = pl.LightningModule
-    HAVE_LIGHTNING = True
+    HAVE_LIGHTNING = not getattr(pl, "__version__", "").endswith("nerfmeshes_amd")
 except Exception:  # noqa: BLE001
+    from ..lightning_compat import LightningModule as _Base   # inference + checkpoint I/O + the Trainer stand-in's hooks
     HAVE_LIGHTNING = False
-
-    class _Base(torch.nn.Module):
-        """Minimal LightningModule stand-in (inference + checkpoint I/O only)."""
-
-        def __init__(self, *args, **kwargs):
-            super().__init__()
-            self.global_step = 0
-
-        @property
-        def device(self):
-            for t in list(self.parameters()) + list(self.buffers()):
-                return t.device
-            return torch.device("cpu")
-
-        def on_save_checkpoint(self, checkpoint):
-            pass
-
-        def on_load_checkpoint(self, checkpoint):
-            pass
-
-        def save_checkpoint(self, path):
-            ckpt = {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams), "epoch": 0,
-                    "global_step": self.global_step}
-            self.on_save_checkpoint(ckpt)
-            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-            torch.save(ckpt, path)
-
-        @classmethod
-        def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
-            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
-            hparams = ckpt.get("hyper_parameters")
-            if not hparams:  # Lightning also writes <version>/hparams.yaml next to checkpoints/
-                side = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(checkpoint_path))), "hparams.yaml")
-                with open(side) as fh:
-                    hparams = yaml.safe_load(fh)
-            model = cls(dict(hparams), **kwargs)
-            model.load_state_dict(ckpt["state_dict"])
-            model.on_load_checkpoint(ckpt)
-            return model
 
 
 def _with_defaults(flat):
@@ -87,6 +48,16 @@ class BaseModel(_Base):
     def get_model(self):
         raise NotImplementedError
 
+    def setup(self, stage):
+        """model_base.py:42-59: load both splits, then size the Trainer from the config -- `train_iters` optimizer steps
+        (min = max), the matching epoch count, validation every `validate_every` steps expressed in epochs."""
+        self.load_train_dataset()
+        self.load_val_dataset()
+        steps, per_epoch = self.cfg.experiment.train_iters, len(self.train_dataset)
+        self.trainer.min_steps = self.trainer.max_steps = steps
+        self.trainer.min_epochs = self.trainer.max_epochs = steps // per_epoch
+        self.trainer.check_val_every_n_epoch = self.cfg.experiment.validate_every // per_epoch
+
     def query(self, ray_batch):
         raise NotImplementedError
 
@@ -94,6 +65,43 @@ class BaseModel(_Base):
         """model_base.py:65-73: finest network on explicit points (N,3) / view dirs (N,3) -> (N,4)."""
         results = self.get_model().forward(points, rays, **kwargs)
         return results[0] if isinstance(results, tuple) else results
+
+    # ---- data feed (model_base.py:105-148): one sample = one image, so both loaders run with batch_size 1 ----
+    def load_dataset(self, dataset_type):
+        kind = self.cfg.dataset.type
+        if kind == "blender":
+            return BlenderDataset(self.cfg, type=dataset_type)
+        if kind == "colmap":
+            return ColmapDataset(self.cfg, type=dataset_type)
+        if kind == "scannet":
+            raise NotImplementedError
+        return None
+
+    def load_train_dataset(self):
+        self.train_dataset = self.load_dataset(DatasetType.TRAIN)
+
+    def load_val_dataset(self):
+        self.val_dataset = self.load_dataset(DatasetType.VALIDATION)
+        self.val_num_samples = self.cfg.nerf.validation.num_samples
+        if self.val_num_samples != -1:
+            self.val_num_samples = max(min(len(self.val_dataset), self.val_num_samples), 1)
+
+    def _loader(self, dataset, sampler=None):
+        # datasets that generate rays touch the GPU in __getitem__/__init__ only through already-materialised host
+        # tensors, so worker processes are safe; the cache files are read by the workers
+        return DataLoader(dataset, batch_size=1, shuffle=False, sampler=sampler, pin_memory=False,
+                          num_workers=self.cfg.dataset.num_workers)
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset)
+
+    def val_dataloader(self):
+        """model_base.py:136-148: `nerf.validation.num_samples` random images (with replacement) per validation run,
+        -1 for the whole split."""
+        sampler = None
+        if self.val_num_samples != -1:
+            sampler = torch.utils.data.RandomSampler(self.val_dataset, replacement=True, num_samples=self.val_num_samples)
+        return self._loader(self.val_dataset, sampler)
 
     # ---- training-side hooks (model_base.py:150-187); NeRFModel implements training_step / validation_step ----
     def get_scheduler(self, optimizer):

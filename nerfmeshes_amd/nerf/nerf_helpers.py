@@ -19,6 +19,42 @@ def mse2psnr(mse):
     return -10.0 * torch.log10(mse)
 
 
+# colours of the depth-residual point clouds (nerf_helpers.py:8-11)
+POINT_GROUND_TRUTH = torch.tensor([0., 0., 255.])
+POINT_OUT_TRUE = torch.tensor([0., 255., 0.])
+POINT_OUT_FALSE_VOID = torch.tensor([0., 0., 0.])
+POINT_OUT_FALSE_SURFACE = torch.tensor([255., 0., 0.])
+
+
+def create_point_cloud(ray_origins, ray_directions, depth, color, mask=None):
+    """nerf_helpers.py:56-64: points o + d * depth (of the masked rays), one constant colour, normals = -d."""
+    if mask is not None:
+        ray_directions, depth = ray_directions[mask], depth[mask]
+    vertices = (ray_origins + ray_directions * depth[..., None]).view(-1, 3)
+    return vertices, color.to(vertices.device).expand(vertices.shape), -ray_directions.view(-1, 3)
+
+
+def get_point_clouds(ray_origins, ray_directions, depth_output, depth_target=None, threshold=0.2, empty=0.):
+    """nerf_helpers.py:26-53: the rendered depths as a coloured point cloud; with target depths, four clouds
+    (target / hits within `threshold` / misses over empty space / misses over the surface) concatenated per field."""
+    if depth_target is None:
+        return create_point_cloud(ray_origins, ray_directions, depth_output, POINT_GROUND_TRUTH)
+    hit = torch.abs(depth_output - depth_target) < threshold
+    clouds = [create_point_cloud(ray_origins, ray_directions, depth_target, POINT_GROUND_TRUTH),
+              create_point_cloud(ray_origins, ray_directions, depth_output, POINT_OUT_TRUE, hit),
+              create_point_cloud(ray_origins, ray_directions, depth_output, POINT_OUT_FALSE_VOID, (depth_target == empty) & ~hit),
+              create_point_cloud(ray_origins, ray_directions, depth_output, POINT_OUT_FALSE_SURFACE, (depth_target != empty) & ~hit)]
+    return [torch.cat(field, dim=0) for field in zip(*clouds)]
+
+
+def comp_depth(depth_output, depth_target, empty_value=0.):
+    """nerf_helpers.py:67-83: depth MSE overall / over empty pixels / over surface pixels, and the mean signed error."""
+    mse = torch.nn.functional.mse_loss
+    surface = depth_target > empty_value
+    return (mse(depth_output, depth_target), mse(depth_output[~surface], depth_target[~surface]),
+            mse(depth_output[surface], depth_target[surface]), (depth_output[surface] - depth_target[surface]).mean())
+
+
 def batchify(*data, batch_size=1024, device="cpu", progress=True):
     """nerf_helpers.py:114-139: yield aligned slices of every tensor, moved to `device`."""
     size = data[0].shape[0]
@@ -78,6 +114,16 @@ def cast_to_disparity_image(tensor, white_background=False):
     if white_background:
         img[img == 0] = 255
     return img.detach().cpu().numpy()
+
+
+def export_point_cloud(it, ray_origins, ray_directions, depth_fine, dep_target):
+    """nerf_helpers.py:142-152: rendered (red) and target (blue) depth points of one image -> `<it:04d>.obj`."""
+    rendered = (ray_origins + ray_directions * depth_fine[..., None]).view(-1, 3)
+    target = (ray_origins + ray_directions * dep_target[..., None]).view(-1, 3)
+    red, blue = torch.zeros_like(rendered), torch.zeros_like(target)
+    red[:, 0], blue[:, 2] = 1.0, 1.0
+    back = -ray_directions.view(-1, 3)
+    export_obj(torch.cat((rendered, target), 0), [], torch.cat((red, blue), 0), torch.cat((back, back), 0), f"{it:04d}.obj")
 
 
 def export_obj(vertices, triangles, diffuse, normals, filename):

@@ -1,136 +1,77 @@
-"""Training driver over the HIP path (counterpart of /root/reference/src/train_nerf.py + the Lightning loop it
-configures): `configure_optimizers()` -> repeated `training_step()` -> `loss.backward()` -> optimizer / scheduler
-step, one process per GPU with the gradient all-reduce of `nerfmeshes_amd.dist` when launched under
-`torch.distributed.run`.
+"""Training entry point with the reference's command line (mirror of /root/reference/src/train_nerf.py:14-108):
+`--config <yml>` for a new experiment or `--log-checkpoint <logdir>/<exp>/<run>/version_N` (+ `--checkpoint`) to resume,
+`--run-name`, `--gpus`, `--precision`, `--deterministic`, `--use-profiler`.
 
-There is no dataset in this environment, so the ray batches come from a *teacher*: the seeded smooth scene
-(`synthetic.make_scene_weights`) rendered through the inference path from orbit poses gives the target pixels;
-the student is a fresh NeRFModel of the given shape.  With a real dataset the loop is the same -- feed
-`DataBundle.serialize(...)` dictionaries to `fit()`.
+`PathParser` resolves the directories and creates the logger, the model class comes from `cfg.experiment.model`, a
+`ModelCheckpoint(save_top_k=3, save_last=True, monitor="val_loss", prefix="model_")` writes
+`<version dir>/checkpoints/model_last.ckpt`, `LoggerCallback` prints progress, and `Trainer.fit(model)` runs
+`BaseModel.setup` -> data loaders -> `training_step` (HIP forward + backward) -> optimizer.  `pytorch_lightning`'s
+Trainer is used when the package is installed, otherwise `nerfmeshes_amd.lightning_compat` (the same hook order).
 
-    python -m nerfmeshes_amd.train_nerf --iters 300 --views 8 --size 100
+Multi-GPU: launch one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m nerfmeshes_amd.train_nerf
+...`); `--gpus` is accepted for command-line compatibility and must match the launcher's world size.  A dataset-free
+demo of the same training arithmetic is `nerfmeshes_amd.train_synthetic`.
 """
 import argparse
-import json
-import time
+import os
 
 import torch
 
-from . import dist as nd, hip_ops, synthetic as S
-from .data import DataBundle, batch_random_sampling
-from .nerf import CfgNode, mse2psnr
+from . import models
+from .lightning_modules import LoggerCallback, PathParser
+
+try:  # pragma: no cover - not installed offline
+    from pytorch_lightning import Trainer, seed_everything
+    from pytorch_lightning.callbacks import ModelCheckpoint
+except Exception:  # noqa: BLE001
+    from .lightning_compat import ModelCheckpoint, Trainer, seed_everything
 
 
-def teacher_views(num_views, size, device, chunk=65536):
-    """Target images of the seeded scene: list of dicts {ray_origins (3,), ray_directions (H,W,3), ray_targets (H,W,3)}."""
-    full = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
-    mlp = hip_ops.HipMLP(S.make_scene_weights(**full), full, device)
-    focal = 1111.1111 * size / 800.0
-    uc, uf = torch.linspace(0, 1, 64), torch.linspace(0, 1, 128)
-    near, far = torch.tensor([2.0]), torch.tensor([6.0])
-    views = []
-    for pose in S.orbit_poses(num_views):
-        origin, dirs = hip_ops.ray_bundle(pose, size, size, focal, 0, size * size, device)
-        rgb = []
-        for s in range(0, size * size, chunk):
-            _, fine = hip_ops.render_rays(mlp, mlp, origin[None], dirs[s:s + chunk], near, far, uc, uf)
-            rgb.append(fine["rgb_map"].clone())
-        views.append(dict(ray_origins=origin, ray_directions=dirs.view(size, size, 3),
-                          ray_targets=torch.cat(rgb).view(size, size, 3), hwf=(size, size, focal)))
-    return views
-
-
-def random_ray_batch(cfg, view, coords):
-    dirs, targets = batch_random_sampling(cfg, coords, (view["ray_directions"], view["ray_targets"]))
-    bundle = DataBundle(ray_origins=view["ray_origins"], ray_directions=dirs, ray_targets=targets,
-                        ray_bounds=torch.tensor([cfg.dataset.near, cfg.dataset.far]))
-    return bundle.serialize(["ray_origins", "ray_directions", "ray_targets", "ray_bounds"])
-
-
-def fit(model, batches, iters, log_every=0):
-    """The Lightning loop the reference configures, reduced to its arithmetic: returns the list of losses."""
-    (optimizer,), (sched,) = model.configure_optimizers()
-    scheduler = sched["scheduler"]
-    losses = []
-    model.train()
-    for step in range(iters):
-        optimizer.zero_grad(set_to_none=True)
-        out = model.training_step(next(batches), step)
-        out["loss"].backward()
-        nd.all_reduce_gradients(model.parameters())
-        optimizer.step()
-        scheduler.step()
-        try:
-            model.global_step = step + 1          # a LightningModule's global_step belongs to its Trainer
-        except AttributeError:
-            pass
-        losses.append(out["loss"].detach())
-        if log_every and (step + 1) % log_every == 0:
-            print(f"step {step + 1}: loss {float(losses[-1]):.5f} psnr {float(mse2psnr(out['log']['train/fine_loss'])):.2f}")
-    return [float(x) for x in losses]
-
-
-def view_psnr(model, view, chunk=8192):
-    model.eval()
-    size = view["ray_directions"].shape[0]
-    dirs, target = view["ray_directions"].reshape(-1, 3), view["ray_targets"].reshape(-1, 3)
-    bounds = torch.tensor([model.cfg.dataset.near, model.cfg.dataset.far])
-    with torch.no_grad():
-        rgb = torch.cat([model.query((view["ray_origins"][None], dirs[s:s + chunk], bounds)).rgb_map
-                         for s in range(0, size * size, chunk)])
-    return float(mse2psnr(torch.nn.functional.mse_loss(rgb, target)))
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--config", type=str, default=None, help="Path to (.yml) config file if running new experiment.")
+    p.add_argument("--log-checkpoint", type=str, default=None,
+                   help="Training log path with the config and checkpoints to resume the experiment.")
+    p.add_argument("--checkpoint", type=str, default="model_last.ckpt",
+                   help="Resume training from the latest checkpoint by default.")
+    p.add_argument("--run-name", type=str, default="default", help="Name of the training log run")
+    p.add_argument("--gpus", type=int, default=1, help="Amount of Gpus that should be used (one process per GPU)")
+    p.add_argument("--precision", type=int, default=32, help="Full precision (32) only on this path.")
+    p.add_argument("--deterministic", action="store_true", default=False,
+                   help="Run deterministic training, useful for experimenting")
+    p.add_argument("--use-profiler", action="store_true", default=False, help="Accepted; profile with rocprofv3 instead")
+    return p
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--iters", type=int, default=300)
-    ap.add_argument("--views", type=int, default=8)
-    ap.add_argument("--size", type=int, default=100, help="target images are size x size")
-    ap.add_argument("--hidden-size", type=int, default=256)
-    ap.add_argument("--num-layers", type=int, default=8)
-    ap.add_argument("--rays", type=int, default=2048, help="cfg.nerf.train.num_random_rays")
-    ap.add_argument("--lr", type=float, default=5e-4)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--save", default="", help="write a Lightning-layout checkpoint here")
-    args = ap.parse_args(argv)
-    from . import models
-    import os
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:   # launched by torch.distributed.run
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")                          # RCCL over xGMI
-    rank, world = nd.world()
-    device = torch.device("cuda", torch.cuda.current_device())
-    flat = S.hparams(hidden_size=args.hidden_size, num_layers=args.num_layers, train_perturb=True, train_noise_std=0.0)
-    flat.update({"nerf.train.num_random_rays": args.rays, "nerf.train.chunksize": args.rays, "optimizer.lr": args.lr})
-    torch.manual_seed(args.seed)                                   # identical replicas on every rank
-    model = models.NeRFModel(CfgNode(flat)).to(device)
-    views = teacher_views(args.views + 1, args.size, device)
-    held_out, train_views = views[-1], views[:-1]
-    coords = torch.stack(torch.meshgrid(torch.arange(args.size), torch.arange(args.size), indexing="ij"), -1).reshape(-1, 2).to(device)
-    torch.manual_seed(args.seed + 1000 * (rank + 1))               # different rays on every rank
-
-    def batches():
-        k = 0
-        while True:
-            yield random_ray_batch(model.cfg, train_views[k % len(train_views)], coords)
-            k += 1
-
-    before = view_psnr(model, held_out)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    losses = fit(model, batches(), args.iters)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    after = view_psnr(model, held_out)
-    if args.save and rank == 0:
-        model.save_checkpoint(args.save)
-    if rank == 0:
-        print(json.dumps({"iters": args.iters, "rays_per_iter": args.rays * world, "seconds": dt,
-                          "iters_per_s": args.iters / dt, "train_rays_per_s": args.iters * args.rays * world / dt,
-                          "first_loss": losses[0], "last_loss": sum(losses[-10:]) / len(losses[-10:]),
-                          "held_out_psnr_before": before, "held_out_psnr_after": after, "world": world}))
-    return losses, before, after
+    torch.set_printoptions(threshold=100, edgeitems=50, precision=8, sci_mode=False)
+    args = build_parser().parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("train_nerf needs a MI355X: the HIP path has no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} processes")
+    path_parser = PathParser()
+    cfg, logger = path_parser.parse(args.config, args.log_checkpoint, args.run_name, args.checkpoint, create_logger=True)
+    if args.deterministic:
+        seed_everything(cfg.experiment.randomseed)
+    model = getattr(models, cfg.experiment.model)(cfg)
+    checkpoint_callback = ModelCheckpoint(filepath=path_parser.checkpoint_dir, save_top_k=3, save_last=True, verbose=True,
+                                          monitor="val_loss", mode="min", prefix="model_")
+    trainer = Trainer(
+        weights_summary=None, resume_from_checkpoint=path_parser.checkpoint_path, gpus=args.gpus,
+        default_root_dir=path_parser.log_dir, logger=logger, num_sanity_val_steps=0,
+        checkpoint_callback=checkpoint_callback, row_log_interval=1, log_gpu_memory=None, precision=args.precision,
+        profiler=None, fast_dev_run=False, deterministic=args.deterministic, progress_bar_refresh_rate=0,
+        accumulate_grad_batches=1, callbacks=[LoggerCallback(cfg)])
+    if args.log_checkpoint is not None:
+        logger.experiment.add_text("description", cfg.experiment.description, 0)
+        logger.experiment.add_text("config", f"\t{cfg.dump()}".replace("\n", "\n\t"), 0)
+    trainer.fit(model)
+    print("Done!")
+    return trainer, model, path_parser
 
 
 if __name__ == "__main__":
+    print(os.getcwd())
     main()

@@ -127,7 +127,7 @@ def _eval_job(rank, world, num_views=1):
         tgt = None if (num_views == 5 and i == 1) else torch.full((6 * 4, 3), 0.5)      # one view without targets
         views.append((pose, 6, 4, 10.0, tgt))
     cfg = CfgNode(nest_dict(S.hparams(chunksize=8), sep="."))
-    losses, total, psnr, _ = E.eval_nerf(None, views, cfg, device="cpu")
+    losses, total, psnr, _ = E.eval_views(None, views, cfg, device="cpu")
     return [float(x) for x in losses], None if total is None else float(total)
 
 

@@ -350,7 +350,7 @@ def test_eval_nerf_loop_matches_oracle_bookkeeping(pkg):
     m = m.eval().to("cuda")
     views = list(ev.synthetic_views(2, height=40, width=52, focal=70.0))
     with torch.no_grad():
-        losses, total, psnr, rgb = ev.eval_nerf(m, views, m.cfg, "cuda")
+        losses, total, psnr, rgb = ev.eval_views(m, views, m.cfg, "cuda")
     assert len(losses) == 2 and rgb.shape == (40 * 52, 3)
     spec, rs = O.MLPSpec(), O.RenderSpec()
     ref_losses = []

@@ -257,7 +257,7 @@ def test_training_step_api_and_driver(tmp_path):
     4x64 student fitted for 80 iterations to renders of the seeded scene: the training loss falls by > 40 %, the
     held-out view does not get worse (the 8x256 student of the default command line goes from 8 dB to 19 dB in 300
     iterations, profiles/r01_train_bench.json), and the checkpoint loads back through the reference's entry point."""
-    from nerfmeshes_amd import models, train_nerf
+    from nerfmeshes_amd import models, train_synthetic as train_nerf
     ckpt = tmp_path / "default" / "version_0" / "checkpoints" / "last.ckpt"
     losses, before, after = train_nerf.main(["--iters", "80", "--views", "4", "--size", "48", "--hidden-size", "64",
                                              "--num-layers", "4", "--rays", "1024", "--lr", "2e-3", "--save", str(ckpt)])
