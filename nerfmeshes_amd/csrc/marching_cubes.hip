@@ -493,7 +493,11 @@ __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const
         }
       }
     }
-    __syncthreads();                                     // the logic wave's last masks
+    __syncthreads();                                     // the logic wave's last masks; every append so far is counted in s_n
+    // The in-loop decision bounds the fill at MC_STAGE after the last iteration's appends (snapshot <= MC_FLUSH_AT, plus
+    // at most one step the snapshot missed, plus that iteration's step) -- the final step below needs its own room.
+    // s_n is exact and stable here (nobody appends between the barrier above and the one inside flush()).
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_n) > (uint32_t)(MC_STAGE - MC_CUBES_PER_PLANE)) flush();
     append(zrun - 1);
     __syncthreads();
     flush();

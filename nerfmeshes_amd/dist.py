@@ -27,7 +27,12 @@ def init_from_env(backend=None):
     WORLD_SIZE (the reference's only multi-GPU hook is `Trainer(gpus=...)`, /root/reference/src/train_nerf.py:35-37,79;
     here the scripts are launched one process per GPU).  Binds this process to its GPU, initialises RCCL
     (backend "nccl") -- or `backend` when given, e.g. "gloo" in the CPU tests -- and returns (rank, world, device).
-    Without a launcher environment it is a no-op returning (0, 1, current device)."""
+    Without a launcher environment it is a no-op returning (0, 1, current device).
+
+    `NERFMESHES_RANKS_PER_GPU=k` (k > 1) puts k consecutive local ranks on the same GPU: a functional mode for
+    exercising the N-rank code paths with the real kernels on a box with fewer GPUs than ranks.  RCCL refuses two ranks
+    on one device, so that mode uses the "gloo" backend (device tensors staged through the host, `_via_host`); it says
+    nothing about scaling."""
     import os
     dist = _dist()
     have_gpu = torch.cuda.is_available()
@@ -35,13 +40,17 @@ def init_from_env(backend=None):
         return 0, 1, torch.device("cuda", torch.cuda.current_device()) if have_gpu else torch.device("cpu")
     rank, ws = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    backend = backend or ("nccl" if have_gpu else "gloo")
+    per_gpu = max(1, int(os.environ.get("NERFMESHES_RANKS_PER_GPU", "1")))
+    backend = backend or ("nccl" if have_gpu and per_gpu == 1 else "gloo")
+    if per_gpu > 1 and backend == "nccl":
+        raise RuntimeError("NERFMESHES_RANKS_PER_GPU > 1 needs the gloo backend: RCCL refuses duplicate devices")
     device = torch.device("cpu")
     if have_gpu:
-        if local >= torch.cuda.device_count():
-            raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible")
-        torch.cuda.set_device(local)
-        device = torch.device("cuda", local)
+        index = local // per_gpu
+        if index >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK={local} ({per_gpu} rank(s) per GPU) but only {torch.cuda.device_count()} GPU(s) are visible")
+        torch.cuda.set_device(index)
+        device = torch.device("cuda", index)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -54,6 +63,35 @@ def shutdown():
     dist = _dist()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def _via_host(t):
+    """True when a collective on `t` has to be staged through host memory: a device tensor under the gloo backend."""
+    return t.is_cuda and _dist().get_backend() == "gloo"
+
+
+def all_gather_into(out, local):
+    """`dist.all_gather_into_tensor(out, local)`; device tensors under gloo go through the host."""
+    dist = _dist()
+    if _via_host(local):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def all_reduce(t, op=None):
+    dist = _dist()
+    op = op if op is not None else dist.ReduceOp.SUM
+    if _via_host(t):
+        host = t.cpu()
+        dist.all_reduce(host, op=op)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
 
 
 def round_robin_counts(n, world_size):
@@ -88,13 +126,12 @@ def all_gather_rows(local, counts):
     tail = tuple(local.shape[1:])
     if len(set(counts)) == 1:
         out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous())
-        return out
+        return all_gather_into(out, local)
     m = max(counts)
     padded = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
     out = torch.empty((ws * m,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded)
+    all_gather_into(out, padded)
     out = out.view((ws, m) + tail)
     return torch.cat([out[r, :counts[r]] for r in range(ws)], 0)
 
@@ -140,7 +177,7 @@ def all_reduce_gradients(parameters, bucket_bytes=64 << 20):
         buckets.append(bucket)
     for group in buckets:
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in group])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(ws)
         offset = 0
         for p in group:

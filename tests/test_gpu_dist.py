@@ -30,10 +30,10 @@ def _env():
     return env
 
 
-def _torchrun(nproc, script, *args, timeout=600):
+def _torchrun(nproc, script, *args, timeout=600, env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
-    return subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=timeout)
+    return subprocess.run(cmd, cwd=ROOT, env=dict(_env(), **(env or {})), capture_output=True, text=True, timeout=timeout)
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -45,6 +45,19 @@ def test_rccl_sharded_render_grid_mesh(world):
     r = _torchrun(world, os.path.join("tests", "tools", "dist_worker.py"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert f"DIST_OK world={world} backend=nccl" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_over_gloo(world):
+    """N > 1 with the REAL kernels on a one-GPU box: `world` processes on cuda:0 over gloo (RCCL refuses duplicate
+    devices).  Sharded pixels, slab-sharded grid -> marching cubes, vertex-sharded appearance re-query + OBJ, ragged
+    eval-loss gather, gradient all-reduce of a real training step -- each equal to the 1-rank result bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X")
+    r = _torchrun(world, os.path.join("tests", "tools", "dist_worker.py"), timeout=900,
+                  env={"NERFMESHES_RANKS_PER_GPU": str(world), "NM_EXPECT_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert f"DIST_OK world={world} backend=gloo device=cuda:0" in r.stdout, r.stdout[-2000:]
 
 
 def test_bench_refuses_more_gpus_than_visible():

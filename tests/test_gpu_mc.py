@@ -50,7 +50,9 @@ def test_mc_golden_set_bitwise(ops):
 @pytest.mark.parametrize("shape", [(2, 2, 2), (2, 9, 3), (17, 5, 33), (64, 64, 64), (33, 130, 77), (160, 160, 160),
                                    # rows wider than one 512-voxel brick (the classify kernel's x-halo path), 16-byte loads and scalar ones,
                                    # and more planes than one march (26 > 24)
-                                   (3, 9, 700), (4, 5, 515), (26, 10, 1032)])
+                                   (3, 9, 700), (4, 5, 515), (26, 10, 1032),
+                                   # every cube cut on full-width rows for more planes than one march: the staging buffer flushes mid-march
+                                   (30, 16, 512)])
 @pytest.mark.parametrize("kind", ["noise", "ties", "smooth"])
 def test_mc_vs_oracle_bitwise(ops, shape, kind):
     rng = np.random.default_rng(hash((shape, kind)) % (2 ** 32))

@@ -1,8 +1,11 @@
 """Launched by tests/test_gpu_dist.py under `python -m torch.distributed.run --nproc-per-node N` on the GPU box:
-initialises RCCL (backend "nccl") through nerfmeshes_amd.dist.init_from_env and pushes REAL kernel outputs through
-the sharding layer -- rendered pixels (render_view_sharded: contiguous ray ranges per rank), a density slab
-(density_grid_sharded: axis-0 planes per rank), the per-view eval losses (ragged) and a gradient all-reduce -- and
-checks on EVERY rank that the N-rank result equals the single-process one bit for bit.  Prints DIST_OK on rank 0."""
+joins the process group through nerfmeshes_amd.dist.init_from_env -- RCCL (backend "nccl", one rank per GPU), or gloo
+with `NERFMESHES_RANKS_PER_GPU=N` (N ranks sharing ONE GPU: the N-rank code paths on the real kernels where the box
+has a single device) -- and pushes REAL kernel outputs through the sharding layer: rendered pixels
+(render_view_sharded: contiguous ray ranges per rank), a density slab (density_grid_sharded: axis-0 planes per rank) ->
+marching cubes, the sharded per-vertex appearance re-query of mesh_nerf, the ragged per-view loss gather of eval_nerf,
+and the gradient all-reduce of a real training step.  Every rank checks that the N-rank result equals the
+single-process one bit for bit.  Prints DIST_OK on rank 0."""
 import os
 import sys
 
@@ -14,10 +17,90 @@ sys.path.insert(0, ROOT)
 from nerfmeshes_amd import dist as nd, hip_ops, synthetic as S  # noqa: E402
 
 
+def single_rank(fn):
+    """Run `fn` as a process outside any group would (nd.world() -> (0, 1)): the 1-rank result, computed on this rank."""
+    real = nd.world, nd.all_gather_rows
+    nd.world, nd.all_gather_rows = (lambda: (0, 1)), (lambda local, counts: local)
+    try:
+        return fn()
+    finally:
+        nd.world, nd.all_gather_rows = real
+
+
+def model_level_checks(rank, world, dev):
+    """The three consumers of the sharding layer inside the package, each against its own single-rank result."""
+    import argparse
+    import contextlib
+    import io
+    import tempfile
+    from nerfmeshes_amd import eval_nerf, mesh_nerf, models
+    hp = S.hparams(chunksize=3000, train_perturb=True, train_noise_std=0.0)
+    torch.manual_seed(0)                                     # identical replicas on every rank
+    model = models.NeRFModel(hp)
+    sd = model.state_dict()
+    for prefix in ("model_coarse.", "model_fine."):
+        for k, v in S.make_scene_weights().items():
+            sd[prefix + k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model = model.eval().to(dev)
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    # (1) eval_nerf: 3 views on `world` ranks (ragged; with 2 ranks rank 1 holds one view), losses back in view order
+    views = list(eval_nerf.synthetic_views(3, height=36, width=44, focal=60.0))
+    with torch.no_grad(), quiet:
+        l1, t1, _, _ = single_rank(lambda: eval_nerf.eval_views(model, views, model.cfg, dev))
+        ln, tn, _, _ = eval_nerf.eval_views(model, views, model.cfg, dev)
+    assert len(ln) == 3 and all(float(a) == float(b) for a, b in zip(l1, ln)) and float(t1) == float(tn), "eval losses differ"
+
+    # (2) mesh_nerf: slab-sharded density grid -> marching cubes -> vertex-sharded appearance re-query -> OBJ on rank 0
+    out = {}
+    for tag in ("n", "1"):
+        d = tempfile.mkdtemp(prefix=f"nm_dist_{rank}_{tag}_")
+        args = mesh_nerf.build_parser().parse_args(["--res", "44", "--save-dir", d, "--view-disparity-max-bound", "1.0",
+                                                    "--iso-level", "32", "--batch-size", "4096"])
+        with torch.no_grad(), quiet:
+            run = lambda: mesh_nerf.export_marching_cubes(model, args, model.cfg, dev)   # noqa: E731
+            out[tag] = (run() if tag == "n" else single_rank(run)) + (d,)
+    for a, b in zip(out["n"][:3], out["1"][:3]):
+        assert torch.equal(a, b), "sharded mesh geometry differs from the 1-rank mesh"
+    assert (out["n"][3] == out["1"][3]).all() and out["n"][3].shape[0] == out["n"][0].shape[0], "sharded vertex colours differ"
+    if rank == 0:
+        assert open(os.path.join(out["n"][4], "mesh.obj"), "rb").read() == open(os.path.join(out["1"][4], "mesh.obj"), "rb").read()
+    else:
+        assert not os.path.exists(os.path.join(out["n"][4], "mesh.obj")), "only rank 0 writes the OBJ"
+
+    # (3) training: every rank draws its own rays; the all-reduced gradients are the mean of the ranks' own, and the
+    # replicas stay identical after the optimizer step
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(100 + rank)
+    o, d = hip_ops.ray_bundle(S.orbit_poses(4)[2], 64, 64, 90.0, device=dev)
+    pick = torch.randperm(4096, generator=g)[:1024].to(dev)
+    batch = {"ray_origins": o, "ray_directions": d[pick], "ray_targets": torch.rand(1024, 3, generator=g).to(dev),
+             "ray_bounds": torch.tensor([2.0, 6.0])}
+    model.training_step(batch, 0)["loss"].backward()
+    params = [p for p in model.parameters() if p.requires_grad]
+    own = torch.cat([p.grad.reshape(-1) for p in params])
+    nd.all_reduce_gradients(model.parameters())
+    got = torch.cat([p.grad.reshape(-1) for p in params])
+    every = nd.all_gather_rows(own[None].contiguous(), [1] * world)
+    mean = every.sum(0) / world
+    # two addends commute exactly; with more ranks the reduction order is the backend's
+    assert torch.equal(got, mean) if world <= 2 else torch.allclose(got, mean, rtol=1e-5, atol=1e-9), \
+        "all-reduced gradients are not the mean of the ranks' gradients"
+    assert world == 1 or not torch.equal(every[0], every[-1]), "ranks were meant to train on different rays"
+    opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    copies = nd.all_gather_rows(flat[None].contiguous(), [1] * world)
+    assert all(torch.equal(copies[0], copies[r]) for r in range(world)), "replicas diverged after the optimizer step"
+    return int(out["n"][0].shape[0])
+
+
 def main():
     rank, world, dev = nd.init_from_env()
     import torch.distributed as dist
-    assert dist.is_initialized() and dist.get_backend() == "nccl", "RCCL process group expected"
+    want = os.environ.get("NM_EXPECT_BACKEND", "nccl")
+    assert dist.is_initialized() and dist.get_backend() == want, f"{want} process group expected, got {dist.get_backend()}"
     kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
     w = S.make_scene_weights(**kw)
     mlp = hip_ops.HipMLP(w, kw, dev)
@@ -58,15 +141,17 @@ def main():
     gathered = nd.all_gather_rows(local[None].contiguous(), [1] * world)
     assert torch.allclose(lin.weight.grad, gathered.mean(0), rtol=1e-6, atol=1e-7)
 
+    mesh_vertices = model_level_checks(rank, world, dev)
+
     # barrier + max-over-ranks reduction as bench.py uses them
     t = torch.tensor([float(rank)], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    nd.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t) == world - 1
     dist.barrier()
     torch.cuda.synchronize()
     if rank == 0:
-        print(f"DIST_OK world={world} backend={dist.get_backend()} rays={hh * ww} planes={n} "
-              f"vertices={int(v1[0].shape[0])}", flush=True)
+        print(f"DIST_OK world={world} backend={dist.get_backend()} device={dev} rays={hh * ww} planes={n} "
+              f"vertices={int(v1[0].shape[0])} mesh_vertices={mesh_vertices}", flush=True)
     nd.shutdown()
 
 
