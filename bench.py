@@ -12,9 +12,15 @@ inverse-CDF resample -> fine MLP -> composite), ray directions already resident 
 
 Multi-GPU: one process per GPU.  `python bench.py --gpus N` with no launcher environment re-executes itself
 under `torch.distributed.run --nproc-per-node N` (and exits non-zero if the node has fewer than N GPUs); under
-a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Views are independent -> rank r renders view
-(step * N + r) (weak scaling), followed by the one real exchange step of the path, an RCCL all-gather of the
-rendered pixels (7.68 MB / rank / view).
+a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Default `--mode weak` (BASELINE config 3: the test set's views
+dealt to the ranks): rank r renders view (step * N + r), followed by the one real exchange step of the path, an RCCL
+all-gather of the rendered pixels (7.68 MB / rank / view).  `--mode strong`: every step is ONE view whose rays are
+split into contiguous ranges over the ranks (`dist.render_view_sharded`), total work fixed.  At N > 1 the line also
+carries the sharded `mesh` (config 4: axis-0 slabs of the density grid, all-gather, marching cubes; compute and
+all-gather times separately) and `buff` (config 5: ray-sharded) objects with per-rank roofline fractions.
+`--ranks-per-gpu k` (k > 1) is a FUNCTIONAL mode for boxes with fewer GPUs than ranks: k processes share each GPU over
+the gloo backend (RCCL refuses duplicate devices); the line then says `"ranks_per_gpu": k` and its rates are not scaling
+numbers.
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value, roofline of the dominant kernel
 (the fused MLP; fp32 MFMA peak 157.3 TFLOP/s), the CPU baseline (the oracle = torch-CPU port of the reference
@@ -139,18 +145,58 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10):
             "workload": "training step: 8x256 coarse+fine, 64+128 samples, perturb + noise, Adam (forward + HIP backward + step)"}
 
 
-def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_points=262144):
-    """BASELINE config 4 (`mesh_nerf.py --res 480 --limit 1.2 --iso-level 32`, /root/reference/src/mesh_nerf.py:27-92)
-    on one GPU: the density-grid query (fused MLP, density-only trunk) against the fp32 MFMA roof, marching cubes
-    against the HBM roof on its algorithmic bytes (4 B / voxel), the mesh compared bitwise IN THIS RUN with the C
-    oracle on the same grid, and the CPU legs (oracle MLP on a bounded point sample; oracle marching cubes)."""
+def _wall_max(fn, dev, use_dist):
+    """Wall time of `fn` between two (barrier +) device synchronisations, max over ranks; returns (seconds, result)."""
+    from nerfmeshes_amd import dist as nd
+    import torch.distributed as dist
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        nd.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def _per_rank(value, dev, world, use_dist):
+    from nerfmeshes_amd import dist as nd
+    if not use_dist:
+        return [float(value)]
+    mine = torch.tensor([[float(value)]], dtype=torch.float64, device=dev)
+    return [float(x) for x in nd.all_gather_rows(mine, [1] * world).reshape(-1)]
+
+
+def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_points=262144, rank=0, world=1,
+               use_dist=False, cpu_legs=True):
+    """BASELINE config 4 (`mesh_nerf.py --res 480 --limit 1.2 --iso-level 32`, /root/reference/src/mesh_nerf.py:27-92):
+    the density-grid query (fused MLP, density-only trunk) against the fp32 MFMA roof -- rank r evaluates its slab of
+    axis-0 planes (`dist.slab_range`), one all-gather assembles the grid on every rank -- then marching cubes against the
+    HBM roof on its algorithmic bytes (4 B / voxel), the mesh compared bitwise IN THIS RUN with the C oracle on the same
+    grid (rank 0), and at N = 1 the CPU legs (oracle MLP on a bounded point sample; oracle marching cubes)."""
     import numpy as np
+    from nerfmeshes_amd import dist as nd
     from nerfmeshes_amd.mesh_nerf import extract_iso_level
     ax = torch.linspace(-limit, limit, res).to(dev)
-    grid = torch.empty(res ** 3, dtype=torch.float32, device=dev)
-    g_min, g_avg, _ = _timed(lambda: fine.grid_query(ax, ax, ax, density_only=True, out=grid), 1)
+    plane = res * res
+    lo, hi = nd.slab_range(res, rank, world)
+    counts = [(b - a) * plane for a, b in (nd.slab_range(res, r, world) for r in range(world))]
+    slab = torch.empty((hi - lo) * plane, dtype=torch.float32, device=dev)
+    query = lambda: fine.grid_query(ax, ax, ax, first=lo * plane, count=(hi - lo) * plane, density_only=True, out=slab)  # noqa: E731
+    g_own, _, _ = _timed(query, 1)                           # this rank's kernel time (HIP events)
+    g_wall, _ = _wall_max(query, dev, use_dist)              # slowest rank, wall
+    if world > 1:
+        nd.all_gather_rows(slab, counts)                     # warm the communicator / staging buffers
+        a_wall, grid = _wall_max(lambda: nd.all_gather_rows(slab, counts), dev, use_dist)
+    else:
+        a_wall, grid = 0.0, slab
     density = grid.view(res, res, res)
-    flops = res ** 3 * fine.flops_per_sample(density_only=True)
+    flops_own = (hi - lo) * plane * fine.flops_per_sample(density_only=True)
+    frac_own = flops_own / (g_own * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
 
     class _A:   # the script's adaptive iso level (mesh_nerf.py:56-65)
         iso_level = iso_request
@@ -159,18 +205,28 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
         iso = float(extract_iso_level(density, _A))
     m_min, m_avg, (v, f, n, val) = _timed(lambda: hip_ops.marching_cubes(density, iso), 5)
     vol_bytes = res ** 3 * 4
+    total_flops = res ** 3 * fine.flops_per_sample(density_only=True)
     out = {
-        "workload": f"mesh_nerf --res {res} --limit {limit} --iso-level {iso_request}: density grid + marching cubes, 1 GPU",
-        "grid_query": {"points": res ** 3, "ms": g_min, "algorithmic_flops_per_point": fine.flops_per_sample(density_only=True),
-                       "roofline": {"bound": "mfma", "achieved": flops / (g_min * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": flops / (g_min * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}},
+        "workload": f"mesh_nerf --res {res} --limit {limit} --iso-level {iso_request}: density grid + marching cubes, "
+                    + (f"axis-0 slabs over {world} ranks + all-gather of the grid, marching cubes on every rank" if world > 1 else "1 GPU"),
+        "grid_query": {"points": res ** 3, "ms": g_wall * 1e3, "planes_per_rank": [c // plane for c in counts],
+                       "algorithmic_flops_per_point": fine.flops_per_sample(density_only=True),
+                       "roofline": {"bound": "mfma", "achieved": total_flops / g_wall / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS * world,
+                                    "unit": "TFLOP/s", "frac": total_flops / g_wall / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+                                    "frac_per_rank": _per_rank(frac_own, dev, world, use_dist),
+                                    "note": "whole-job: all ranks' points / slowest rank's wall time, peak x ranks; per rank: own slab / own kernel time"}},
+        "all_gather": {"ms": a_wall * 1e3, "bytes_total": vol_bytes, "GBps_per_rank_received": (vol_bytes * (world - 1) / world) / a_wall / 1e9 if a_wall else None},
         "marching_cubes": {"iso": iso, "vertices": int(v.shape[0]), "faces": int(f.shape[0]), "ms_min": m_min, "ms_avg": m_avg,
                            "algorithmic_bytes": vol_bytes,
                            "roofline": {"bound": "hbm", "achieved": vol_bytes / (m_min * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": vol_bytes / (m_min * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "note": "whole nm_mc_count + nm_mc_emit call incl. workspace allocation and the host sync"},
+        "ms_total": g_wall * 1e3 + a_wall * 1e3 + m_min,
+        "all_gather_share_of_total": a_wall * 1e3 / (g_wall * 1e3 + a_wall * 1e3 + m_min),
     }
-    # ---- CPU legs (oracle = checker + baseline)
+    if rank != 0:
+        return out
+    # ---- CPU side: the checker (every N) and the baselines (N = 1 only)
     from oracle import mc_oracle, nerf_oracle as O
     vol = density.cpu().numpy()
     t0 = time.perf_counter()
@@ -181,9 +237,11 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
     out["marching_cubes"]["iso_equals_numpy_fp32"] = bool(iso == iso_numpy)
     same = (np.array_equal(rf, f.cpu().numpy()) and rv.tobytes() == v.cpu().numpy().tobytes()
             and rn.tobytes() == n.cpu().numpy().tobytes() and rval.tobytes() == val.cpu().numpy().tobytes())
-    out["marching_cubes"].update({"bitwise_identical_to_oracle": bool(same),
-                                  "cpu_baseline": {"value": dt, "unit": "s", "cores": 1, "kind": "port",
-                                                   "sample": f"the full {res}^3 grid (oracle/mc_lewiner.c)"}})
+    out["marching_cubes"]["bitwise_identical_to_oracle"] = bool(same)
+    if not cpu_legs:
+        return out
+    out["marching_cubes"]["cpu_baseline"] = {"value": dt, "unit": "s", "cores": 1, "kind": "port",
+                                             "sample": f"the full {res}^3 grid (oracle/mc_lewiner.c)"}
     spec = O.MLPSpec(**MLP_KW)
     pts = O.grid_points(limit, res)[:: max(1, res ** 3 // cpu_points)][:cpu_points]
     with torch.no_grad():
@@ -191,22 +249,31 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
         t0 = time.perf_counter()
         ref = O.mlp_forward(weights, spec, pts, pts)
         dt = time.perf_counter() - t0
+        # the reference's own loop shape: batches of --batch-size 1024 points (mesh_nerf.py:43-48,239), bounded sample
+        small = pts[:65536]
+        t0 = time.perf_counter()
+        for s0 in range(0, small.shape[0], 1024):
+            O.mlp_forward(weights, spec, small[s0:s0 + 1024], small[s0:s0 + 1024])
+        dt1024 = time.perf_counter() - t0
     got = fine.sample_points(pts.to(dev), pts.to(dev)).cpu()
     out["grid_query"]["cpu_baseline"] = {"value": pts.shape[0] / dt, "unit": "points/s", "cores": threads,
                                          "host_cores": os.cpu_count(), "kind": "port",
-                                         "sample": f"{pts.shape[0]} strided grid points, one batch, {dt:.2f} s"}
-    out["grid_query"]["speedup_vs_cpu"] = (res ** 3 / (g_min * 1e-3)) / (pts.shape[0] / dt)
+                                         "sample": f"{pts.shape[0]} strided grid points, one batch, {dt:.2f} s",
+                                         "at_reference_batch_1024": {"value": small.shape[0] / dt1024, "unit": "points/s",
+                                                                     "sample": f"{small.shape[0]} points in batches of 1024 (mesh_nerf.py --batch-size default), {dt1024:.2f} s"}}
+    out["grid_query"]["speedup_vs_cpu"] = (res ** 3 / g_wall) / (pts.shape[0] / dt)
     scale = float(ref[:, 3].abs().max()) + 1.0
     out["grid_query"]["parity"] = {"max_abs_dsigma_over_scale": float((got[:, 3] - ref[:, 3]).abs().max()) / scale,
                                    "max_abs_drgb": float((got[:, :3] - ref[:, :3]).abs().max()), "points": int(pts.shape[0])}
     return out
 
 
-def buff_probe(dev, cpu_rays=2048):
+def buff_probe(dev, cpu_rays=2048, rank=0, world=1, use_dist=False, cpu_legs=True):
     """BASELINE config 5 geometry (/root/reference/config/buff-colmap-fern.yml:31-74): BuFFModel.query on a
     504x378 view (fern 4032x3024 / 8), 192 samples per ray placed by the voxel-tree sampler (12^3 voxels on
-    [-0.6, 0.6]^3), single 8x256 network, bounds [0, 1.2], synthetic pose on radius 1."""
-    from nerfmeshes_amd import models
+    [-0.6, 0.6]^3), single 8x256 network, bounds [0, 1.2], synthetic pose on radius 1.  At N > 1 the view's rays are
+    split into contiguous ranges over the ranks and the pixels all-gathered (strong scaling of one view)."""
+    from nerfmeshes_amd import dist as nd, models
     hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=192, num_fine=64, near=0.0, far=1.2, dataset_type="colmap")
     w = S.make_mlp_weights(9, density_gain=1500.0, density_bias=60.0, **MLP_KW)
     model = models.BuFFModel(hp)
@@ -219,40 +286,52 @@ def buff_probe(dev, cpu_rays=2048):
     o, d = hip_ops.ray_bundle(S.pose_spherical(30.0, -20.0, 1.0), hh, ww, 0.8 * ww, device=dev)
     bounds = torch.tensor([0.0, 1.2])
     chunk = 65536
+    rays = hh * ww
+    lo, hi = nd.split_range(rays, rank, world)
+    counts = [b_ - a_ for a_, b_ in (nd.split_range(rays, r, world) for r in range(world))]
 
     def view():
         outs = []
-        for s in range(0, d.shape[0], chunk):
-            outs.append(model.query((o[None], d[s:s + chunk], bounds)).rgb_map)
-        return torch.cat(outs, 0)
+        for s0 in range(lo, hi, chunk):
+            outs.append(model.query((o[None], d[s0:min(s0 + chunk, hi)], bounds)).rgb_map)
+        mine = torch.cat(outs, 0)
+        return nd.all_gather_rows(mine, counts) if world > 1 else mine
 
     with torch.no_grad():
         hip_ops.mlp_profile_enable(True)
         view()
         torch.cuda.synchronize()
         hip_ops.mlp_profile_read()
-        t0 = time.perf_counter()
         reps = 3
-        for _ in range(reps):
-            rgb = view()
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / reps
+        wall, rgb = _wall_max(lambda: [view() for _ in range(reps)][-1], dev, use_dist)
+        wall /= reps
         launches, kernel_ms, kernel_flops = hip_ops.mlp_profile_read()
         hip_ops.mlp_profile_enable(False)
-        i_min, i_avg, (z, idx, mask) = _timed(
-            lambda: model.tree.batch_ray_voxel_intersect(o[None], d[:chunk], 0.0, 1.2, 192), 5)
-    rays = hh * ww
+        timings = {}
+        for tie in ("stable", "reference"):
+            model.tree.tie_order = tie
+            t_min, t_avg, (z, idx, mask) = _timed(lambda: model.tree.batch_ray_voxel_intersect(o[None], d[:chunk], 0.0, 1.2, 192), 5)
+            timings[tie] = {"ms_min": t_min, "ms_avg": t_avg}
+        model.tree.tie_order = "stable"
     achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     out = {
-        "workload": "buff-colmap-fern geometry: BuFFModel.query, 504x378 rays x 192 tree-placed samples, 8x256 network, 1 GPU",
-        "value": rays / wall, "unit": "rays/s", "ms_per_view": wall * 1e3, "rays_per_view": rays, "chunk_rays": chunk,
+        "workload": "buff-colmap-fern geometry: BuFFModel.query, 504x378 rays x 192 tree-placed samples, 8x256 network, "
+                    + (f"rays split over {world} ranks + all-gather of the pixels" if world > 1 else "1 GPU"),
+        "value": rays / wall, "unit": "rays/s", "ms_per_view": wall * 1e3, "rays_per_view": rays, "rays_per_rank": counts, "chunk_rays": chunk,
+        "scaling": "strong" if world > 1 else None,
         "algorithmic_flops_per_ray": 192 * model.model.hip().flops_per_sample(),
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "launches": launches,
+                     "frac_per_rank": _per_rank(achieved / FP32_MFMA_PEAK_TFLOPS, dev, world, use_dist),
                      "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / (wall * reps)},
-        "nm_buff_intersect": {"ms_min": i_min, "ms_avg": i_avg, "rays": chunk, "voxels": int(model.tree.voxels.shape[0]),
-                              "samples": 192, "rays_hitting_tree": float(mask.float().mean())},
+        "nm_buff_intersect": {"rays": chunk, "voxels": int(model.tree.voxels.shape[0]), "samples": 192,
+                              "rays_hitting_tree": float(mask.float().mean()),
+                              "tie_order_stable": timings["stable"], "tie_order_reference": timings["reference"],
+                              "note": "stable: every id is the voxel its sample lies in (eval default); reference: the reference's "
+                                      "own ids (its three unstable sorts replayed), the default while training"},
     }
+    if rank != 0 or not cpu_legs:
+        return out
     # ---- CPU leg: the oracle's BuFF chain on a bounded strided ray sample + parity on those rays
     from oracle import nerf_oracle as O, parity
     spec, rs = O.MLPSpec(**MLP_KW), O.RenderSpec(num_coarse=192, num_fine=0)
@@ -321,32 +400,97 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def tiny_probe(dev, cpu_legs=True):
+    """BASELINE config 1 (`config/tiny.yaml` sizes: 4-layer x 64 MLP, 32 coarse samples, no fine network, ONE 400x400 view;
+    the reference runs it on the CPU as plumbing): the same product path on the GPU, its MLP kernel against the fp32 MFMA
+    roof (useful FLOP only -- the 64-wide layers pad their encodings), parity against the oracle on a ray sample, and the
+    oracle timed on the host."""
+    kw = dict(num_layers=4, hidden_size=64, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    w = S.make_mlp_weights(11, density_gain=30.0, density_bias=0.3, **kw)
+    net = hip_ops.HipMLP(w, kw, dev)
+    hh = ww = 400
+    o, d = hip_ops.ray_bundle(S.orbit_poses(4)[1], hh, ww, S.LEGO_FOCAL_800 / 2, device=dev)
+    near, far = torch.tensor([NEAR], device=dev), torch.tensor([FAR], device=dev)
+    u_c = torch.linspace(0.0, 1.0, 32).to(dev)
+
+    def view():
+        return hip_ops.render_rays(net, None, o[None], d, near, far, u_c, None)[0]["rgb_map"]
+
+    hip_ops.mlp_profile_enable(True)
+    view()
+    torch.cuda.synchronize()
+    hip_ops.mlp_profile_read()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rgb = view()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    launches, kernel_ms, kernel_flops = hip_ops.mlp_profile_read()
+    hip_ops.mlp_profile_enable(False)
+    achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    out = {"workload": "config 1 (tiny): 4x64 MLP, 32 coarse samples, no fine network, one 400x400 view, 1 GPU",
+           "value": hh * ww / wall, "unit": "rays/s", "ms_per_view": wall * 1e3, "rays_per_view": hh * ww,
+           "algorithmic_flops_per_ray": 32 * net.flops_per_sample(),
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "launches": launches,
+                        "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / (wall * reps),
+                        "note": "one 160 000-ray launch of 5.1 M samples lasts ~2 ms: the share of wall not in the MLP kernel is the per-ray kernels and launch latency"}}
+    if not cpu_legs:
+        return out
+    from oracle import nerf_oracle as O, parity
+    spec, rs = O.MLPSpec(**kw), O.RenderSpec(num_coarse=32, num_fine=0)
+    idx = torch.arange(0, hh * ww, 10, device=dev)                       # 16 000 rays
+    dc = d[idx].cpu()
+    with torch.no_grad():
+        threads = _pick_threads(lambda: O.render(w, None, spec, None, rs, o[None].cpu(), dc[:2048], NEAR, FAR), os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        ref = torch.cat([O.render(w, None, spec, None, rs, o[None].cpu(), dc[s0:s0 + 2048], NEAR, FAR)[0]["rgb_map"]
+                         for s0 in range(0, dc.shape[0], 2048)])
+        dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": dc.shape[0] / dt, "unit": "rays/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+                           "sample": f"{dc.shape[0]} rays of the view (stride 10), chunks of 2048, {dt:.2f} s"}
+    out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    out["parity"] = parity.psnr_parity(rgb[idx].cpu(), ref, chunk=2048)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=65536, help="rays per nm_render_rays call")
+    ap.add_argument("--mode", choices=("weak", "strong"), default="weak",
+                    help="weak: one whole view per rank and step; strong: one view per step, its rays split over the ranks")
+    ap.add_argument("--ranks-per-gpu", type=int, default=1,
+                    help="functional mode: this many processes share each GPU over gloo (not a scaling measurement)")
+    ap.add_argument("--mesh-res", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
     ap.add_argument("--no-mesh-probe", action="store_true")
     ap.add_argument("--no-buff-probe", action="store_true")
     ap.add_argument("--no-b3-probe", action="store_true")
+    ap.add_argument("--no-tiny-probe", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip every secondary object and the CPU legs")
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline = args.no_train_probe = args.no_mesh_probe = args.no_buff_probe = args.no_b3_probe = True
+        args.no_tiny_probe = True
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback exists for the hot path)")
     visible = torch.cuda.device_count()
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
+    if args.gpus < 1 or args.ranks_per_gpu < 1:
+        raise SystemExit("--gpus and --ranks-per-gpu must be >= 1")
     if args.gpus > visible:
         raise SystemExit(f"--gpus {args.gpus} but only {visible} GPU(s) are visible on this node")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # no launcher: become one.  One process per GPU over RCCL, rendezvous on 127.0.0.1.
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+    ranks = args.gpus * args.ranks_per_gpu
+    if args.ranks_per_gpu > 1:
+        os.environ["NERFMESHES_RANKS_PER_GPU"] = str(args.ranks_per_gpu)
+    if "WORLD_SIZE" not in os.environ and ranks > 1:
+        # no launcher: become one.  One process per rank, rendezvous on 127.0.0.1.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
 
@@ -357,21 +501,23 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    from nerfmeshes_amd import dist as nd
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != ranks:
+        raise SystemExit(f"--gpus {args.gpus} x --ranks-per-gpu {args.ranks_per_gpu} but WORLD_SIZE={world}")
     dist = None
-    # a launcher environment (WORLD_SIZE set, also WORLD_SIZE=1) or NM_BENCH_FORCE_DIST=1 exercises the RCCL path
+    # a launcher environment (WORLD_SIZE set, also WORLD_SIZE=1) or NM_BENCH_FORCE_DIST=1 exercises the collective path
     use_dist = world > 1 or "WORLD_SIZE" in os.environ or os.environ.get("NM_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("RANK", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        rank, _, dev = nd.init_from_env()     # RCCL ("nccl"), one rank per GPU; gloo when ranks share a GPU
+    else:
+        rank, dev = 0, torch.device("cuda", 0)
+        torch.cuda.set_device(0)
 
     weights = S.make_scene_weights(**MLP_KW)
     coarse = hip_ops.HipMLP(weights, MLP_KW, dev)
@@ -380,22 +526,27 @@ def main():
     u_f = torch.linspace(0.0, 1.0, NUM_FINE).to(dev)
     near, far = torch.tensor([NEAR], device=dev), torch.tensor([FAR], device=dev)
 
+    strong = args.mode == "strong"
     total_steps = args.warmup + args.steps
-    poses = S.orbit_poses(max(total_steps * world, 1))
-    views = []   # ray directions resident in HBM before the timed region
+    views_per_step = 1 if strong else world
+    poses = S.orbit_poses(max(total_steps * views_per_step, 1))
+    lo, hi = nd.split_range(H * W, rank, world) if strong else (0, H * W)
+    counts = [b - a for a, b in (nd.split_range(H * W, r, world) for r in range(world))] if strong else [H * W] * world
+    views = []   # ray directions resident in HBM before the timed region (strong: this rank's range of the step's view)
     for s in range(total_steps):
-        o, d = hip_ops.ray_bundle(poses[s * world + rank], H, W, S.LEGO_FOCAL_800, device=dev)
+        o, d = hip_ops.ray_bundle(poses[s if strong else s * world + rank], H, W, S.LEGO_FOCAL_800, lo, hi - lo, device=dev)
         views.append((o[None].contiguous(), d))
-    image = torch.empty(H * W, 3, device=dev)
-    gathered = torch.empty(world * H * W, 3, device=dev) if use_dist else None
+    image = torch.empty(hi - lo, 3, device=dev)
+    gathered = None
 
     def step(i):
+        nonlocal gathered
         o, d = views[i]
-        for s in range(0, H * W, args.chunk):
+        for s in range(0, hi - lo, args.chunk):
             _, fb = hip_ops.render_rays(coarse, fine, o, d[s:s + args.chunk], near, far, u_c, u_f)
             image[s:s + args.chunk] = fb["rgb_map"]
         if use_dist:
-            dist.all_gather_into_tensor(gathered, image)
+            gathered = nd.all_gather_rows(image, counts)     # weak: `world` views; strong: the one view, in ray order
 
     def fence():
         if use_dist:
@@ -418,50 +569,61 @@ def main():
     rccl = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        nd.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # what the all-gather actually delivered: every rank's slot of the last step must hold THAT rank's pixels
         # (slot checksums are compared with the checksums the ranks computed locally), and per-rank roofline fractions
-        mine = torch.stack([image.double().sum(), torch.tensor(achieved, device=dev, dtype=torch.float64)])
-        allv = torch.empty(world, 2, device=dev, dtype=torch.float64)
-        dist.all_gather_into_tensor(allv, mine)
-        slots = gathered.view(world, H * W, 3).double().sum(dim=(1, 2))
+        mine = torch.stack([image.double().sum(), torch.tensor(achieved, device=dev, dtype=torch.float64)])[None]
+        allv = nd.all_gather_rows(mine.contiguous(), [1] * world)
+        starts = [sum(counts[:r]) for r in range(world)]
+        slots = torch.stack([gathered[starts[r]:starts[r] + counts[r]].double().sum() for r in range(world)])
         rccl = {"backend": dist.get_backend(), "ranks_in_all_gather": int(dist.get_world_size()),
                 "gathered_bytes_per_step": int(gathered.numel() * 4),
                 "slots_match_rank_checksums": bool(torch.allclose(slots, allv[:, 0], rtol=1e-9, atol=0)),   # fp64 sums, two reduction shapes
                 "roofline_frac_per_rank": [float(x) / FP32_MFMA_PEAK_TFLOPS for x in allv[:, 1]]}
 
-    rays_total = args.steps * H * W * world
+    rays_total = args.steps * H * W * views_per_step
     value = rays_total / elapsed
     flops_per_ray = (NUM_COARSE + NUM_COARSE + NUM_FINE) * coarse.flops_per_sample()
 
-    traffic = None
-    for name in ("r02_pmc_mlp_kernel.json", "r01_pmc_mlp_kernel.json"):
+    traffic, traffic_source = None, None
+    for name in ("r03_pmc_mlp_kernel.json", "r02_pmc_mlp_kernel.json", "r01_pmc_mlp_kernel.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
+                                  "(committed profile, NOT measured inside this run)")
                 break
             except Exception:
                 traffic = None
 
+    if world == 1:
+        parallelism = "single GPU"
+    elif strong:
+        parallelism = f"each view's rays split over {world} ranks (contiguous ranges), all-gather of pixels"
+    else:
+        parallelism = f"views dealt to {world} ranks, all-gather of pixels"
     out = {
         "metric": "rendered rays/sec (64+128 samples, 8x256 MLP), lego scene geometry",
-        "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": value, "unit": "rays/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "nerf-synthetic lego: 8x256 coarse+fine MLP, 64 coarse + 128 fine samples, "
-                               "800x800 view per step per GPU, bounds [2,6], seeded weights/orbit poses",
-                   "rays_per_step_per_gpu": H * W, "chunk_rays": args.chunk,
-                   "parallelism": f"views sharded over {world} GPU(s), RCCL all-gather of pixels" if world > 1
-                   else "single GPU"},
+                               + ("one 800x800 view per step, rays split over the ranks" if strong else "800x800 view per step per rank")
+                               + ", bounds [2,6], seeded weights/orbit poses",
+                   "rays_per_step_per_rank": hi - lo, "chunk_rays": args.chunk, "parallelism": parallelism},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "nm::mlp_kernel3<256,10,4,8,8,1>", "launches": launches,
                      "avg_launch_ms": kernel_ms / max(launches, 1),
                      "algorithmic_flops_per_ray": flops_per_ray,
                      "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / elapsed},
     }
+    if args.ranks_per_gpu > 1:
+        out["ranks_per_gpu"] = args.ranks_per_gpu
+        out["note"] = (f"FUNCTIONAL run: {world} ranks share {args.gpus} GPU(s) over gloo (host-staged collectives); it exercises the "
+                       "N-rank code paths on the real kernels and is not a scaling measurement")
     if rccl is not None:
         out["rccl"] = rccl
 
@@ -480,16 +642,33 @@ def main():
                                          f"({threads} torch threads = fastest of 8/16/32/64/{os.cpu_count()} on this host)",
                                "speedup": value / rps}
         out["parity"] = parity.psnr_parity(fb["rgb_map"].cpu(), ref_rgb, chunk=2048)
-    for name, skip, fn in (("train", args.no_train_probe, lambda: train_probe(dev, views[0][1], views[0][0])),
-                           ("mesh", args.no_mesh_probe, lambda: mesh_probe(dev, weights, fine)),
-                           ("buff", args.no_buff_probe, lambda: buff_probe(dev)),
+    cpu_legs = world == 1 and not args.no_cpu_baseline
+    shard = dict(rank=rank, world=world, use_dist=use_dist and world > 1, cpu_legs=cpu_legs)
+    # objects every rank takes part in (sharded at N > 1) ...
+    for name, skip, fn in (("mesh", args.no_mesh_probe, lambda: mesh_probe(dev, weights, fine, res=args.mesh_res, **shard)),
+                           ("buff", args.no_buff_probe, lambda: buff_probe(dev, **shard))):
+        if skip:
+            continue
+        try:
+            res = fn()
+        except Exception as e:  # the headline line must not depend on a secondary figure
+            if world > 1:
+                raise           # a rank that leaves a collective early would hang the others: fail loudly instead
+            res = {"error": repr(e)}
+        if rank == 0:
+            out[name] = res
+    # ... and single-GPU objects
+    for name, skip, fn in (("tiny", args.no_tiny_probe, lambda: tiny_probe(dev, cpu_legs)),
+                           ("train", args.no_train_probe, lambda: train_probe(dev, views[0][1], views[0][0])),
                            ("bf16x3", args.no_b3_probe,
                             lambda: b3_probe(dev, weights, views, near, far, u_c, u_f, args.chunk, ref_idx, ref_rgb))):
         if solo and not skip:
             try:
                 out[name] = fn()
-            except Exception as e:  # the headline line must not depend on a secondary figure
+            except Exception as e:
                 out[name] = {"error": repr(e)}
+    if use_dist:
+        dist.barrier()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -82,6 +82,31 @@ def test_bench_rccl_leg_on_one_rank():
     assert line["value"] > 1e5 and 0.5 < line["roofline"]["frac"] < 1.0
 
 
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu_carries_the_sharded_objects(mode):
+    """`python bench.py --gpus 1 --ranks-per-gpu 2` (self-launching, gloo): the N > 1 legs of BASELINE configs 3 / 4 / 5
+    -- views dealt to the ranks or one view's rays split over them, the slab-sharded density grid + all-gather +
+    marching cubes (bitwise vs the C oracle in-run), the ray-sharded BuFF view -- all present on the line, with
+    per-rank roofline fractions, and labelled as a functional (not a scaling) run."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--ranks-per-gpu", "2", "--steps", "1", "--warmup", "1",
+                        "--mode", mode, "--mesh-res", "120", "--no-cpu-baseline"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    printed = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, printed
+    line = json.loads(printed[0])
+    assert line["n_gpus"] == 1 and line["ranks_per_gpu"] == 2 and line["scaling"] == mode and "FUNCTIONAL" in line["note"]
+    assert line["rccl"]["backend"] == "gloo" and line["rccl"]["ranks_in_all_gather"] == 2
+    assert line["rccl"]["slots_match_rank_checksums"] is True and len(line["rccl"]["roofline_frac_per_rank"]) == 2
+    assert line["config"]["rays_per_step_per_rank"] == (320000 if mode == "strong" else 640000)
+    mesh, buff = line["mesh"], line["buff"]
+    assert mesh["grid_query"]["planes_per_rank"] == [60, 60] and len(mesh["grid_query"]["roofline"]["frac_per_rank"]) == 2
+    assert mesh["all_gather"]["ms"] > 0 and mesh["all_gather"]["bytes_total"] == 120 ** 3 * 4
+    assert mesh["marching_cubes"]["bitwise_identical_to_oracle"] is True and mesh["marching_cubes"]["iso_equals_numpy_fp32"] is True
+    assert buff["rays_per_rank"] == [95256, 95256] and len(buff["roofline"]["frac_per_rank"]) == 2 and buff["value"] > 1e4
+    assert "cpu_baseline" not in line and "train" not in line            # N = 1 only
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` with no launcher must start two ranks by itself and print n_gpus: 2."""
     if torch.cuda.device_count() < 2:
