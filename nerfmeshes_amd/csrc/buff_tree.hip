@@ -13,6 +13,10 @@
 // with its own z values on ~90 % of samples (tests/test_oracle_golden.py::test_buff_...).
 #include "nm_internal.h"
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace nm {
 
 constexpr int BUFF_MAX_HITS = 512;     // boxes one ray can cross (12^3 root grid: <= 34; refined trees more)
@@ -272,15 +276,15 @@ __global__ __launch_bounds__(256) void buff_random_kernel(const float* __restric
 // ties decides (a) the order of equal entry depths -- common: every voxel of a slab shares the slab's entry plane --
 // hence the 0/1 hit sequence, (b) which crossed voxel each slot of the "rolled to the front" list is attributed to
 // (tree.py:306-309: the VALUES are placed by a boolean mask, in order; the INDICES come from the unstable sort), and
-// (c) the order of samples with equal depth.  This kernel replays exactly that: one wavefront per ray, the three
-// introsorts run on lane 0 over LDS (they are sequential algorithms), everything else is wave-parallel.  It exists
-// for parity (ids == the reference's, bit for bit, also on rays where they are not the voxels the samples lie in);
-// the default kernel above keeps the stable, geometrically meaningful order and is ~100x faster.
+// (c) the order of samples with equal depth.  buff_reference_ids_kernel replays exactly that, one wavefront per ray: the
+// ids are the reference's, bit for bit, also on rays where they are not the voxels the samples lie in.  Below first
+// the algorithm as libstdc++ writes it (sequential; used for the heap-sort fallback and on the host), then its
+// wave-parallel evaluation.
 struct CmpAsc {   // KeyValueCompAsc<float>: NaNs last
-    __device__ __forceinline__ bool operator()(float a, float b) const { return (!(a != a) && (b != b)) || (a < b); }
+    __host__ __device__ __forceinline__ bool operator()(float a, float b) const { return (!(a != a) && (b != b)) || (a < b); }
 };
 struct CmpDesc {  // KeyValueCompDesc<float>: NaNs first
-    __device__ __forceinline__ bool operator()(float a, float b) const { return ((a != a) && !(b != b)) || (a > b); }
+    __host__ __device__ __forceinline__ bool operator()(float a, float b) const { return ((a != a) && !(b != b)) || (a > b); }
 };
 
 template <typename Cmp>
@@ -288,11 +292,11 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
     float* k;
     unsigned short* ix;
     Cmp cmp;
-    __device__ __forceinline__ void swap(int i, int j) {
+    __host__ __device__ __forceinline__ void swap(int i, int j) {
         const float tk = k[i]; k[i] = k[j]; k[j] = tk;
         const unsigned short ti = ix[i]; ix[i] = ix[j]; ix[j] = ti;
     }
-    __device__ void move_median_to_first(int result, int a, int b, int c) {
+    __host__ __device__ void move_median_to_first(int result, int a, int b, int c) {
         if (cmp(k[a], k[b])) {
             if (cmp(k[b], k[c])) swap(result, b);
             else if (cmp(k[a], k[c])) swap(result, c);
@@ -301,7 +305,7 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
         else if (cmp(k[b], k[c])) swap(result, c);
         else swap(result, b);
     }
-    __device__ int unguarded_partition(int first, int last, int pivot) {
+    __host__ __device__ int unguarded_partition(int first, int last, int pivot) {
         for (;;) {
             while (cmp(k[first], k[pivot])) ++first;
             --last;
@@ -312,7 +316,7 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
         }
     }
     // heap fallback (__partial_sort(first, last, last) = make_heap + sort_heap) when the depth limit is reached
-    __device__ void push_heap(int first, int hole, int top, float vk, unsigned short vi) {
+    __host__ __device__ void push_heap(int first, int hole, int top, float vk, unsigned short vi) {
         int parent = (hole - 1) / 2;
         while (hole > top && cmp(k[first + parent], vk)) {
             k[first + hole] = k[first + parent]; ix[first + hole] = ix[first + parent];
@@ -320,7 +324,7 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
         }
         k[first + hole] = vk; ix[first + hole] = vi;
     }
-    __device__ void adjust_heap(int first, int hole, int len, float vk, unsigned short vi) {
+    __host__ __device__ void adjust_heap(int first, int hole, int len, float vk, unsigned short vi) {
         const int top = hole;
         int child = hole;
         while (child < (len - 1) / 2) {
@@ -336,7 +340,7 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
         }
         push_heap(first, hole, top, vk, vi);
     }
-    __device__ void heap_sort(int first, int last) {
+    __host__ __device__ void heap_sort(int first, int last) {
         const int len = last - first;
         if (len >= 2) {
             for (int parent = (len - 2) / 2;; --parent) {
@@ -351,13 +355,13 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
             adjust_heap(first, 0, last - first, vk, vi);
         }
     }
-    __device__ void unguarded_linear_insert(int last) {
+    __host__ __device__ void unguarded_linear_insert(int last) {
         const float vk = k[last]; const unsigned short vi = ix[last];
         int next = last - 1;
         while (cmp(vk, k[next])) { k[last] = k[next]; ix[last] = ix[next]; last = next; --next; }
         k[last] = vk; ix[last] = vi;
     }
-    __device__ void insertion_sort(int first, int last) {
+    __host__ __device__ void insertion_sort(int first, int last) {
         if (first == last) return;
         for (int i = first + 1; i != last; ++i) {
             if (cmp(k[i], k[first])) {
@@ -367,7 +371,7 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
             } else unguarded_linear_insert(i);
         }
     }
-    __device__ void sort(int n) {
+    __host__ __device__ void sort(int n) {
         if (n <= 0) return;
         int lg = 0;
         while ((2 << lg) <= n) ++lg;          // std::__lg(n)
@@ -395,25 +399,159 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
     }
 };
 
-__global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __restrict__ voxels, int nvox, int npad,
+
+// ---- the same three sorts, wave-parallel and still EXACT -----------------------------------------------------------
+// Running libstdc++'s introsort on one lane (above, round 2) costs ~1 ms per ray: every compare is an LDS round trip.
+// Its result, however, is a function of data-parallel steps:
+//  * __unguarded_partition(first, last, pivot): the left scan stops at every element with !(k < pivot) ("left
+//    stoppers"), the right scan at every element with !(pivot < k) ("right stoppers"); the j-th swap exchanges the j-th
+//    left stopper counted from the left with the j-th right stopper counted from the right, for as long as the former
+//    lies in front of the latter.  Neither scan ever revisits a swapped slot before the scans meet, so the pairing is a
+//    function of the ORIGINAL stopper positions: a ballot / popcount prefix gives every stopper its ordinal, two position
+//    lists in LDS pair them, all swaps of a partition happen at once.  The returned cut is min(next left stopper,
+//    last swapped right position) -- see partition() for the case analysis.
+//  * __final_insertion_sort is a STABLE sort of what the partition loop leaves, and that array consists of runs of at
+//    most 16 elements (longer only where the heap-sort fallback already sorted them) with every run <= the next one: an
+//    element's final slot is its position plus (smaller elements among the 15 behind it) minus (larger elements among
+//    the 15 in front of it) -- 30 comparisons, no data movement.
+//  * only the slots of the crossed boxes are needed from sorts 1 and 2: a range without any of them is left alone
+//    (partitioning permutes within its range only) -- for the 0/1 keys of sort 2 that skips almost everything.
+// One wavefront per ray, ~22 KB of LDS (7 rays per CU).  The sequential struct above remains as the heap-sort fallback
+// (depth limit 2 lg n: adversarial inputs only) and, on the host, for the one data-independent case -- a ray that
+// crosses nothing sorts an all-equal mask, whose first slot depends on n alone.
+constexpr int REF_MAX_HITS = 512;
+
+template <typename Cmp>
+struct WaveSort {
+    float* k;
+    unsigned short* ix;
+    unsigned short* la;        // left stoppers, ascending, first len/2 + 2 of them
+    unsigned short* lb;        // right stoppers, ascending (the j-th from the right is lb[nr - 1 - j])
+    unsigned short* stack;     // pending ranges: (first, last, depth) triples
+    int lane;
+    Cmp cmp;
+
+    __device__ __forceinline__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+
+    // __unguarded_partition over [first, last) against k[pivot]; every lane takes part
+    __device__ int partition(int first, int last, int pivot) {
+        const float pk = k[pivot];
+        const int cap = (last - first) / 2 + 2;
+        int nl = 0, nr = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (int base = first; base < last; base += 64) {
+            const int p = base + lane;
+            bool L = false, R = false;
+            if (p < last) { const float v = k[p]; L = !cmp(v, pk); R = !cmp(pk, v); }
+            const unsigned long long bl = __ballot(L), br = __ballot(R);
+            if (L) { const int j = nl + __popcll(bl & below); if (j < cap) la[j] = (unsigned short)p; }
+            if (R) lb[nr + __popcll(br & below)] = (unsigned short)p;
+            nl += __popcll(bl); nr += __popcll(br);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int lim = min(min(nl, cap), nr);
+        int J = 0;
+        for (int base = 0; base < lim; base += 64) {
+            const int j = base + lane;
+            int a = 0, b = 0;
+            bool ok = false;
+            if (j < lim) { a = la[j]; b = lb[nr - 1 - j]; ok = a < b; }      // true for a prefix of j: a ascends, b descends
+            const int c = __popcll(__ballot(ok));
+            if (ok) {
+                const float ka = k[a], kb = k[b]; k[a] = kb; k[b] = ka;
+                const unsigned short ia = ix[a], ib = ix[b]; ix[a] = ib; ix[b] = ia;
+            }
+            J += c;
+            if (c < 64) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // The scans meet after J swaps.  The left scan resumes behind its last swap and stops at the next left stopper
+        // of the CURRENT array: the next original one if it lies in front of the last swapped right position b_{J-1}
+        // (everything between the last swapped pair is untouched), else b_{J-1} itself, which now holds a left stopper.
+        // The right scan then stops at or in front of it (an original right stopper in the untouched middle, the last
+        // swapped left position, or the pivot), so the loop exits and returns that left position.
+        const int a_next = (J < nl) ? (int)la[J] : 0x7fffffff;              // J <= (len - 1) / 2 < cap
+        const int b_last = (J > 0) ? (int)lb[nr - J] : 0x7fffffff;
+        return uni(min(a_next, b_last));
+    }
+
+    template <typename Keep>   // keep(first, last): does the range hold an element whose final slot is needed?
+    __device__ void loop(int n, Keep keep) {
+        if (n <= 16) return;
+        int lg = 0;
+        while ((2 << lg) <= n) ++lg;
+        int sp = 0, first = 0, last = n, depth = 2 * lg;
+        for (;;) {
+            while (last - first > 16) {
+                if (!keep(first, last)) break;
+                if (depth == 0) {
+                    if (lane == 0) { Introsort<Cmp> seq{k, ix, cmp}; seq.heap_sort(first, last); }
+                    __builtin_amdgcn_wave_barrier();
+                    break;
+                }
+                --depth;
+                const int mid = first + (last - first) / 2, a = first + 1, c = last - 1;
+                const float ka = k[a], kb = k[mid], kc = k[c];
+                int m;                                     // __move_median_to_first(first, a, mid, c)
+                if (cmp(ka, kb)) m = cmp(kb, kc) ? mid : (cmp(ka, kc) ? c : a);
+                else m = cmp(ka, kc) ? a : (cmp(kb, kc) ? c : mid);
+                m = uni(m);
+                if (lane == 0) {
+                    const float t = k[first]; k[first] = k[m]; k[m] = t;
+                    const unsigned short ti = ix[first]; ix[first] = ix[m]; ix[m] = ti;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int cut = partition(first + 1, last, first);
+                if (lane == 0) { stack[3 * sp] = (unsigned short)cut; stack[3 * sp + 1] = (unsigned short)last; stack[3 * sp + 2] = (unsigned short)depth; }
+                ++sp;
+                last = cut;
+            }
+            if (sp == 0) break;
+            --sp;
+            __builtin_amdgcn_wave_barrier();
+            first = uni(stack[3 * sp]); last = uni(stack[3 * sp + 1]); depth = uni(stack[3 * sp + 2]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // slot of element i after the final (stable) insertion sort
+    __device__ __forceinline__ int final_slot(int i, int n) const {
+        const float v = k[i];
+        int f = i;
+        const int hi = min(n - 1, i + 15), lo = max(0, i - 15);
+        for (int j = i + 1; j <= hi; ++j) f += cmp(k[j], v) ? 1 : 0;
+        for (int j = lo; j < i; ++j) f -= cmp(v, k[j]) ? 1 : 0;
+        return f;
+    }
+};
+
+__global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __restrict__ voxels, int nvox, int npad, int spad,
+                                                               int key_bytes, int la_cap, int list_bytes, int zero_slot0,
                                                                const float* __restrict__ origins, int origins_per_ray,
                                                                const float* __restrict__ dirs, float near_, float far_,
                                                                const float* __restrict__ u, int64_t rays, int samples,
                                                                float* __restrict__ z_out, int64_t* __restrict__ idx_out,
-                                                               uint8_t* __restrict__ mask_out) {
+                                                               uint8_t* __restrict__ mask_out, int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* key = reinterpret_cast<float*>(smem);                       // [npad] sort keys
-    float* r_tmin = key + npad;                                        // [npad] crossed boxes in reference order
-    float* r_cum = r_tmin + npad;                                      // [npad]
-    float* p_s = r_cum + npad;                                         // [BUFF_MAX_SAMPLES]
-    float* p_z = p_s + BUFF_MAX_SAMPLES;
-    int* p_bucket = reinterpret_cast<int*>(p_z + BUFF_MAX_SAMPLES);
-    unsigned short* perm1 = reinterpret_cast<unsigned short*>(p_bucket + BUFF_MAX_SAMPLES);   // crosses_sorted.indices
-    unsigned short* perm2 = perm1 + npad;                                                     // crosses_start.indices
-    unsigned short* p_ix = perm2 + npad;                               // [BUFF_MAX_SAMPLES] z sort indices
-    unsigned short* p_vid = p_ix + BUFF_MAX_SAMPLES;
-    unsigned char* hit = reinterpret_cast<unsigned char*>(p_vid + BUFF_MAX_SAMPLES);          // [npad] by box index
+    // region A (key_bytes): sort keys; later the per-sample arrays.  region B (list_bytes): stopper lists / f per crossed box
+    float* key = reinterpret_cast<float*>(smem);
+    unsigned short* la = reinterpret_cast<unsigned short*>(smem + key_bytes);
+    unsigned short* lb = la + la_cap;
+    unsigned short* perm = reinterpret_cast<unsigned short*>(smem + key_bytes + list_bytes);    // [npad] index | hit << 15; later markers
+    unsigned short* T = perm + npad;                                   // [REF_MAX_HITS] box id of the c-th crossed box
+    unsigned short* vslot = T + REF_MAX_HITS;                          // [REF_MAX_HITS] box id attributed to bucket b
+    unsigned short* stack = vslot + REF_MAX_HITS;                      // [96]
+    float* r_tmin = reinterpret_cast<float*>(stack + 96);              // [REF_MAX_HITS] crossed boxes in reference order
+    float* r_cum = r_tmin + REF_MAX_HITS;
+    // per-sample arrays (alias region A once the sorts over the boxes are done)
+    float* p_s = key;
+    float* p_z = p_s + spad;
+    unsigned short* p_bucket = reinterpret_cast<unsigned short*>(p_z + spad);
+    unsigned short* p_ix = p_bucket + spad;
+    unsigned short* p_vid = p_ix + spad;
+    unsigned short* fslot = la;                                        // [REF_MAX_HITS] final slot (sort 1) of the c-th crossed box
     const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int64_t ray = blockIdx.x; ray < rays; ray += gridDim.x) {
         const float* o = origins + (origins_per_ray ? 3 * ray : 0);
         float inv[3], org[3];
@@ -440,35 +578,88 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
             tmax = hi_t[2] < tmax ? hi_t[2] : tmax;
             return valid && (tmin >= near_) && (tmax <= far_);
         };
-        for (int n = lane; n < nvox; n += 64) {
-            float tmin, tmax;
-            hit[n] = slab(n, tmin, tmax) ? 1 : 0;
-            key[n] = tmin;
-            perm1[n] = (unsigned short)n;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { Introsort<CmpAsc> s1{key, perm1, CmpAsc()}; s1.sort(nvox); }      // tree.py:300
-        __builtin_amdgcn_wave_barrier();
-        // crossed boxes in sorted order (tree.py:303-309: values placed through the boolean mask, i.e. in order)
         int K = 0;
         for (int base = 0; base < nvox; base += 64) {
-            const int p = base + lane;
-            bool v = false;
-            int n = 0;
-            if (p < nvox) { n = perm1[p]; v = hit[n] != 0; }
-            const unsigned long long bal = __ballot(v);
-            if (v) {
+            const int n = base + lane;
+            bool h = false;
+            if (n < nvox) {
                 float tmin, tmax;
-                slab(n, tmin, tmax);
-                const int pos = K + __popcll(bal & ((1ull << lane) - 1ull));
-                r_tmin[pos] = tmin;
-                r_cum[pos] = tmax - tmin;
+                h = slab(n, tmin, tmax);
+                key[n] = tmin;
+                perm[n] = (unsigned short)(n | (h ? 0x8000 : 0));
             }
-            K += __popcll(bal);
-            if (p < nvox) { key[p] = v ? 1.0f : 0.0f; perm2[p] = (unsigned short)p; }
+            K += __popcll(__ballot(h));
+        }
+        if (K > REF_MAX_HITS) { if (lane == 0) atomicExch(overflow, 1); K = REF_MAX_HITS; }
+        __builtin_amdgcn_wave_barrier();
+        // ---- sort 1 (tree.py:300): entry depths ascending.  Ranges without a crossed box are left alone -- unless the ray
+        // crosses nothing: then the box in one particular slot of the sorted order is what the reference reports.
+        WaveSort<CmpAsc> s1{key, perm, la, lb, stack, lane, CmpAsc()};
+        const bool none = K == 0;
+        s1.loop(nvox, [&](int first, int last) -> bool {
+            if (none || last - first > 128) return true;
+            bool any = false;
+            for (int base = first; base < last; base += 64) { const int p = base + lane; any = any || (p < last && (perm[p] & 0x8000)); }
+            return __ballot(any) != 0ull;
+        });
+        int lone = 0;                                     // K == 0: the box in slot zero_slot0 of the sorted order
+        if (none) {
+            const int i = zero_slot0 - 15 + lane;
+            const bool mine = lane < 31 && i >= 0 && i < nvox && s1.final_slot(i, nvox) == zero_slot0;
+            const unsigned long long bm = __ballot(mine);
+            const int src = bm ? __builtin_ctzll(bm) : 0;
+            lone = __shfl(i >= 0 && i < nvox ? (int)(perm[i] & 0x7fff) : 0, src);
+        }
+        // ---- the crossed boxes: id, final slot of sort 1 (= position in the sorted order)
+        int seen = 0;
+        for (int base = 0; base < nvox && !none; base += 64) {
+            const int i = base + lane;
+            const bool h = i < nvox && (perm[i] & 0x8000);
+            const unsigned long long bal = __ballot(h);
+            if (h) {
+                const int c = seen + __popcll(bal & below);
+                if (c < REF_MAX_HITS) { T[c] = perm[i] & 0x7fff; fslot[c] = (unsigned short)s1.final_slot(i, nvox); }
+            }
+            seen += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { Introsort<CmpDesc> s2{key, perm2, CmpDesc()}; s2.sort(nvox); }    // tree.py:306
+        // crossed boxes in sorted order (tree.py:303-309: values placed through the boolean mask, i.e. in order)
+        for (int c = lane; c < K; c += 64) {
+            const int f = fslot[c];
+            int pos = 0;
+            for (int e = 0; e < K; ++e) pos += fslot[e] < f ? 1 : 0;
+            float tmin, tmax;
+            slab(T[c], tmin, tmax);
+            r_tmin[pos] = tmin;
+            r_cum[pos] = tmax - tmin;
+        }
+        // ---- sort 2 (tree.py:306): the 0/1 hit sequence of the sorted order, descending; the element in slot f carries
+        // the ordinal of its crossed box
+        int myf[REF_MAX_HITS / 64];
+#pragma unroll
+        for (int q = 0; q < REF_MAX_HITS / 64; ++q) myf[q] = (q * 64 + lane < K) ? (int)fslot[q * 64 + lane] : -1;
+        __builtin_amdgcn_wave_barrier();
+        for (int p = lane; p < nvox; p += 64) { key[p] = 0.0f; perm[p] = 0; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < REF_MAX_HITS / 64; ++q)
+            if (myf[q] >= 0) { key[myf[q]] = 1.0f; perm[myf[q]] = (unsigned short)(q * 64 + lane); }
+        __builtin_amdgcn_wave_barrier();
+        WaveSort<CmpDesc> s2{key, perm, la, lb, stack, lane, CmpDesc()};
+        s2.loop(nvox, [&](int first, int last) -> bool {
+            bool any = false;
+            for (int base = first; base < last; base += 64) { const int p = base + lane; any = any || (p < last && key[p] != 0.0f); }
+            return __ballot(any) != 0ull;
+        });
+        // the final insertion sort is stable: the ones take the first K slots in the order of their positions
+        seen = 0;
+        for (int base = 0; base < nvox && !none; base += 64) {
+            const int p = base + lane;
+            const bool one = p < nvox && key[p] != 0.0f;
+            const unsigned long long bal = __ballot(one);
+            if (one) vslot[seen + __popcll(bal & below)] = T[perm[p]];
+            seen += __popcll(bal);
+        }
         __builtin_amdgcn_wave_barrier();
         double carry = 0.0;
         for (int base = 0; base < K; base += 64) {
@@ -494,7 +685,7 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
                 if (r_cum[mid] < s) lo = mid + 1; else hi = mid;
             }
             p_s[j] = s;
-            p_bucket[j] = lo;
+            p_bucket[j] = (unsigned short)lo;
         }
         __builtin_amdgcn_wave_barrier();
         for (int j = lane; j < samples; j += 64) {
@@ -506,15 +697,17 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
             }
             const float offset = p_s[j] - p_s[lo];
             p_z[j] = (K > 0 ? r_tmin[bkt] : 0.0f) + offset;
-            p_vid[j] = perm1[perm2[bkt]];          // tree.py:331-332: crosses_sorted.indices[crosses_start.indices[bucket]]
+            p_vid[j] = (unsigned short)(K > 0 ? (int)vslot[bkt] : lone);   // tree.py:331-332: crosses_sorted.indices[crosses_start.indices[bucket]]
             p_ix[j] = (unsigned short)j;
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { Introsort<CmpAsc> s3{p_z, p_ix, CmpAsc()}; s3.sort(samples); }    // tree.py:335
-        __builtin_amdgcn_wave_barrier();
+        // ---- sort 3 (tree.py:335): the sample depths ascending, every slot needed
+        WaveSort<CmpAsc> s3{p_z, p_ix, la, lb, stack, lane, CmpAsc()};
+        s3.loop(samples, [](int, int) -> bool { return true; });
         for (int j = lane; j < samples; j += 64) {
-            z_out[ray * samples + j] = p_z[j];
-            idx_out[ray * samples + j] = p_vid[p_ix[j]];
+            const int f = s3.final_slot(j, samples);
+            z_out[ray * samples + f] = p_z[j];
+            idx_out[ray * samples + f] = p_vid[p_ix[j]];
         }
         if (lane == 0) mask_out[ray] = K > 0 ? 1 : 0;
         __builtin_amdgcn_wave_barrier();
@@ -573,6 +766,22 @@ extern "C" int nm_tree_integrate(const int64_t* d_idx, const float* d_weights, c
     return 0;
 }
 
+// The reference's second sort on a ray that crosses nothing orders an all-equal mask: data-independent, so the index
+// that ends up in slot 0 is a function of n alone (the same libstdc++ algorithm, run once per n on the host).
+static int all_equal_first_slot(int n) {
+    static std::mutex lock;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> g(lock);
+    auto it = cache.find(n);
+    if (it != cache.end()) return it->second;
+    std::vector<float> k((size_t)n, 0.0f);
+    std::vector<unsigned short> ix((size_t)n);
+    for (int i = 0; i < n; ++i) ix[(size_t)i] = (unsigned short)i;
+    Introsort<CmpDesc> s{k.data(), ix.data(), CmpDesc()};
+    s.sort(n);
+    return cache[n] = (int)ix[0];
+}
+
 // one overflow flag per device (allocated on the device the call runs on)
 static int* overflow_flag() {
     static int* flags[64] = {};
@@ -596,18 +805,39 @@ extern "C" int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const f
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (tie_order == NM_TIES_REFERENCE) {
         NM_REQUIRE(nvox <= 8192, "buff_intersect(reference tie order): at most 8192 voxels");
-        const int npad = (nvox + 63) & ~63;
-        const size_t lds = (size_t)npad * (3 * 4 + 2 * 2 + 1) + BUFF_MAX_SAMPLES * (3 * 4 + 2 * 2);
-        static size_t attr = 0;
-        if (attr < lds) {
-            NM_HIP_CHECK(hipFuncSetAttribute((const void*)buff_reference_ids_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = lds;
+        const int npad = (nvox + 63) & ~63, spad = (samples + 63) & ~63, lpad = npad > spad ? npad : spad;
+        const int key_bytes = ((4 * npad > 14 * spad ? 4 * npad : 14 * spad) + 15) & ~15;
+        const int la_cap = lpad / 2 + 64 > REF_MAX_HITS ? lpad / 2 + 64 : REF_MAX_HITS;
+        const int list_bytes = (2 * (la_cap + lpad) + 15) & ~15;
+        const size_t lds = (size_t)key_bytes + list_bytes + 2 * npad + 2 * 2 * REF_MAX_HITS + 2 * 96 + 2 * 4 * REF_MAX_HITS;
+        int dev = 0;
+        NM_HIP_CHECK(hipGetDevice(&dev));
+        static size_t attr[64] = {};                  // hipFuncAttributeMaxDynamicSharedMemorySize is per device
+        static std::mutex attr_lock;
+        {
+            std::lock_guard<std::mutex> g(attr_lock);
+            if (dev < 0 || dev >= 64 || attr[dev] < lds) {
+                NM_HIP_CHECK(hipFuncSetAttribute((const void*)buff_reference_ids_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (dev >= 0 && dev < 64) attr[dev] = lds;
+            }
         }
-        hipLaunchKernelGGL(buff_reference_ids_kernel, dim3((unsigned)(rays < 8192 ? rays : 8192)), dim3(64), lds, stream,
-                           d_voxels, nvox, npad, d_origins, origins_per_ray, d_dirs, near_, far_, d_u, rays, samples, d_z,
-                           d_idx, d_mask);
+        int* d_over = overflow_flag();
+        NM_REQUIRE(d_over != nullptr, "buff_intersect: cannot allocate the overflow flag");
+        const int zero_slot0 = all_equal_first_slot(nvox);
+        const int64_t want = 256 * 8;                 // persistent: the LDS footprint admits ~7 rays per CU
+        hipLaunchKernelGGL(buff_reference_ids_kernel, dim3((unsigned)(rays < want ? rays : want)), dim3(64), lds, stream,
+                           d_voxels, nvox, npad, spad, key_bytes, la_cap, list_bytes, zero_slot0, d_origins, origins_per_ray,
+                           d_dirs, near_, far_, d_u, rays, samples, d_z, d_idx, d_mask, d_over);
         NM_HIP_CHECK(hipGetLastError());
+        int h = 0;
+        NM_HIP_CHECK(hipMemcpyAsync(&h, d_over, sizeof(int), hipMemcpyDeviceToHost, stream));
+        NM_HIP_CHECK(hipStreamSynchronize(stream));
+        if (h) {
+            NM_HIP_CHECK(hipMemset(d_over, 0, sizeof(int)));
+            set_error("buff_intersect(reference tie order): a ray crosses more than 512 voxels");
+            return 4;
+        }
         return 0;
     }
     int* d_overflow = overflow_flag();
