@@ -312,7 +312,7 @@ def buff_probe(dev, cpu_rays=2048, rank=0, world=1, use_dist=False, cpu_legs=Tru
             model.tree.tie_order = tie
             t_min, t_avg, (z, idx, mask) = _timed(lambda: model.tree.batch_ray_voxel_intersect(o[None], d[:chunk], 0.0, 1.2, 192), 5)
             timings[tie] = {"ms_min": t_min, "ms_avg": t_avg}
-        model.tree.tie_order = "stable"
+        model.tree.tie_order = "auto"
     achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     out = {
         "workload": "buff-colmap-fern geometry: BuFFModel.query, 504x378 rays x 192 tree-placed samples, 8x256 network, "

@@ -317,8 +317,10 @@ int nm_buff_intersect(const float* d_voxels, int32_t nvox, const float* d_origin
  *   NM_TIES_STABLE     ties keep voxel-index / sample order: every id is the voxel its sample lies in (default);
  *   NM_TIES_REFERENCE  ties ordered as torch's CPU sort orders them (libstdc++ std::sort over (key, index) pairs,
  *                      restated in the kernel): d_idx equals the reference's output bit for bit, including its
- *                      scrambled attribution of samples to the crossed voxels.  Parity / reproduction mode:
- *                      sequential per ray, ~100x slower; nvox <= 8192.  d_z and d_mask are identical in both. */
+ *                      scrambled attribution of samples to the crossed voxels.  The three introsorts are evaluated
+ *                      wave-parallel and exactly (one wavefront per ray; 7.6 ms vs 1.3 ms per 65 536 rays x 192
+ *                      samples on 1728 voxels); nvox <= 8192, at most 512 crossed voxels per ray (error 4 beyond).
+ *                      Synchronises the stream.  d_z and d_mask are identical in both. */
 enum { NM_TIES_STABLE = 0, NM_TIES_REFERENCE = 1 };
 int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const float* d_origins, int origins_per_ray,
                          const float* d_dirs, float near_, float far_, const float* d_u, int64_t rays,

@@ -419,7 +419,9 @@ struct Introsort {   // libstdc++ bits/stl_algo.h: __sort = __introsort_loop + _
 // One wavefront per ray, ~22 KB of LDS (7 rays per CU).  The sequential struct above remains as the heap-sort fallback
 // (depth limit 2 lg n: adversarial inputs only) and, on the host, for the one data-independent case -- a ray that
 // crosses nothing sorts an all-equal mask, whose first slot depends on n alone.
-constexpr int REF_MAX_HITS = 512;
+constexpr int REF_MAX_HITS = 512;   // boxes one ray may cross in this mode; rays are first tried with room for REF_FAST_HITS
+constexpr int REF_FAST_HITS = 128;
+constexpr int EQ_MIN = 17, EQ_MAX = 128;   // all-equal ranges of these lengths are permuted from a table (see WaveSort::loop)
 
 template <typename Cmp>
 struct WaveSort {
@@ -430,6 +432,7 @@ struct WaveSort {
     unsigned short* stack;     // pending ranges: (first, last, depth) triples
     int lane;
     Cmp cmp;
+    const unsigned char* eq_table;   // eq_table[eq_offset(len) + i]: source index of slot i after sorting len equal keys
 
     __device__ __forceinline__ int uni(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -484,6 +487,39 @@ struct WaveSort {
         for (;;) {
             while (last - first > 16) {
                 if (!keep(first, last)) break;
+                // A range of equivalent keys sorts data-independently (every comparison is false): the partitions reverse
+                // and halve it the same way whatever it holds, so the whole sub-sort is one gather through a table built
+                // by the sequential algorithm on the host.  Ties are the rule here: every box entered through the same
+                // plane shares its entry depth.
+                const int len = last - first;
+                if (eq_table && len <= EQ_MAX && depth >= 4) {
+                    const float v0 = k[first];
+                    bool diff = false;
+                    float kv[2];
+                    unsigned short iv[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int p = first + q * 64 + lane;
+                        kv[q] = p < last ? k[p] : v0;
+                        diff = diff || cmp(kv[q], v0) || cmp(v0, kv[q]);
+                    }
+                    if (__ballot(diff) == 0ull) {
+                        const unsigned char* tab = eq_table + (len * (len - 1) / 2 - EQ_MIN * (EQ_MIN - 1) / 2);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int i = q * 64 + lane;
+                            if (i < len) { const int src = first + tab[i]; kv[q] = k[src]; iv[q] = ix[src]; }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int i = q * 64 + lane;
+                            if (i < len) { k[first + i] = kv[q]; ix[first + i] = iv[q]; }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        break;
+                    }
+                }
                 if (depth == 0) {
                     if (lane == 0) { Introsort<Cmp> seq{k, ix, cmp}; seq.heap_sort(first, last); }
                     __builtin_amdgcn_wave_barrier();
@@ -525,8 +561,10 @@ struct WaveSort {
     }
 };
 
+template <int CAP>
 __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __restrict__ voxels, int nvox, int npad, int spad,
                                                                int key_bytes, int la_cap, int list_bytes, int zero_slot0,
+                                                               const unsigned char* __restrict__ eq_table,
                                                                const float* __restrict__ origins, int origins_per_ray,
                                                                const float* __restrict__ dirs, float near_, float far_,
                                                                const float* __restrict__ u, int64_t rays, int samples,
@@ -538,18 +576,18 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
     unsigned short* la = reinterpret_cast<unsigned short*>(smem + key_bytes);
     unsigned short* lb = la + la_cap;
     unsigned short* perm = reinterpret_cast<unsigned short*>(smem + key_bytes + list_bytes);    // [npad] index | hit << 15; later markers
-    unsigned short* T = perm + npad;                                   // [REF_MAX_HITS] box id of the c-th crossed box
-    unsigned short* vslot = T + REF_MAX_HITS;                          // [REF_MAX_HITS] box id attributed to bucket b
-    unsigned short* stack = vslot + REF_MAX_HITS;                      // [96]
-    float* r_tmin = reinterpret_cast<float*>(stack + 96);              // [REF_MAX_HITS] crossed boxes in reference order
-    float* r_cum = r_tmin + REF_MAX_HITS;
+    unsigned short* T = perm + npad;                                   // [CAP] box id of the c-th crossed box
+    unsigned short* vslot = T + CAP;                          // [CAP] box id attributed to bucket b
+    unsigned short* stack = vslot + CAP;                      // [96]
+    float* r_tmin = reinterpret_cast<float*>(stack + 96);              // [CAP] crossed boxes in reference order
+    float* r_cum = r_tmin + CAP;
     // per-sample arrays (alias region A once the sorts over the boxes are done)
     float* p_s = key;
     float* p_z = p_s + spad;
     unsigned short* p_bucket = reinterpret_cast<unsigned short*>(p_z + spad);
     unsigned short* p_ix = p_bucket + spad;
     unsigned short* p_vid = p_ix + spad;
-    unsigned short* fslot = la;                                        // [REF_MAX_HITS] final slot (sort 1) of the c-th crossed box
+    unsigned short* fslot = la;                                        // [CAP] final slot (sort 1) of the c-th crossed box
     const int lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int64_t ray = blockIdx.x; ray < rays; ray += gridDim.x) {
@@ -590,11 +628,11 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
             }
             K += __popcll(__ballot(h));
         }
-        if (K > REF_MAX_HITS) { if (lane == 0) atomicExch(overflow, 1); K = REF_MAX_HITS; }
+        if (K > CAP) { if (lane == 0) atomicExch(overflow, 1); K = CAP; }
         __builtin_amdgcn_wave_barrier();
         // ---- sort 1 (tree.py:300): entry depths ascending.  Ranges without a crossed box are left alone -- unless the ray
         // crosses nothing: then the box in one particular slot of the sorted order is what the reference reports.
-        WaveSort<CmpAsc> s1{key, perm, la, lb, stack, lane, CmpAsc()};
+        WaveSort<CmpAsc> s1{key, perm, la, lb, stack, lane, CmpAsc(), eq_table};
         const bool none = K == 0;
         s1.loop(nvox, [&](int first, int last) -> bool {
             if (none || last - first > 128) return true;
@@ -618,7 +656,7 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
             const unsigned long long bal = __ballot(h);
             if (h) {
                 const int c = seen + __popcll(bal & below);
-                if (c < REF_MAX_HITS) { T[c] = perm[i] & 0x7fff; fslot[c] = (unsigned short)s1.final_slot(i, nvox); }
+                if (c < CAP) { T[c] = perm[i] & 0x7fff; fslot[c] = (unsigned short)s1.final_slot(i, nvox); }
             }
             seen += __popcll(bal);
         }
@@ -635,17 +673,17 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
         }
         // ---- sort 2 (tree.py:306): the 0/1 hit sequence of the sorted order, descending; the element in slot f carries
         // the ordinal of its crossed box
-        int myf[REF_MAX_HITS / 64];
+        int myf[CAP / 64];
 #pragma unroll
-        for (int q = 0; q < REF_MAX_HITS / 64; ++q) myf[q] = (q * 64 + lane < K) ? (int)fslot[q * 64 + lane] : -1;
+        for (int q = 0; q < CAP / 64; ++q) myf[q] = (q * 64 + lane < K) ? (int)fslot[q * 64 + lane] : -1;
         __builtin_amdgcn_wave_barrier();
         for (int p = lane; p < nvox; p += 64) { key[p] = 0.0f; perm[p] = 0; }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < REF_MAX_HITS / 64; ++q)
+        for (int q = 0; q < CAP / 64; ++q)
             if (myf[q] >= 0) { key[myf[q]] = 1.0f; perm[myf[q]] = (unsigned short)(q * 64 + lane); }
         __builtin_amdgcn_wave_barrier();
-        WaveSort<CmpDesc> s2{key, perm, la, lb, stack, lane, CmpDesc()};
+        WaveSort<CmpDesc> s2{key, perm, la, lb, stack, lane, CmpDesc(), nullptr};
         s2.loop(nvox, [&](int first, int last) -> bool {
             bool any = false;
             for (int base = first; base < last; base += 64) { const int p = base + lane; any = any || (p < last && key[p] != 0.0f); }
@@ -702,7 +740,7 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
         }
         __builtin_amdgcn_wave_barrier();
         // ---- sort 3 (tree.py:335): the sample depths ascending, every slot needed
-        WaveSort<CmpAsc> s3{p_z, p_ix, la, lb, stack, lane, CmpAsc()};
+        WaveSort<CmpAsc> s3{p_z, p_ix, la, lb, stack, lane, CmpAsc(), eq_table};
         s3.loop(samples, [](int, int) -> bool { return true; });
         for (int j = lane; j < samples; j += 64) {
             const int f = s3.final_slot(j, samples);
@@ -782,6 +820,30 @@ static int all_equal_first_slot(int n) {
     return cache[n] = (int)ix[0];
 }
 
+// Sorting `len` equivalent keys is data-independent: slot i of the result holds the element that stood at
+// eq_table[offset(len) + i].  Built once per device with the sequential algorithm (lengths EQ_MIN..EQ_MAX, 8 KB).
+static const unsigned char* equal_keys_table() {
+    static std::mutex lock;
+    static unsigned char* tables[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(lock);
+    if (tables[dev]) return tables[dev];
+    std::vector<unsigned char> host;
+    for (int len = EQ_MIN; len <= EQ_MAX; ++len) {
+        std::vector<float> k((size_t)len, 0.0f);
+        std::vector<unsigned short> ix((size_t)len);
+        for (int i = 0; i < len; ++i) ix[(size_t)i] = (unsigned short)i;
+        Introsort<CmpAsc> s{k.data(), ix.data(), CmpAsc()};
+        s.sort(len);
+        for (int i = 0; i < len; ++i) host.push_back((unsigned char)ix[(size_t)i]);
+    }
+    unsigned char* d = nullptr;
+    if (hipMalloc(&d, host.size()) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    return tables[dev] = d;
+}
+
 // one overflow flag per device (allocated on the device the call runs on)
 static int* overflow_flag() {
     static int* flags[64] = {};
@@ -807,38 +869,49 @@ extern "C" int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const f
         NM_REQUIRE(nvox <= 8192, "buff_intersect(reference tie order): at most 8192 voxels");
         const int npad = (nvox + 63) & ~63, spad = (samples + 63) & ~63, lpad = npad > spad ? npad : spad;
         const int key_bytes = ((4 * npad > 14 * spad ? 4 * npad : 14 * spad) + 15) & ~15;
-        const int la_cap = lpad / 2 + 64 > REF_MAX_HITS ? lpad / 2 + 64 : REF_MAX_HITS;
-        const int list_bytes = (2 * (la_cap + lpad) + 15) & ~15;
-        const size_t lds = (size_t)key_bytes + list_bytes + 2 * npad + 2 * 2 * REF_MAX_HITS + 2 * 96 + 2 * 4 * REF_MAX_HITS;
-        int dev = 0;
-        NM_HIP_CHECK(hipGetDevice(&dev));
-        static size_t attr[64] = {};                  // hipFuncAttributeMaxDynamicSharedMemorySize is per device
-        static std::mutex attr_lock;
-        {
-            std::lock_guard<std::mutex> g(attr_lock);
-            if (dev < 0 || dev >= 64 || attr[dev] < lds) {
-                NM_HIP_CHECK(hipFuncSetAttribute((const void*)buff_reference_ids_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                if (dev >= 0 && dev < 64) attr[dev] = lds;
-            }
-        }
         int* d_over = overflow_flag();
         NM_REQUIRE(d_over != nullptr, "buff_intersect: cannot allocate the overflow flag");
+        const unsigned char* d_eq = equal_keys_table();
+        NM_REQUIRE(d_eq != nullptr, "buff_intersect: cannot allocate the equal-keys table");
         const int zero_slot0 = all_equal_first_slot(nvox);
-        const int64_t want = 256 * 8;                 // persistent: the LDS footprint admits ~7 rays per CU
-        hipLaunchKernelGGL(buff_reference_ids_kernel, dim3((unsigned)(rays < want ? rays : want)), dim3(64), lds, stream,
-                           d_voxels, nvox, npad, spad, key_bytes, la_cap, list_bytes, zero_slot0, d_origins, origins_per_ray,
-                           d_dirs, near_, far_, d_u, rays, samples, d_z, d_idx, d_mask, d_over);
-        NM_HIP_CHECK(hipGetLastError());
-        int h = 0;
-        NM_HIP_CHECK(hipMemcpyAsync(&h, d_over, sizeof(int), hipMemcpyDeviceToHost, stream));
-        NM_HIP_CHECK(hipStreamSynchronize(stream));
-        if (h) {
+        int dev = 0;
+        NM_HIP_CHECK(hipGetDevice(&dev));
+        // rays are first run with room for REF_FAST_HITS crossed boxes each (less LDS: more rays in flight); if one of them
+        // crosses more, the whole call is repeated with REF_MAX_HITS
+        for (int pass = 0; pass < 2; ++pass) {
+            const int cap = pass == 0 ? REF_FAST_HITS : REF_MAX_HITS;
+            const int la_cap = lpad / 2 + 64 > cap ? lpad / 2 + 64 : cap;
+            const int list_bytes = (2 * (la_cap + lpad) + 15) & ~15;
+            const size_t lds = (size_t)key_bytes + list_bytes + 2 * npad + 2 * 2 * cap + 2 * 96 + 2 * 4 * cap;
+            const void* fn = pass == 0 ? (const void*)buff_reference_ids_kernel<REF_FAST_HITS> : (const void*)buff_reference_ids_kernel<REF_MAX_HITS>;
+            static size_t attr[2][64] = {};               // hipFuncAttributeMaxDynamicSharedMemorySize is per device
+            static std::mutex attr_lock;
+            {
+                std::lock_guard<std::mutex> g(attr_lock);
+                if (dev < 0 || dev >= 64 || attr[pass][dev] < lds) {
+                    NM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    if (dev >= 0 && dev < 64) attr[pass][dev] = lds;
+                }
+            }
+            const int64_t want = 256 * 12;                // persistent: the LDS footprint admits ~9 rays per CU
+            const dim3 grid((unsigned)(rays < want ? rays : want));
+            if (pass == 0)
+                hipLaunchKernelGGL(buff_reference_ids_kernel<REF_FAST_HITS>, grid, dim3(64), lds, stream, d_voxels, nvox, npad, spad,
+                                   key_bytes, la_cap, list_bytes, zero_slot0, d_eq, d_origins, origins_per_ray, d_dirs, near_, far_,
+                                   d_u, rays, samples, d_z, d_idx, d_mask, d_over);
+            else
+                hipLaunchKernelGGL(buff_reference_ids_kernel<REF_MAX_HITS>, grid, dim3(64), lds, stream, d_voxels, nvox, npad, spad,
+                                   key_bytes, la_cap, list_bytes, zero_slot0, d_eq, d_origins, origins_per_ray, d_dirs, near_, far_,
+                                   d_u, rays, samples, d_z, d_idx, d_mask, d_over);
+            NM_HIP_CHECK(hipGetLastError());
+            int h = 0;
+            NM_HIP_CHECK(hipMemcpyAsync(&h, d_over, sizeof(int), hipMemcpyDeviceToHost, stream));
+            NM_HIP_CHECK(hipStreamSynchronize(stream));
+            if (!h) return 0;
             NM_HIP_CHECK(hipMemset(d_over, 0, sizeof(int)));
-            set_error("buff_intersect(reference tie order): a ray crosses more than 512 voxels");
-            return 4;
         }
-        return 0;
+        set_error("buff_intersect(reference tie order): a ray crosses more than 512 voxels");
+        return 4;
     }
     int* d_overflow = overflow_flag();
     NM_REQUIRE(d_overflow != nullptr, "buff_intersect: cannot allocate the overflow flag");

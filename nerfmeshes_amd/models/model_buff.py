@@ -24,6 +24,7 @@ class BuFFModel(BaseModel):
         ray_origins, ray_directions = ray_origins.to(dev), ray_directions.to(dev)
         ray_count = ray_directions.shape[0]
         uniform = self.sampler(nerf_cfg, ray_count, near, far)
+        self.tree.training = self.training                        # selects the reference's own voxel ids where they are consumed
         intervals, indices, mask = self.tree.batch_ray_voxel_intersect(ray_origins, ray_directions, near, far,
                                                                        samples_count=nerf_cfg.num_coarse)
         intervals[~mask] = uniform[~mask]                         # rays that miss every voxel (model_buff.py:53)

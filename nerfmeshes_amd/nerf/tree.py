@@ -57,10 +57,14 @@ class TreeSampling:
         self.voxels = None
         self.memm = None
         self.counter = 1
-        # "stable" (default): every voxel id is the voxel its sample lies in.  "reference": ties ordered as the
-        # reference's three unstable torch.sort calls order them on the CPU -- its ids, hence its memm and its
-        # refined voxel sets, bit for bit (tests/golden/buff_sampled_tree.npz); optional hparams key `tree.tie_order`.
-        self.tie_order = getattr(self.config.tree, "tie_order", "stable")
+        # Tie order of the voxel ids.  "reference": ties ordered as the reference's three unstable torch.sort calls order
+        # them on the CPU -- its ids, hence its memm and its refined voxel sets, bit for bit
+        # (tests/golden/buff_sampled_tree.npz).  "stable": every id is the voxel its sample lies in (6x faster, not the
+        # reference's ids).  "auto" (default): "reference" while the owning model trains -- the ids are consumed by
+        # ray_batch_integration only (model_buff.py:66-68) --, "stable" in eval, where nothing reads them.  The
+        # optional hparams key `tree.tie_order` pins one of the three.
+        self.tie_order = getattr(self.config.tree, "tie_order", "auto")
+        self.training = False          # set by the owning model before each call (BuFFModel.forward)
         self.consolidate()
 
     def ticked(self, step):
@@ -124,8 +128,10 @@ class TreeSampling:
             u_pick = torch.rand(shape, dtype=torch.float64, device=dev)
             u_pos = torch.rand(shape, dtype=torch.float32, device=dev)
             return hip_ops.buff_intersect_random(self.voxels, origins, dirs, float(near), float(far), u_pick, u_pos)
-        return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count),
-                                      ids=getattr(self, "tie_order", "stable"))
+        order = getattr(self, "tie_order", "auto")
+        if order == "auto":
+            order = "reference" if getattr(self, "training", False) else "stable"
+        return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count), ids=order)
 
     def serialize(self):
         return {"root": self.root, "voxels": self.voxels, "memm": self.memm, "counter": self.counter}

@@ -70,6 +70,29 @@ def test_buff_intersect_vs_oracle(pkg, rays, samples, nvox_side):
         assert np.array_equal(z2.cpu().numpy(), zr.numpy()) and np.array_equal(i2.cpu().numpy(), ir.numpy())
 
 
+@pytest.mark.parametrize("slabs,expect_error", [(200, False), (600, True)])
+def test_buff_reference_order_many_crossed_boxes(pkg, slabs, expect_error):
+    """The reference tie order keeps per-ray state for 128 crossed boxes and repeats the call with room for 512 when a ray
+    crosses more (thin slabs stacked along x: axis-parallel rays cross them all, oblique ones a few); beyond 512 it
+    reports the overflow like the stable kernel does."""
+    g = torch.Generator().manual_seed(slabs)
+    xs = torch.linspace(-0.6, 0.6, slabs + 1)
+    lo = torch.stack([xs[:-1], torch.full((slabs,), -0.6), torch.full((slabs,), -0.6)], -1)
+    hi = torch.stack([xs[1:], torch.full((slabs,), 0.6), torch.full((slabs,), 0.6)], -1)
+    vox = torch.stack([lo, hi], 1)                                     # (N, 2, 3)
+    rays = 48
+    o = torch.tensor([-0.75, 0.0, 0.0]).repeat(rays, 1) + 0.05 * torch.randn(rays, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.tensor([1.0, 0.0, 0.0]) + 0.3 * torch.randn(rays, 3, generator=g) * torch.linspace(0, 1, rays)[:, None], dim=-1)
+    if expect_error:
+        with pytest.raises(Exception, match="512"):
+            pkg["ops"].buff_intersect(vox.cuda(), o.cuda(), d.cuda(), 0.0, 1.6, 192, ids="reference")
+        return
+    zr, ir, mr = O.buff_intersect(vox, o, d, 0.0, 1.6, 192, ties="reference")
+    z, i, m = pkg["ops"].buff_intersect(vox.cuda(), o.cuda(), d.cuda(), 0.0, 1.6, 192, ids="reference")
+    assert bool(mr.any()) and np.array_equal(m.cpu().numpy(), mr.numpy())
+    assert np.array_equal(z.cpu().numpy(), zr.numpy()) and np.array_equal(i.cpu().numpy(), ir.numpy())
+
+
 def test_buff_random_branch_vs_reference_golden_and_oracle(pkg):
     """R9 `tree.use_random_sampling` (tree.py:280-297) on the GPU: given the draws the UNMODIFIED reference consumed
     (tests/golden/buff_random.npz) nm_buff_intersect_random returns its depths and voxel ids bit for bit on every ray
@@ -138,12 +161,12 @@ def test_buff_sampled_tree_reference_tie_order(pkg):
     equal the UNMODIFIED reference's (tests/golden/buff_sampled_tree.npz: it sampled with its own unstable sorts)."""
     g = load_golden("buff_sampled_tree")
     hp = golden_hparams(g)
-    hp["tree.tie_order"] = "reference"
+    # no extra hparam: "auto" selects the reference's ids while the model trains
     m = pkg["models"].BuFFModel(hp)
     kw = mlp_kwargs(hp, "coarse")
     _load(m, "model.", S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw))
     m = m.train().to("cuda")
-    assert m.tree.tie_order == "reference"
+    assert m.tree.tie_order == "auto"
     for k in range(3):
         m.global_step = k
         with torch.no_grad():
