@@ -371,6 +371,27 @@ int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double
                void* d_vertex_scratch, int64_t vertices, int64_t faces, float* d_verts, int32_t* d_faces,
                float* d_normals, float* d_values, void* stream);
 
+/* Per-slab marching cubes (multi-GPU mesh extraction: every rank meshes its own axis-0 slab, only the triangles are
+ * gathered -- SURVEY.md 8(e), BASELINE.json north_star "all-gather of emitted triangles"; replaces the all-gather of the
+ * density grid in front of skimage.measure.marching_cubes, src/mesh_nerf.py:79).
+ * d_volume holds the global planes [z_global, z_global + n0) of the grid.  Its first cube layer is a ghost of the slab below
+ * when ghost_below = 1 (classified and numbered -- the faces of the layer above reference the vertices it creates -- but
+ * nothing of it is emitted), its last one a ghost of the slab above when ghost_above = 1 (never classified; its voxels are
+ * read when the normals of this slab's top vertices replay the cubes around them).  Vertex ownership follows the GLOBAL
+ * plane index, so a slab creates exactly the vertices the single-volume run creates in its layers, in the same order.
+ *   nm_mc_count_slab  -> V, F including the ghost layer's, and the ghost layer's own V_g, F_g;
+ *   nm_mc_emit_slab   writes the slab's V - V_g vertices / normals / values and F - F_g faces; face entries are
+ *                     local id + index_base: with index_base = (vertices of all lower slabs) - V_g the concatenation of
+ *                     the ranks' arrays in rank order IS the single-volume mesh, bit for bit, vertex numbering included.
+ * With z_global = ghost_below = ghost_above = 0 these are nm_mc_count / nm_mc_emit. */
+int nm_mc_count_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, int32_t z_global,
+                     int32_t ghost_below, int32_t ghost_above, void* d_workspace, int64_t* h_vertices, int64_t* h_faces,
+                     int64_t* h_ghost_vertices, int64_t* h_ghost_faces, void* stream);
+int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, int32_t z_global,
+                    int32_t ghost_below, int32_t ghost_above, void* d_workspace, void* d_vertex_scratch, int64_t vertices,
+                    int64_t faces, int64_t ghost_vertices, int64_t ghost_faces, int64_t index_base, float* d_verts,
+                    int32_t* d_faces, float* d_normals, float* d_values, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Mesh export: export_obj (src/nerf/nerf_helpers.py:86-111), byte-identical text.  HOST arrays:
  * vertices (V,3), diffuse (C,3) with C <= V allowed (colours only while they last), normals (N,3),

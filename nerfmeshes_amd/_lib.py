@@ -133,6 +133,11 @@ SIGNATURES = {
                               C.POINTER(C.c_int64), c_void_p]),
     "nm_mc_emit": (C.c_int, [c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_void_p, c_void_p, C.c_int64,
                              C.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nm_mc_count_slab": (C.c_int, [c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, c_void_p,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_void_p]),
+    "nm_mc_emit_slab": (C.c_int, [c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, c_void_p,
+                                  c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
     "nm_export_obj": (C.c_int, [c_void_p, C.c_int64, c_void_p, C.c_int64, c_void_p, C.c_int64, c_void_p, C.c_int64,
                                 C.c_char_p]),
 }

@@ -36,7 +36,6 @@ namespace nm {
 constexpr double SK_EPS = 2.220446049250313e-16;   // skimage's "FLT_EPSILON" is np.spacing(1.0)
 constexpr int MC_BLOCK = 256;
 constexpr int MC_ITEMS = 4;                          // CONSECUTIVE cubes per thread (their 4 code bytes = one dword)
-constexpr int MC_TILE = MC_BLOCK * MC_ITEMS;
 
 struct McDims {
     int n0, n1, n2;          // volume extents (axis0 = skimage z, axis2 = skimage x)
@@ -337,34 +336,25 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 //     overflow.  The code bytes of all other cubes are a memset.
 // (b) mc_classify_cut -- one thread per queued cube: corner pattern, the MC33 face / interior tests (fp64), the tiling
 //     row, the number of vertices the cube creates; writes that cube's code byte.
-constexpr int MC_ZRUN_MIN = 8, MC_ZRUN_MAX = 24;                    // planes per march: chosen per launch (mc_pick_zrun)
+constexpr int MC_ZRUN_MIN = 8;                     // planes per march: chosen per launch (mc_pick_zrun)
 constexpr int MC_GX = 128, MC_GY = 8;                               // thread grid: x-groups per row, rows (7 cube rows + halo)
 constexpr int MC_STREAM_THREADS = MC_GX * MC_GY;
-constexpr int MC_CUBES_PER_PLANE = MC_GX * MC_ITEMS * (MC_GY - 1);  // 3584 cubes per step of the march
-constexpr int MC_STAGE = 12288;                                     // LDS staging entries (48 KB)
-constexpr int MC_FLUSH_AT = MC_STAGE - 2 * MC_CUBES_PER_PLANE;      // see the flush decision below
+constexpr int MC_UNIT = MC_GX * MC_ITEMS;                            // cubes of one row that one workgroup covers (512)
 constexpr int MC_AHEAD = 4;   // even (LDS double buffers are indexed by the ring slot's parity).  6 needs 67 VGPRs: 3 spills, one
                               // of them reloaded -- behind an s_waitcnt vmcnt(0), i.e. behind all its prefetches -- by the logic wave every step
 constexpr bool MC_MARCH0 = true;   // march along axis 0, thread rows = adjacent rows of axis 1 (false: the other way round; same speed)
 constexpr int MC_LOGIC_WAVE = MC_STREAM_THREADS / 64 - 1;           // second half of the halo row: owns no cubes
 static_assert(MC_GX == 128 && MC_ITEMS == 4 && 8 * (MC_GY - 1) <= 64 && MC_AHEAD % 2 == 0, "two wavefronts per row, four voxels per lane");
 
-struct __attribute__((packed)) McWord { uint32_t v; };              // 4 code bytes at any byte offset
 
 // Sign masks of one row as a wavefront sees it: mask j, bit L = voxel 4 L + j of the wave's 256-voxel span; "column 4"
 // (voxel 4 L + 4) is column 0 shifted down one lane with the neighbour wave's / halo voxel's bit on top.
 template <bool VEC, bool XHALO>   // VEC: n2 % 4 == 0 (every x-group is one 16-byte load); XHALO: more than one brick in x
 __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const float* __restrict__ vol, McDims d, float thr,
-                                                                        uint64_t* __restrict__ queue,
-                                                                        unsigned long long* __restrict__ qcount, const int zrun) {
+                                                                        uint64_t* __restrict__ cut_masks, const int zrun) {
     __shared__ uint64_t s_m[2][MC_GY][2][4];             // sign masks   [step parity][row][x half][column]
-    __shared__ uint64_t s_cut[2][MC_GY - 1][2][4];       // cut masks    [step parity][cube row][x half][column]
-    __shared__ uint32_t s_some[2][MC_GY - 1][2];         // any bit set in the 4 cut masks
     __shared__ uint64_t s_prev[2 * (MC_GY - 1)][2][5];   // logic wave: [wave-row][AND, OR][column] of the previous step
     __shared__ uint32_t s_h[2][MC_GY];                   // the voxel behind the brick
-    __shared__ uint32_t s_q[MC_STAGE];
-    __shared__ uint32_t s_n, s_snap[2];
-    __shared__ unsigned long long s_base;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xh = wave & 1, tz = wave >> 1, tx = xh * 64 + lane;
@@ -375,7 +365,6 @@ __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const
     const int x0 = xb + tx * MC_ITEMS, r = r0 + tz;
     const int xl = min(x0, VEC ? d.n2 - 4 : d.n2 - 1);
     const float* rowp = vol + (int64_t)min(r, nr - 1) * sr;
-    if (threadIdx.x == 0) { s_n = 0; s_snap[0] = s_snap[1] = 0; }
     struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
     auto fetch = [&](int l) -> F4 {
         const float* p = rowp + (int64_t)min(m0 + l, nm - 1) * sm;
@@ -398,33 +387,14 @@ __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const
         pf[l] = fetch(l);
         if constexpr (XHALO) ph[l] = fetch_halo(l);
     }
-    auto flush = [&]() {                                 // entered by every wave, or by none
-        if (threadIdx.x == 0) s_base = atomicAdd(qcount, (unsigned long long)s_n);
-        __syncthreads();
-        const uint32_t cnt = s_n;
-        for (uint32_t e = threadIdx.x; e < cnt; e += MC_STREAM_THREADS) {
-            const uint32_t local = s_q[e];
-            const int k = local % (MC_GX * MC_ITEMS), rr = (local / (MC_GX * MC_ITEMS)) % (MC_GY - 1), ll = local / MC_CUBES_PER_PLANE;
-            const int cz = MC_MARCH0 ? m0 + ll : r0 + rr, cy = MC_MARCH0 ? r0 + rr : m0 + ll;
-            queue[s_base + e] = (uint64_t)(((int64_t)cz * d.c1 + cy) * d.c2 + xb + k);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-    };
-    // owners: append the cut cubes of march step `lc` (cubes between voxel planes lc and lc + 1) from the cut masks
-    auto append = [&](int lc) {
-        if (tz >= MC_GY - 1) return;
-        const int par = (lc + 1) & 1;                    // written by the logic wave in iteration lc + 1
-        if (__builtin_amdgcn_readfirstlane((int)s_some[par][tz][xh]) == 0) return;   // scalar branch: nothing cut here
-        const uint32_t base = (uint32_t)(lc * MC_CUBES_PER_PLANE + tz * (MC_GX * MC_ITEMS) + tx * MC_ITEMS);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (((s_cut[par][tz][xh][j] >> lane) & 1u) && x0 + j < d.c2) s_q[atomicAdd(&s_n, 1u)] = base + j;
-    };
     // logic wave: lane = 4 k + column, k = 2 cube row + x half (56 lanes)
     const int kk = lane >> 2, kcol = lane & 3, krow = min(kk >> 1, MC_GY - 2), khalf = kk & 1;
     const bool k_exists = r0 + krow < cr;
+    // cubes of column kcol that exist in this wave-row: bit L = cube 4 L + kcol of the half-row (lanes past the end of a row
+    // hold copies of its last voxels)
+    const int k_valid = max(0, min(MC_UNIT / 2, d.c2 - xb - khalf * (MC_UNIT / 2)));
+    const int k_lanes = max(0, min(64, (k_valid - kcol + 3) >> 2));
+    const uint64_t k_colmask = k_lanes >= 64 ? ~0ull : ((1ull << k_lanes) - 1ull);
     // (that state -- 10 masks per lane -- lives in LDS, not in registers every wave would have to reserve: at 64 VGPRs
     // two workgroups share a CU)
     __syncthreads();
@@ -454,13 +424,7 @@ __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const
             const uint64_t hm = __ballot(hq > thr);
             if (xh == 1 && lane == 0) s_h[u & 1][tz] = (uint32_t)(hm >> 63);
         }
-        // Flush decision, identical in every wave: thread 0's snapshot of the fill level, taken BEFORE this barrier
-        // (it counts every append up to two iterations back, possibly some of the previous one's), read after it.
-        // Without a flush the buffer holds at most snapshot + 2 steps' worth of appends at the next decision.
-        if (threadIdx.x == 0) s_snap[u & 1] = s_n;
         __syncthreads();
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_snap[u & 1]) > (uint32_t)MC_FLUSH_AT) flush();
-        if (l >= 2) append(l - 2);                       // masks the logic wave wrote during the previous iteration
         if (wave == MC_LOGIC_WAVE) {
             // lane (k, j), k = wave-row (krow, khalf), j = column: the cut mask of the 64 cubes 4 L + j of that wave-row
             // from columns j and j + 1 of two rows (krow, krow + 1) and two planes (the previous step's AND / OR per
@@ -482,27 +446,22 @@ __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const
                 }
                 const uint64_t all1 = s_prev[kk][0][kcol] & and_c & s_prev[kk][0][kcol + 1] & and_n;
                 const uint64_t any1 = s_prev[kk][1][kcol] | or_c | s_prev[kk][1][kcol + 1] | or_n;
-                if (l > 0 && k_exists && m0 + l - 1 < cm) cut = any1 & ~all1;      // cubes of step l - 1
+                if (l > 0 && k_exists && m0 + l - 1 < cm) cut = any1 & ~all1 & k_colmask;      // cubes of step l - 1
                 s_prev[kk][0][kcol] = and_c;
                 s_prev[kk][1][kcol] = or_c;
                 if (kcol == 3) { s_prev[kk][0][4] = and_n; s_prev[kk][1][4] = or_n; }
-                s_cut[par][krow][khalf][kcol] = cut;     // (lanes past the end of a row hold copies of its last voxels; append() masks them)
+                // The cut mask of the 64 cubes 4 L + kcol of half-row (krow, khalf), step l - 1, goes straight to HBM: 8
+                // qwords per unit = (plane, row, x brick), units in scan order.  Every existing unit is written, cut or not
+                // (nothing is cleared beforehand); the next pass turns the masks into ordered entries.
+                if (l > 0 && k_exists && m0 + l - 1 < cm) {
+                    const int cz = MC_MARCH0 ? m0 + l - 1 : r0 + krow, cy = MC_MARCH0 ? r0 + krow : m0 + l - 1;
+                    cut_masks[(((int64_t)cz * d.c1 + cy) * gridDim.x + blockIdx.x) * 8 + khalf * 4 + kcol] = cut;
+                }
             }
-            const uint64_t nonzero = __ballot(cut != 0);
-            if (lane < 2 * (MC_GY - 1)) s_some[par][lane >> 1][lane & 1] = (uint32_t)((nonzero >> (4 * lane)) & 15u);
         }
       }
     }
-    __syncthreads();                                     // the logic wave's last masks; every append so far is counted in s_n
-    // The in-loop decision bounds the fill at MC_STAGE after the last iteration's appends (snapshot <= MC_FLUSH_AT, plus
-    // at most one step the snapshot missed, plus that iteration's step) -- the final step below needs its own room.
-    // s_n is exact and stable here (nobody appends between the barrier above and the one inside flush()).
-    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_n) > (uint32_t)(MC_STAGE - MC_CUBES_PER_PLANE)) flush();
-    append(zrun - 1);
-    __syncthreads();
-    flush();
 }
-static_assert(MC_FLUSH_AT > 0 && (int64_t)MC_ZRUN_MAX * MC_CUBES_PER_PLANE < (int64_t(1) << 32), "staging buffer / local id");
 
 // Planes per march: 24 (halo planes cost 25/24; 1380 workgroups at 480^3), fewer for volumes that would not give every
 // CU its two workgroups.  (Choosing zrun to make the launch a whole number of "rounds" -- 22 at 480^3 -- measures
@@ -514,70 +473,117 @@ static int mc_pick_zrun(int64_t bricks_xy, int c_march, int num_cus) {
     return z;
 }
 
-__global__ __launch_bounds__(MC_BLOCK) void mc_classify_cut(const float* __restrict__ vol, McDims d, double iso,
-                                                            const uint64_t* __restrict__ queue,
-                                                            const unsigned long long* __restrict__ qcount,
-                                                            uint8_t* __restrict__ codes, uint8_t* __restrict__ tile_flag) {
-    const int64_t n = (int64_t)*qcount;
-    for (int64_t q = (int64_t)blockIdx.x * MC_BLOCK + threadIdx.x; q < n; q += (int64_t)gridDim.x * MC_BLOCK) {
-        const int64_t id = (int64_t)queue[q];
-        int z, y, x;
-        cube_coords(d, id, z, y, x);
+// A SEGMENT is what one workgroup of mc_classify_stream covers in one step: MC_GY - 1 = 7 consecutive rows of one plane,
+// one x brick wide = 7 units.  The passes over the cut cubes run one wavefront per segment (most segments are empty and
+// exit on their counts), lanes = cut cubes in (row, position) order.
+struct McSegment {
+    int z, r0, xb;             // plane, first row, x brick
+    int64_t unit0, ustride;    // unit of row r0; + ustride per row
+    uint32_t start[MC_GY];     // start[t] = cut cubes in rows r0 .. r0 + t - 1; start[7] = all of them
+};
+
+__device__ __forceinline__ void mc_segment_place(const McDims& d, int64_t seg, int bx, int by, McSegment& s) {
+    s.xb = (int)(seg % bx);
+    const int64_t zy = seg / bx;
+    s.r0 = (int)(zy % by) * (MC_GY - 1);
+    s.z = (int)(zy / by);
+    s.unit0 = ((int64_t)s.z * d.c1 + s.r0) * bx + s.xb;
+    s.ustride = bx;
+}
+
+// row t of entry e (start[] is non-decreasing) and the entry's position in its row
+__device__ __forceinline__ int mc_segment_row(const McSegment& s, uint32_t e, uint32_t& k) {
+    int t = 0;
+#pragma unroll
+    for (int q = 1; q < MC_GY - 1; ++q) t += e >= s.start[q] ? 1 : 0;
+    uint32_t st = s.start[0];
+#pragma unroll
+    for (int q = 1; q < MC_GY - 1; ++q) st = t == q ? s.start[q] : st;
+    k = e - st;
+    return t;
+}
+
+// (b) mc_classify_cut: the cut masks of a segment -> its cut cubes in scan order -> their MC33 tests.  Per unit, the slot
+// receives one entry per cut cube (position in the brick | triangles << 16 | created vertices << 20) and unit_sums the
+// unit's (created vertices, triangles, cut cubes).  Every unit is written (zeros for the untouched ones).
+//   Lane L of a half-row holds cubes 4 L .. 4 L + 3, mask j bit L = cube 4 L + j: the number of cut cubes in front of a
+//   lane's four is the population count of the four masks below bit L, so a wave lists a row in cube order with 8 mbcnt.
+constexpr int MC_SEG_MAX = (MC_GY - 1) * MC_UNIT;      // 3584 cubes per segment
+__global__ __launch_bounds__(256) void mc_classify_cut(const float* __restrict__ vol, McDims d, double iso, int zg0,
+                                                       const uint64_t* __restrict__ cut_masks, uint32_t* __restrict__ slots,
+                                                       const int cap, int bx, int by, int64_t segments,
+                                                       uint4* __restrict__ unit_sums) {
+    __shared__ uint16_t s_x[4][MC_SEG_MAX];             // position in the brick of every cut cube of the segment, in order
+    __shared__ uint32_t s_acc[4][MC_GY - 1][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
+    if (seg >= segments) return;
+    McSegment sg;
+    mc_segment_place(d, seg, bx, by, sg);
+    // lanes 8 t + 4 h + j: mask j of half h of row t
+    const int mt = lane >> 3;
+    const bool row_exists = mt < MC_GY - 1 && sg.r0 + mt < d.c1;
+    uint64_t mask = 0;
+    if (row_exists) mask = cut_masks[(sg.unit0 + mt * sg.ustride) * 8 + (lane & 7)];
+    uint32_t cnt = (uint32_t)__popcll(mask);
+    cnt += __shfl_xor(cnt, 1); cnt += __shfl_xor(cnt, 2); cnt += __shfl_xor(cnt, 4);        // the row's cut cubes, in its 8 lanes
+    const uint32_t row_cnt = (uint32_t)__shfl((int)cnt, lane < MC_GY - 1 ? 8 * lane : 0);   // lane t: cut cubes of row t
+    uint32_t run = 0;
+#pragma unroll
+    for (int t = 0; t < MC_GY - 1; ++t) { sg.start[t] = run; run += (uint32_t)__builtin_amdgcn_readlane((int)cnt, 8 * t); }
+    sg.start[MC_GY - 1] = run;
+    const uint32_t total = run;
+    if (lane < MC_GY - 1 && sg.r0 + lane < d.c1 && total == 0) unit_sums[sg.unit0 + lane * sg.ustride] = make_uint4(0u, 0u, 0u, 0u);
+    if (total == 0) return;
+    if (lane < 2 * (MC_GY - 1)) s_acc[wave][lane >> 1][lane & 1] = 0;
+    // ---- the segment's cut cubes in order
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int mlo = (int)(uint32_t)mask, mhi = (int)(uint32_t)(mask >> 32);
+#pragma unroll
+    for (int t = 0; t < MC_GY - 1; ++t) {
+        if (sg.start[t + 1] == sg.start[t]) continue;
+        uint32_t pos = sg.start[t];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint64_t m[4];
+            uint32_t in_front = 0, own = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int src = 8 * t + 4 * h + j;
+                m[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, src) << 32) | (uint32_t)__builtin_amdgcn_readlane(mlo, src);
+                in_front += (uint32_t)__popcll(m[j] & below);
+                own += (uint32_t)__popcll(m[j]);
+            }
+            uint32_t p = pos + in_front;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((m[j] >> lane) & 1ull) s_x[wave][p++] = (uint16_t)(h * (MC_UNIT / 2) + 4 * lane + j);
+            pos += own;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- the MC33 tests, one lane per cut cube
+    for (uint32_t e = lane; e < total; e += 64) {
+        uint32_t k;
+        const int t = mc_segment_row(sg, e, k);
+        const uint32_t xoff = s_x[wave][e];
+        const int z = sg.z, y = sg.r0 + t, x = sg.xb * MC_UNIT + (int)xoff;
         Cube c;
         load_cube(vol, d, z, y, x, iso, c);
         int off, nt;
         select_tiling(c, index_of(c), off, nt);
-        if (nt > 0) {
-            codes[id] = (uint8_t)pack_code(nt, count_created(off, nt, z, y, x));
-            // mark the cube's tile: the passes over the code bytes skip unmarked tiles (~60 % at 480^3).  (Adding the
-            // tile sums here with integer atomics instead costs more than the pass it saves: 35 -> 133 us, neighbouring
-            // queue entries hit the same counters.)
-            tile_flag[id / MC_TILE] = 1;
-        }
+        const int created = count_created(off, nt, z + zg0, y, x);
+        slots[(sg.unit0 + t * sg.ustride) * cap + k] = xoff | (pack_code(nt, created) << 16);
+        atomicAdd(&s_acc[wave][t][0], (uint32_t)created);
+        atomicAdd(&s_acc[wave][t][1], (uint32_t)nt);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < MC_GY - 1 && sg.r0 + lane < d.c1)
+        unit_sums[sg.unit0 + lane * sg.ustride] =
+            make_uint4(s_acc[wave][lane][0], s_acc[wave][lane][1], row_cnt, 0u);
 }
 
-// the 16 code bytes of cubes first .. first + 15 (bytes past the last cube read as 0)
-__device__ __forceinline__ uint4 load_codes16(const McDims& d, const uint32_t* __restrict__ codes4, int64_t first) {
-    if (first >= d.cubes) return make_uint4(0, 0, 0, 0);
-    uint4 w = *reinterpret_cast<const uint4*>(codes4 + (first >> 2));      // the buffer is padded by 4 KiB
-    const int64_t left = d.cubes - first;                                  // cubes from `first` to the end
-    uint32_t* p = &w.x;
-    for (int q = 0; q < 4; ++q) {
-        const int64_t have = left - 4 * q;
-        if (have <= 0) p[q] = 0u;
-        else if (have < 4) p[q] &= (1u << (8 * (int)have)) - 1u;
-    }
-    return w;
-}
-
-// per-tile (1024 cubes in scan order) sums of created vertices / triangles / active cubes, from the code bytes:
-// one wavefront per tile, 16 cubes (one 16-byte load) per lane (a workgroup per tile is dispatch-bound: 91 us); tiles
-// mc_classify_cut did not mark are all zero and are not read
-__global__ __launch_bounds__(256) void mc_tile_sums(McDims d, const uint32_t* __restrict__ codes4, int64_t tiles,
-                                                    const uint8_t* __restrict__ tile_flag, uint4* __restrict__ tile_sums) {
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= tiles) return;
-    if (!tile_flag[tile]) {
-        if (lane == 0) tile_sums[tile] = make_uint4(0, 0, 0, 0);
-        return;
-    }
-    const uint4 w = load_codes16(d, codes4, tile * MC_TILE + lane * 16);
-    uint32_t nv = 0, ntri = 0, nact = 0;
-    const uint32_t* p = &w.x;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t c = p[q] >> (8 * it);
-            nv += code_created(c); ntri += code_nt(c); nact += code_nt(c) ? 1 : 0;
-        }
-    for (int o = 32; o > 0; o >>= 1) { nv += __shfl_xor(nv, o); ntri += __shfl_xor(ntri, o); nact += __shfl_xor(nact, o); }
-    if (lane == 0) tile_sums[tile] = make_uint4(nv, ntri, nact, 0);
-}
-
-// ---- pass 2: exclusive scan of the per-tile sums: 1024-tile groups in parallel, then the group totals ------
+// ---- pass 2: exclusive scan of the per-unit sums (units are in scan order): 1024-tile groups in parallel, then the group totals ------
 __device__ __forceinline__ void block_scan3(uint32_t (&inc)[3], uint32_t (&tot)[3], uint32_t (*s_w)[16]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 1024 threads: inclusive scan in place
 #pragma unroll
@@ -642,53 +648,78 @@ struct McActive {      // one entry per cube that emits triangles, in scan order
     uint32_t vbase, tbase;
 };
 
-// ---- pass 3a: compact the active cubes (scan order) with their vertex / triangle bases -----------------------
-// one wavefront per tile, 16 cubes per lane, wave-level exclusive scan
-__global__ __launch_bounds__(256) void mc_compact(McDims d, const uint32_t* __restrict__ codes4, int64_t tiles,
-                                                  const uint4* __restrict__ tile_prefix,
+// ---- pass 3a: the cut cubes (scan order) with their vertex / triangle bases ------------------------------------------
+// one wavefront per segment; a unit's entries are consecutive lanes, so the running sums of (created, triangles) over the
+// segment's entries minus their value at the unit's first entry are the in-unit prefixes; the unit's own base comes from
+// the scan over the units (which are in scan order: (plane, row, x brick)).
+__global__ __launch_bounds__(256) void mc_compact(McDims d, const uint32_t* __restrict__ slots, const int cap, int bx, int by,
+                                                  int64_t segments, const uint4* __restrict__ unit_prefix,
                                                   const uint4* __restrict__ group_prefix, McActive* __restrict__ list) {
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= tiles) return;
-    const uint4 tp = tile_prefix[tile];
-    if (tp.w == 0) return;                                 // nothing cut in this tile (~60 % of them): its code bytes are not read
-    const int64_t first = tile * MC_TILE + lane * 16;
-    const uint4 w = load_codes16(d, codes4, first);
-    const uint32_t* p = &w.x;
-    uint32_t own[3] = {0, 0, 0};
+    __shared__ uint32_t s_first[4][MC_GY - 1][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
+    if (seg >= segments) return;
+    // counts of the 7 units: .w of the scanned entries (mc_scan_groups keeps each unit's own count there)
+    McSegment sg;
+    mc_segment_place(d, seg, bx, by, sg);
+    {
+        uint32_t c = 0;
+        if (lane < MC_GY - 1 && sg.r0 + lane < d.c1) c = unit_prefix[sg.unit0 + lane * sg.ustride].w;
+        uint32_t run = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t c = p[q] >> (8 * it);
-            own[0] += code_created(c); own[1] += code_nt(c); own[2] += code_nt(c) ? 1 : 0;
+        for (int t = 0; t < MC_GY - 1; ++t) { sg.start[t] = run; run += (uint32_t)__builtin_amdgcn_readlane((int)c, t); }
+        sg.start[MC_GY - 1] = run;
+        if (run == 0) return;
+    }
+    const uint32_t total = sg.start[MC_GY - 1];
+    uint32_t carry_v = 0, carry_t = 0;
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t e = base + lane;
+        const bool live = e < total;
+        int t = 0;
+        uint32_t k = 0, ent = 0;
+        if (live) {
+            t = mc_segment_row(sg, e, k);
+            ent = slots[(sg.unit0 + t * sg.ustride) * cap + k];
         }
-    uint32_t inc[3] = {own[0], own[1], own[2]};
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
+        const uint32_t code = ent >> 16;
+        uint32_t iv = code_created(code), it = code_nt(code);
+        const uint32_t ov = iv, ot = it;
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t pv = __shfl_up(inc[k], o);
-            if (lane >= o) inc[k] += pv;
+            const uint32_t pv = __shfl_up(iv, o), pt = __shfl_up(it, o);
+            if (lane >= o) { iv += pv; it += pt; }
         }
-    if (own[2] == 0) return;
-    const uint4 gp = group_prefix[tile >> 10];
-    uint32_t pre[3] = {gp.x + tp.x + inc[0] - own[0], gp.y + tp.y + inc[1] - own[1], gp.z + tp.z + inc[2] - own[2]};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t c = p[q] >> (8 * it);
-            if (code_nt(c)) {
-                McActive e; e.id = first + 4 * q + it; e.vbase = pre[0]; e.tbase = pre[1];
-                list[pre[2]++] = e;
-            }
-            pre[0] += code_created(c); pre[1] += code_nt(c);
+        const uint32_t ev = carry_v + iv - ov, et = carry_t + it - ot;          // exclusive over the segment's entries
+        if (live && k == 0) { s_first[wave][t][0] = ev; s_first[wave][t][1] = et; }
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            const int64_t unit = sg.unit0 + t * sg.ustride;
+            const uint4 up = unit_prefix[unit], gp = group_prefix[unit >> 10];
+            McActive a;
+            a.id = ((int64_t)sg.z * d.c1 + (sg.r0 + t)) * d.c2 + (sg.xb * MC_UNIT + (int)(ent & 0xffffu));
+            a.vbase = gp.x + up.x + (ev - s_first[wave][t][0]);
+            a.tbase = gp.y + up.y + (et - s_first[wave][t][1]);
+            list[gp.z + up.z + k] = a;
         }
+        carry_v += (uint32_t)__builtin_amdgcn_readlane((int)iv, 63);
+        carry_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---- pass 3b: vertices and faces, one thread per ACTIVE cube (all lanes busy) ---------------------------------
+// A SLAB of a larger volume (per-rank marching cubes, see nm_mc_count_slab): local plane 0 is global plane zg0; the
+// first `ghost` cube layers belong to the slab below -- their cubes are classified and numbered (the faces of the layer above
+// reference the vertices they create) but emit nothing: vertex / face rows start behind the ghost_v / ghost_f they
+// account for, and vertex ids are written as local id + index_base.
+struct McSlab {
+    int zg0, ghost;
+    uint32_t ghost_v, ghost_f;
+    int64_t index_base;
+};
+
 template <bool FACES>
-__global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, McDims d, double iso,
+__global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, McDims d, double iso, McSlab sl,
                                                const McActive* __restrict__ list, const uint32_t* __restrict__ totals,
                                                McOut out, int64_t* __restrict__ vertex_cube,
                                                int8_t* __restrict__ vertex_edge) {
@@ -708,7 +739,7 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
             const int e = lut(off + i);
             if (seen & (1u << e)) continue;
             seen |= 1u << e;
-            if (!owns_edge(e, z, y, x)) continue;
+            if (!owns_edge(e, z + sl.zg0, y, x)) continue;
             double px, py, pz;
             if (e == 12) {
                 double fx = 0, fy = 0, fz = 0, ff = 0;
@@ -718,7 +749,7 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
                     const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
                     fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
                 }
-                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+                px = x + fx / ff; py = y + fy / ff; pz = (z + sl.zg0) + fz / ff;
             } else {
                 const signed char* ea = MC_EDGE_A[e];
                 const signed char* eb = MC_EDGE_B[e];
@@ -728,20 +759,24 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
                 double fx = 0, fy = 0, fz = 0, ff = 0;
                 fx += (double)ea[2] * w1; fy += (double)ea[1] * w1; fz += (double)ea[0] * w1; ff += w1;
                 fx += (double)eb[2] * w2; fy += (double)eb[1] * w2; fz += (double)eb[0] * w2; ff += w2;
-                px = x + fx / ff; py = y + fy / ff; pz = z + fz / ff;
+                px = x + fx / ff; py = y + fy / ff; pz = (z + sl.zg0) + fz / ff;
                 const signed char* lo = MC_EDGE_LO[e];
                 const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
                 out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
             }
-            // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
-            out.verts[3 * (int64_t)next] = (float)pz;
-            out.verts[3 * (int64_t)next + 1] = (float)py;
-            out.verts[3 * (int64_t)next + 2] = (float)px;
-            vertex_cube[next] = ent.id;
-            vertex_edge[next] = (int8_t)e;
+            if (z >= sl.ghost) {
+                const int64_t row = (int64_t)next - sl.ghost_v;
+                // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
+                out.verts[3 * row] = (float)pz;
+                out.verts[3 * row + 1] = (float)py;
+                out.verts[3 * row + 2] = (float)px;
+                vertex_cube[row] = ent.id;
+                vertex_edge[row] = (int8_t)e;
+            }
             ++next;
         }
     } else {
+        if (z < sl.ghost) return;
         // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
         int centre = -1;
         {
@@ -752,7 +787,7 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
                 if (seen & (1u << e)) continue;
                 seen |= 1u << e;
                 if (e == 12) { centre = (int)ent.vbase + k; break; }
-                k += owns_edge(e, z, y, x) ? 1 : 0;
+                k += owns_edge(e, z + sl.zg0, y, x) ? 1 : 0;
             }
         }
         for (int t = 0; t < nt; ++t) {
@@ -765,8 +800,9 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
                 const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
                 idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
             }
-            int32_t* f = out.faces + 3 * ((int64_t)ent.tbase + t);
-            f[0] = idx[2]; f[1] = idx[1]; f[2] = idx[0];   // gradient_direction='descent' reverses each triple
+            int32_t* f = out.faces + 3 * ((int64_t)ent.tbase - sl.ghost_f + t);
+            const int32_t ib = (int32_t)sl.index_base;
+            f[0] = idx[2] + ib; f[1] = idx[1] + ib; f[2] = idx[0] + ib;   // gradient_direction='descent' reverses each triple
         }
     }
 }
@@ -791,7 +827,7 @@ __device__ __constant__ signed char MC_SHARE[3][4][4] = {
     {{-1, 0, -1, 5}, {-1, 0, 0, 7}, {0, 0, -1, 1}, {0, 0, 0, 3}},     // y edge
     {{0, -1, -1, 10}, {0, -1, 0, 11}, {0, 0, -1, 9}, {0, 0, 0, 8}}};  // z edge
 
-__global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restrict__ vol, McDims d, double iso,
+__global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restrict__ vol, McDims d, McDims dc, double iso,
                                                             const int64_t* __restrict__ vertex_cube,
                                                             const int8_t* __restrict__ vertex_edge, int64_t nverts,
                                                             McOut out) {
@@ -800,7 +836,7 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
     const int64_t home = vertex_cube[vid];
     const int e_home = vertex_edge[vid];
     int hz, hy, hx;
-    cube_coords(d, home, hz, hy, hx);
+    cube_coords(dc, home, hz, hy, hx);      // ids count the classified layers; the neighbours may lie in the ghost layer above (d)
     float nx = 0.0f, ny = 0.0f, nz = 0.0f, value = 0.0f;
     int ncubes = 1, axis = 0, lz = 0, ly = 0, lx = 0;
     if (e_home != 12) {
@@ -874,9 +910,10 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
 static inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct McWorkspace {
-    uint32_t* codes; uint4* tile_sums; uint8_t* tile_flag; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
+    uint64_t* masks; uint32_t* slots; uint4* unit_sums; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
     McActive* active;
-    int64_t tiles;
+    int64_t units;     // (plane, row, x brick) triples, in scan order
+    int cap, bx, by;   // entries per unit; x bricks per row; row groups per plane
 };
 
 static McDims make_dims(int n0, int n1, int n2) {
@@ -885,18 +922,20 @@ static McDims make_dims(int n0, int n1, int n2) {
 }
 
 static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
-    const int64_t tiles = (d.cubes + MC_TILE - 1) / MC_TILE;
+    const int bx = (d.c2 + MC_UNIT - 1) / MC_UNIT, by = (d.c1 + MC_GY - 2) / (MC_GY - 1);
+    const int cap = bx > 1 ? MC_UNIT : ((d.c2 + 3) & ~3);
+    const int64_t units = (int64_t)d.c0 * d.c1 * bx;
     const size_t vox = (size_t)d.n0 * d.n1 * d.n2;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
     char* p;
-    p = take((((size_t)d.cubes + 3) & ~size_t(3)) + 4096); if (ws) ws->codes = (uint32_t*)p;
-    p = take((size_t)tiles * 16); if (ws) ws->tile_sums = (uint4*)p;
-    p = take((size_t)tiles); if (ws) ws->tile_flag = (uint8_t*)p;
-    p = take((size_t)((tiles + 1023) / 1024) * 16); if (ws) ws->group_sums = (uint4*)p;
+    p = take((size_t)units * 64); if (ws) ws->masks = (uint64_t*)p;
+    p = take((size_t)units * cap * 4); if (ws) ws->slots = (uint32_t*)p;
+    p = take((size_t)units * 16); if (ws) ws->unit_sums = (uint4*)p;
+    p = take((size_t)((units + 1023) / 1024) * 16); if (ws) ws->group_sums = (uint4*)p;
     p = take(256); if (ws) ws->totals = (uint32_t*)p;
     for (int a = 0; a < 3; ++a) { p = take(vox * 4); if (ws) ws->edge[a] = (int32_t*)p; }
-    if (ws) ws->tiles = tiles;
+    if (ws) { ws->units = units; ws->cap = cap; ws->bx = bx; ws->by = by; }
     return off;
 }
 
@@ -916,16 +955,26 @@ int64_t nm_mc_vertex_scratch_bytes(int64_t vertices, int64_t faces) {
     return (int64_t)(al((size_t)vertices * 8) + al((size_t)vertices) + al((size_t)faces * sizeof(McActive)));
 }
 
-int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
-                int64_t* h_vertices, int64_t* h_faces, void* stream_) {
-    NM_REQUIRE(d_volume && d_workspace && h_vertices && h_faces, "bad argument");
+int nm_mc_count_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, int32_t z_global,
+                     int32_t ghost_below, int32_t ghost_above, void* d_workspace, int64_t* h_vertices, int64_t* h_faces,
+                     int64_t* h_ghost_vertices, int64_t* h_ghost_faces, void* stream_) {
+    NM_REQUIRE(d_volume && d_workspace && h_vertices && h_faces && h_ghost_vertices && h_ghost_faces, "bad argument");
     NM_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
+    NM_REQUIRE((ghost_below == 0 || ghost_below == 1) && (ghost_above == 0 || ghost_above == 1) && z_global >= 0,
+               "mc slab: ghost layers are 0 or 1 planes, the global plane index is >= 0");
+    NM_REQUIRE(n0 - 1 - ghost_below - ghost_above >= 1, "mc slab: the slab needs a cube layer of its own");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const McDims d = make_dims(n0, n1, n2);
     NM_REQUIRE(d.cubes < (int64_t(1) << 40), "volume too large");
     McWorkspace ws;
     carve(d, static_cast<char*>(d_workspace), &ws);
-    const int c_rows = MC_MARCH0 ? d.c1 : d.c0, c_march = MC_MARCH0 ? d.c0 : d.c1;
+    // the layers this call classifies: everything but the ghost layer above (that one belongs to the next slab; its voxels
+    // are only read when the normals of this slab's top vertices replay the cubes around them)
+    McDims dc = d;
+    dc.c0 = d.c0 - ghost_above;
+    dc.cubes = (int64_t)dc.c0 * d.c1 * d.c2;
+    const int64_t units = (int64_t)dc.c0 * d.c1 * ws.bx;
+    const int c_rows = MC_MARCH0 ? dc.c1 : dc.c0, c_march = MC_MARCH0 ? dc.c0 : dc.c1;
     static int cus_of_device[64] = {};
     int dev = 0;
     NM_HIP_CHECK(hipGetDevice(&dev));
@@ -934,71 +983,92 @@ int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, doubl
         NM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         cus_of_device[dev] = prop.multiProcessorCount;
     }
-    const unsigned bx = (unsigned)((d.c2 + MC_GX * MC_ITEMS - 1) / (MC_GX * MC_ITEMS)), by = (unsigned)((c_rows + MC_GY - 2) / (MC_GY - 1));
+    const unsigned bx = (unsigned)ws.bx, by = (unsigned)((c_rows + MC_GY - 2) / (MC_GY - 1));
     const int zrun = mc_pick_zrun((int64_t)bx * by, c_march, dev >= 0 && dev < 64 ? cus_of_device[dev] : 0);
     const dim3 bricks(bx, by, (unsigned)((c_march + zrun - 1) / zrun));
     NM_REQUIRE(bricks.y <= 65535u && bricks.z <= 65535u, "volume too large");
-    // code bytes: zero everywhere (incl. the <= 3 bytes behind the last cube that share a dword with real cubes);
-    // the cut cubes' bytes are written by mc_classify_cut
-    NM_HIP_CHECK(hipMemsetAsync(ws.codes, 0, (((size_t)d.cubes + 3) & ~size_t(3)) + 8, stream));
     NM_HIP_CHECK(hipMemsetAsync(ws.totals, 0, 256, stream));
-    NM_HIP_CHECK(hipMemsetAsync(ws.tile_flag, 0, (size_t)ws.tiles, stream));        // set by mc_classify_cut
     float thr = (float)iso;                        // largest float <= iso (exact equivalence of the sign test)
     if ((double)thr > iso) thr = nextafterf(thr, -INFINITY);
-    // the queue of cut cubes (worst case: every cube) lives in the first two edge->vertex volumes, which nothing
-    // touches before nm_mc_emit
-    uint64_t* queue = reinterpret_cast<uint64_t*>(ws.edge[0]);
-    unsigned long long* qcount = reinterpret_cast<unsigned long long*>(ws.totals + 8);
     const bool vec = n2 % 4 == 0, xhalo = bricks.x > 1;
-#define NM_STREAM(V, X) hipLaunchKernelGGL((mc_classify_stream<V, X>), bricks, dim3(MC_STREAM_THREADS), 0, stream, d_volume, d, thr, queue, qcount, zrun)
+#define NM_STREAM(V, X) hipLaunchKernelGGL((mc_classify_stream<V, X>), bricks, dim3(MC_STREAM_THREADS), 0, stream, d_volume, dc, thr, ws.masks, zrun)
     if (vec && !xhalo) NM_STREAM(true, false);
     else if (vec) NM_STREAM(true, true);
     else if (!xhalo) NM_STREAM(false, false);
     else NM_STREAM(false, true);
 #undef NM_STREAM
-    hipLaunchKernelGGL(mc_classify_cut, dim3(2048), dim3(MC_BLOCK), 0, stream, d_volume, d, iso, queue, qcount,
-                       reinterpret_cast<uint8_t*>(ws.codes), ws.tile_flag);
-    hipLaunchKernelGGL(mc_tile_sums, dim3((unsigned)((ws.tiles + 3) / 4)), dim3(256), 0, stream, d, ws.codes, ws.tiles,
-                       ws.tile_flag, ws.tile_sums);
-    const int64_t groups = (ws.tiles + 1023) / 1024;
-    hipLaunchKernelGGL(mc_scan_groups, dim3((unsigned)groups), dim3(1024), 0, stream, ws.tile_sums, ws.tiles, ws.group_sums);
+    const int64_t segments = (int64_t)dc.c0 * by * bx;
+    hipLaunchKernelGGL(mc_classify_cut, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0, stream, d_volume, dc, iso, (int)z_global,
+                       ws.masks, ws.slots, ws.cap, (int)bx, (int)by, segments, ws.unit_sums);
+    const int64_t groups = (units + 1023) / 1024;
+    hipLaunchKernelGGL(mc_scan_groups, dim3((unsigned)groups), dim3(1024), 0, stream, ws.unit_sums, units, ws.group_sums);
     hipLaunchKernelGGL(mc_scan_totals, dim3(1), dim3(1024), 0, stream, ws.group_sums, groups, ws.totals);
     NM_HIP_CHECK(hipGetLastError());
     uint32_t totals[3];
+    uint4 ghost_unit = make_uint4(0, 0, 0, 0), ghost_group = make_uint4(0, 0, 0, 0);
     NM_HIP_CHECK(hipMemcpyAsync(totals, ws.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
+    if (ghost_below) {      // what the first layer accounts for = the exclusive prefix of the first unit of the second layer
+        const int64_t u1 = (int64_t)d.c1 * ws.bx;
+        NM_HIP_CHECK(hipMemcpyAsync(&ghost_unit, ws.unit_sums + u1, sizeof(uint4), hipMemcpyDeviceToHost, stream));
+        NM_HIP_CHECK(hipMemcpyAsync(&ghost_group, ws.group_sums + (u1 >> 10), sizeof(uint4), hipMemcpyDeviceToHost, stream));
+    }
     NM_HIP_CHECK(hipStreamSynchronize(stream));
     *h_vertices = totals[0];
     *h_faces = totals[1];
+    *h_ghost_vertices = (int64_t)ghost_unit.x + ghost_group.x;
+    *h_ghost_faces = (int64_t)ghost_unit.y + ghost_group.y;
     return 0;
 }
 
-int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
-               void* d_vertex_scratch, int64_t vertices, int64_t faces, float* d_verts, int32_t* d_faces,
-               float* d_normals, float* d_values, void* stream_) {
+int nm_mc_count(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
+                int64_t* h_vertices, int64_t* h_faces, void* stream_) {
+    int64_t gv = 0, gf = 0;
+    return nm_mc_count_slab(d_volume, n0, n1, n2, iso, 0, 0, 0, d_workspace, h_vertices, h_faces, &gv, &gf, stream_);
+}
+
+int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, int32_t z_global,
+                    int32_t ghost_below, int32_t ghost_above, void* d_workspace, void* d_vertex_scratch, int64_t vertices,
+                    int64_t faces, int64_t ghost_vertices, int64_t ghost_faces, int64_t index_base, float* d_verts,
+                    int32_t* d_faces, float* d_normals, float* d_values, void* stream_) {
     NM_REQUIRE(d_volume && d_workspace && d_vertex_scratch && d_verts && d_faces && d_normals && d_values, "bad argument");
+    NM_REQUIRE(ghost_vertices >= 0 && ghost_vertices <= vertices && ghost_faces >= 0 && ghost_faces <= faces, "mc slab: bad ghost counts");
+    NM_REQUIRE(index_base + vertices < (int64_t(1) << 31) && index_base + ghost_vertices >= 0, "mc slab: vertex ids do not fit int32");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (vertices == 0) return 0;
     const McDims d = make_dims(n0, n1, n2);
     McWorkspace ws;
     carve(d, static_cast<char*>(d_workspace), &ws);
+    McDims dc = d;
+    dc.c0 = d.c0 - ghost_above;
+    dc.cubes = (int64_t)dc.c0 * d.c1 * d.c2;
+    const int64_t own_v = vertices - ghost_vertices;
     ws.vertex_cube = static_cast<int64_t*>(d_vertex_scratch);
     ws.vertex_edge = reinterpret_cast<int8_t*>(static_cast<char*>(d_vertex_scratch) + al((size_t)vertices * 8));
     ws.active = reinterpret_cast<McActive*>(static_cast<char*>(d_vertex_scratch) + al((size_t)vertices * 8) + al((size_t)vertices));
     McOut out;
     out.verts = d_verts; out.faces = d_faces; out.normals = d_normals; out.values = d_values;
     for (int a = 0; a < 3; ++a) out.edge_vertex[a] = ws.edge[a];
+    McSlab sl{(int)z_global, (int)ghost_below, (uint32_t)ghost_vertices, (uint32_t)ghost_faces, index_base};
     const unsigned ablocks = (unsigned)((faces + 255) / 256);   // active cubes <= faces; surplus threads exit
-    hipLaunchKernelGGL(mc_compact, dim3((unsigned)((ws.tiles + 3) / 4)), dim3(256), 0, stream, d, ws.codes, ws.tiles,
-                       ws.tile_sums, ws.group_sums, ws.active);
-    hipLaunchKernelGGL(mc_emit<false>, dim3(ablocks), dim3(256), 0, stream, d_volume, d, iso, ws.active, ws.totals, out,
+    const int64_t segments = (int64_t)dc.c0 * ws.by * ws.bx;
+    hipLaunchKernelGGL(mc_compact, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0, stream, dc, ws.slots, ws.cap, ws.bx, ws.by,
+                       segments, ws.unit_sums, ws.group_sums, ws.active);
+    hipLaunchKernelGGL(mc_emit<false>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
                        ws.vertex_cube, ws.vertex_edge);
-    hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, d, iso, ws.active, ws.totals, out,
+    hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
                        ws.vertex_cube, ws.vertex_edge);
-    hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((vertices + 255) / 256)), dim3(256), 0, stream, d_volume, d, iso,
-                       ws.vertex_cube, ws.vertex_edge, vertices, out);
+    if (own_v > 0)
+        hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((own_v + 255) / 256)), dim3(256), 0, stream, d_volume, d, dc, iso,
+                           ws.vertex_cube, ws.vertex_edge, own_v, out);
     NM_HIP_CHECK(hipGetLastError());
-    (void)faces;
     return 0;
+}
+
+int nm_mc_emit(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, double iso, void* d_workspace,
+               void* d_vertex_scratch, int64_t vertices, int64_t faces, float* d_verts, int32_t* d_faces,
+               float* d_normals, float* d_values, void* stream_) {
+    return nm_mc_emit_slab(d_volume, n0, n1, n2, iso, 0, 0, 0, d_workspace, d_vertex_scratch, vertices, faces, 0, 0, 0, d_verts,
+                           d_faces, d_normals, d_values, stream_);
 }
 
 }  // extern "C"

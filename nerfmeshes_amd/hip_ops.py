@@ -416,3 +416,43 @@ def marching_cubes(volume, level):
     check(lib.nm_mc_emit(_ptr(vol), n0, n1, n2, level, _ptr(ws), _ptr(scratch), nv.value, nf.value, _ptr(verts),
                          _ptr(faces), _ptr(normals), _ptr(values), _stream()), "nm_mc_emit")
     return verts, faces, normals, values
+
+
+def marching_cubes_slab(volume, level, z_global, ghost_below, ghost_above):
+    """Marching cubes of ONE axis-0 slab of a larger grid (nm_mc_count_slab / nm_mc_emit_slab).  `volume` holds the global
+    planes [z_global, z_global + n0); its first cube layer is a ghost of the slab below (`ghost_below`), its last one a ghost
+    of the slab above (`ghost_above`).  Returns an object with `.vertices` (the slab's own vertex count), `.faces`,
+    `.ghost_vertices`, and `.emit(index_base)` -> (verts, faces, normals, values) with face entries = local id + index_base.
+    Concatenating the ranks' arrays in rank order, with index_base = (own vertex counts of all lower ranks) - ghost_vertices,
+    gives the mesh of the whole grid bit for bit (dist.marching_cubes_sharded does that)."""
+    lib = _lib.load()
+    if not isinstance(volume, torch.Tensor) or volume.dim() != 3:
+        raise ValueError("Input volume should be a 3D tensor.")
+    vol = _dev32(volume, name="volume")
+    level = float(level)
+    n0, n1, n2 = vol.shape
+    dev = vol.device
+    ws = torch.empty(int(lib.nm_mc_workspace_bytes(n0, n1, n2)), dtype=torch.uint8, device=dev)
+    nv, nf, gv, gf = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib.nm_mc_count_slab(_ptr(vol), n0, n1, n2, level, int(z_global), int(bool(ghost_below)), int(bool(ghost_above)),
+                               _ptr(ws), C.byref(nv), C.byref(nf), C.byref(gv), C.byref(gf), _stream()), "nm_mc_count_slab")
+
+    class Slab:
+        vertices, faces = nv.value - gv.value, nf.value - gf.value
+        ghost_vertices, ghost_faces = gv.value, gf.value
+
+        @staticmethod
+        def emit(index_base):
+            verts = torch.empty(Slab.vertices, 3, dtype=torch.float32, device=dev)
+            normals = torch.empty(Slab.vertices, 3, dtype=torch.float32, device=dev)
+            values = torch.empty(Slab.vertices, dtype=torch.float32, device=dev)
+            faces = torch.empty(Slab.faces, 3, dtype=torch.int32, device=dev)
+            if nv.value:
+                scratch = torch.empty(int(lib.nm_mc_vertex_scratch_bytes(nv.value, nf.value)) + 256, dtype=torch.uint8, device=dev)
+                check(lib.nm_mc_emit_slab(_ptr(vol), n0, n1, n2, level, int(z_global), int(bool(ghost_below)), int(bool(ghost_above)),
+                                          _ptr(ws), _ptr(scratch), nv.value, nf.value, gv.value, gf.value, int(index_base),
+                                          _ptr(verts), _ptr(faces), _ptr(normals), _ptr(values), _stream()), "nm_mc_emit_slab")
+            return verts, faces, normals, values
+
+    return Slab
+

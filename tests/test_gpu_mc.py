@@ -75,6 +75,42 @@ def test_mc_vs_oracle_bitwise(ops, shape, kind):
     _check(ops, vol, iso, ref, f"{shape} {kind}")
 
 
+@pytest.mark.parametrize("shape,parts", [((9, 6, 7), 2), ((33, 40, 21), 3), ((64, 64, 64), 8), ((26, 10, 1032), 4), ((5, 9, 11), 4)])
+@pytest.mark.parametrize("kind", ["noise", "ties", "smooth"])
+def test_mc_slabs_concatenate_to_the_whole_mesh(ops, shape, parts, kind):
+    """Per-slab marching cubes (nm_mc_count_slab / nm_mc_emit_slab): the cube layers of a volume are cut into `parts` slabs,
+    every slab is meshed on its own from its planes plus one ghost plane on either side, and the slabs' arrays concatenated
+    in order ARE the mesh of the whole volume -- vertices, faces with their vertex numbering, normals, values, bitwise."""
+    from nerfmeshes_amd import dist as nd
+    rng = np.random.default_rng(hash((shape, kind, parts)) % (2 ** 32))
+    if kind == "noise":
+        vol, iso = rng.standard_normal(shape).astype(np.float32), 0.1
+    elif kind == "ties":
+        vol, iso = rng.integers(-2, 3, shape).astype(np.float32), 0.0
+    else:
+        g = np.stack(np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing="ij"), -1)
+        vol, iso = (np.sin(3 * g[..., 0]) * np.cos(2 * g[..., 1]) + g[..., 2] ** 2 - 0.3).astype(np.float32), float(np.float32(0.05))
+    full = torch.from_numpy(vol).cuda()
+    try:
+        want = ops.marching_cubes(full, iso)
+    except (RuntimeError, ValueError):
+        pytest.skip("no surface in this volume")
+    layers = shape[0] - 1
+    pieces, base = [], 0
+    for r in range(parts):
+        lo, hi = nd.split_range(layers, r, parts)
+        if hi == lo:
+            continue                                                   # more parts than layers: an empty slab
+        below, above = int(lo > 0), int(hi < layers)
+        sub = full[lo - below:hi + 1 + above].contiguous()             # planes lo - below .. hi + above
+        slab = ops.marching_cubes_slab(sub, iso, lo - below, below, above)
+        pieces.append(slab.emit(base - slab.ghost_vertices))
+        base += slab.vertices
+    got = [torch.cat([p[i] for p in pieces], 0) for i in range(4)]
+    for name, a, b in zip(("vertices", "faces", "normals", "values"), got, want):
+        assert a.shape == b.shape and torch.equal(a, b), f"{shape} {kind} x{parts}: {name} differ"
+
+
 def test_mc_errors(ops):
     vol = torch.ones(4, 4, 4, device="cuda")
     with pytest.raises(ValueError):
