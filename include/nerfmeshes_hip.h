@@ -301,6 +301,22 @@ int nm_sample_pdf_rand(const float* d_t, const float* d_weights, const float* d_
 int64_t nm_np_stats_workspace_bytes(int64_t n);
 int nm_np_stats(const float* d_x, int64_t n, void* d_workspace, float* h_out6, void* stream);
 
+/* The same statistics when the array is spread over several devices (multi-GPU mesh extraction: every rank holds an axis-0
+ * slab of the density grid and the adaptive iso level of src/mesh_nerf.py:56-65 still has to be numpy's, bit for bit).
+ * numpy sums 8192-element chunks pairwise and accumulates the chunk sums sequentially, so the two stages separate:
+ *   nm_np_chunk_sums  a rank holding the global elements [first, first + count) sums the chunks [chunk_lo, chunk_hi) of
+ *                     the GLOBAL array of n elements (all of their elements must be held).  First pass
+ *                     (squared_deviation = 0): sums + per-chunk min / max (NaN-propagating, as numpy); second pass
+ *                     (squared_deviation = 1, with the mean of the first): sums of (x - mean)^2; d_csum then needs room
+ *                     for chunk_hi - chunk_lo + 1 floats.
+ *   nm_np_finish      the chunk sums of all ranks concatenated in chunk order -> [sum, mean, -, -, min, max] (first pass)
+ *                     or [-, -, var, std, -, -] (second pass) in d_out6 / h_out6; synchronises the stream. */
+int64_t nm_np_chunk_count(int64_t n);
+int nm_np_chunk_sums(const float* d_x, int64_t first, int64_t count, int64_t n, int64_t chunk_lo, int64_t chunk_hi,
+                     int32_t squared_deviation, float mean, float* d_csum, float* d_cmin, float* d_cmax, void* stream);
+int nm_np_finish(const float* d_csum, const float* d_cmin, const float* d_cmax, int64_t chunks, int64_t n,
+                 int32_t squared_deviation, float* d_out6, float* h_out6, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BuFF voxel-tree sampler: TreeSampling.batch_ray_voxel_intersect, deterministic branch
  * (src/nerf/tree.py:215-343).  d_voxels (nvox,2,3) min/max corners; d_origins (1,3) or (rays,3);

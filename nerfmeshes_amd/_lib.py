@@ -124,6 +124,10 @@ SIGNATURES = {
                                            c_void_p, C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_np_stats_workspace_bytes": (C.c_int64, [C.c_int64]),
     "nm_np_stats": (C.c_int, [c_void_p, C.c_int64, c_void_p, c_float_p, c_void_p]),
+    "nm_np_chunk_count": (C.c_int64, [C.c_int64]),
+    "nm_np_chunk_sums": (C.c_int, [c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_float, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "nm_np_finish": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int64, C.c_int32, c_void_p, c_float_p, c_void_p]),
     "nm_tree_workspace_bytes": (C.c_int64, [C.c_int32]),
     "nm_tree_integrate": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p, c_void_p,
                                     c_void_p]),

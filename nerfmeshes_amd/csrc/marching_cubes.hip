@@ -34,7 +34,6 @@
 namespace nm {
 
 constexpr double SK_EPS = 2.220446049250313e-16;   // skimage's "FLT_EPSILON" is np.spacing(1.0)
-constexpr int MC_BLOCK = 256;
 constexpr int MC_ITEMS = 4;                          // CONSECUTIVE cubes per thread (their 4 code bytes = one dword)
 
 struct McDims {

@@ -22,6 +22,10 @@ namespace nm {
 
 constexpr int NP_CHUNK = 8192;
 
+// numpy's minimum / maximum reductions propagate NaN (fminf / fmaxf would drop it)
+__device__ __forceinline__ float np_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float np_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+
 template <bool SQDEV>
 __device__ __forceinline__ float np_elem(const float* __restrict__ a, int64_t i, float mean) {
     const float v = a[i];
@@ -71,21 +75,24 @@ __device__ float np_pairwise(const float* __restrict__ a, int64_t off, int n, fl
 // one wavefront per full chunk; also folds min / max of the raw values (exact, order-free) into the first pass
 template <bool SQDEV>
 __global__ __launch_bounds__(64) void np_chunk_sums_kernel(const float* __restrict__ a, int64_t full_chunks, int64_t n,
+                                                           int64_t chunk_lo, int64_t chunk_hi,
                                                            const float* __restrict__ mean_ptr, float* __restrict__ csum,
                                                            float* __restrict__ cmin, float* __restrict__ cmax) {
+    // `a` is addressed with GLOBAL element indices (the caller offsets the pointer when it holds a slice of the array);
+    // chunks [chunk_lo, chunk_hi) of the global array are summed, results at csum[chunk - chunk_lo]
     const int lane = threadIdx.x;
     const int blk = lane >> 3, j = lane & 7;          // block of this iteration's 8, accumulator
     const float mean = SQDEV ? *mean_ptr : 0.0f;
-    const int64_t total_chunks = full_chunks + ((n % NP_CHUNK) ? 1 : 0);
-    for (int64_t c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+    csum -= chunk_lo; cmin -= chunk_lo; cmax -= chunk_lo;
+    for (int64_t c = chunk_lo + blockIdx.x; c < chunk_hi; c += gridDim.x) {
         const int64_t base = c * NP_CHUNK;
         if (c >= full_chunks) {                         // ragged tail: generic recursion on one lane
             const int m = (int)(n - base);
             if (lane == 0) csum[c] = np_pairwise<SQDEV>(a, base, m, mean);
             if (!SQDEV) {
                 float lo = INFINITY, hi = -INFINITY;
-                for (int i = lane; i < m; i += 64) { const float v = a[base + i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
-                for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+                for (int i = lane; i < m; i += 64) { const float v = a[base + i]; lo = np_min(lo, v); hi = np_max(hi, v); }
+                for (int off = 32; off > 0; off >>= 1) { lo = np_min(lo, __shfl_xor(lo, off)); hi = np_max(hi, __shfl_xor(hi, off)); }
                 if (lane == 0) { cmin[c] = lo; cmax[c] = hi; }
             }
             continue;
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(64) void np_chunk_sums_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float v = p[8 * i];
-                if (!SQDEV) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+                if (!SQDEV) { lo = np_min(lo, v); hi = np_max(hi, v); }
                 float e = v;
                 if (SQDEV) { const float d = v - mean; e = d * d; }
                 r = i == 0 ? e : r + e;
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(64) void np_chunk_sums_kernel(const float* __restri
         const float s = ((sub[0] + sub[1]) + (sub[2] + sub[3])) + ((sub[4] + sub[5]) + (sub[6] + sub[7]));
         if (lane == 0) csum[c] = s;
         if (!SQDEV) {
-            for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+            for (int off = 32; off > 0; off >>= 1) { lo = np_min(lo, __shfl_xor(lo, off)); hi = np_max(hi, __shfl_xor(hi, off)); }
             if (lane == 0) { cmin[c] = lo; cmax[c] = hi; }
         }
     }
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void np_finish_kernel(const float* __restrict_
         const int m = (int)((chunks - base) < 8192 ? (chunks - base) : 8192);
         for (int i = threadIdx.x; i < m; i += 256) {
             tile[i] = csum[base + i];
-            if (!SQDEV) { lo = fminf(lo, cmin[base + i]); hi = fmaxf(hi, cmax[base + i]); }
+            if (!SQDEV) { lo = np_min(lo, cmin[base + i]); hi = np_max(hi, cmax[base + i]); }
         }
         __syncthreads();
         if (threadIdx.x == 0)
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void np_finish_kernel(const float* __restrict_
         red[0][threadIdx.x] = lo; red[1][threadIdx.x] = hi;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int i = 1; i < 256; ++i) { lo = fminf(lo, red[0][i]); hi = fmaxf(hi, red[1][i]); }
+            for (int i = 1; i < 256; ++i) { lo = np_min(lo, red[0][i]); hi = np_max(hi, red[1][i]); }
             out[4] = lo; out[5] = hi;
         }
     }
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256) void np_finish_kernel(const float* __restrict_
 using namespace nm;
 
 extern "C" int64_t nm_np_stats_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
     const int64_t chunks = (n + NP_CHUNK - 1) / NP_CHUNK;
     return (3 * chunks + 16) * 4;
 }
@@ -176,14 +184,64 @@ extern "C" int nm_np_stats(const float* d_x, int64_t n, void* d_workspace, float
     float* cmax = cmin + chunks;
     float* out = cmax + chunks;                          // 6 floats (+ padding)
     const unsigned grid = (unsigned)(chunks < 65536 ? chunks : 65536);
-    hipLaunchKernelGGL(np_chunk_sums_kernel<false>, dim3(grid), dim3(64), 0, stream, d_x, full, n, (const float*)nullptr,
-                       csum, cmin, cmax);
+    hipLaunchKernelGGL(np_chunk_sums_kernel<false>, dim3(grid), dim3(64), 0, stream, d_x, full, n, (int64_t)0, chunks,
+                       (const float*)nullptr, csum, cmin, cmax);
     hipLaunchKernelGGL(np_finish_kernel<false>, dim3(1), dim3(256), 0, stream, csum, cmin, cmax, chunks, n, out);
-    hipLaunchKernelGGL(np_chunk_sums_kernel<true>, dim3(grid), dim3(64), 0, stream, d_x, full, n, (const float*)(out + 1),
-                       csum, cmin, cmax);
+    hipLaunchKernelGGL(np_chunk_sums_kernel<true>, dim3(grid), dim3(64), 0, stream, d_x, full, n, (int64_t)0, chunks,
+                       (const float*)(out + 1), csum, cmin, cmax);
     hipLaunchKernelGGL(np_finish_kernel<true>, dim3(1), dim3(256), 0, stream, csum, cmin, cmax, chunks, n, out);
     NM_HIP_CHECK(hipGetLastError());
     NM_HIP_CHECK(hipMemcpyAsync(h_out6, out, 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    NM_HIP_CHECK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// The same statistics of an array that is spread over several devices (axis-0 slabs of the density grid): the two stages
+// separately.  A rank holds the global elements [first, first + count) and sums the 8192-element chunks
+// [chunk_lo, chunk_hi) of the GLOBAL array (every element of those chunks must be among the ones it holds);
+// nm_np_chunk_count(n) chunks exist.  The chunk sums of all ranks, concatenated in chunk order, go through nm_np_finish --
+// the sequential fp32 accumulation numpy's reduction iterator performs -- on every rank alike.
+extern "C" int64_t nm_np_chunk_count(int64_t n) { return n > 0 ? (n + NP_CHUNK - 1) / NP_CHUNK : 0; }
+
+extern "C" int nm_np_chunk_sums(const float* d_x, int64_t first, int64_t count, int64_t n, int64_t chunk_lo, int64_t chunk_hi,
+                                int32_t squared_deviation, float mean, float* d_csum, float* d_cmin, float* d_cmax,
+                                void* stream_) {
+    NM_REQUIRE(d_x && d_csum && n > 0 && count > 0 && first >= 0 && first + count <= n, "bad argument");
+    NM_REQUIRE(squared_deviation || (d_cmin && d_cmax), "np_chunk_sums: the first pass also returns the chunks' min / max");
+    const int64_t chunks = (n + NP_CHUNK - 1) / NP_CHUNK;
+    NM_REQUIRE(chunk_lo >= 0 && chunk_lo <= chunk_hi && chunk_hi <= chunks, "np_chunk_sums: bad chunk range");
+    if (chunk_hi == chunk_lo) return 0;
+    const int64_t need_hi = chunk_hi * NP_CHUNK < n ? chunk_hi * NP_CHUNK : n;
+    NM_REQUIRE(chunk_lo * NP_CHUNK >= first && need_hi <= first + count, "np_chunk_sums: the chunks reach outside the held elements");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t m = chunk_hi - chunk_lo;
+    const unsigned grid = (unsigned)(m < 65536 ? m : 65536);
+    float* d_mean = nullptr;
+    if (squared_deviation) {            // the kernel reads the mean from device memory: park it behind the caller's sums
+        d_mean = d_csum + m;            // (the caller allocates m + 1 floats for the second pass)
+        NM_HIP_CHECK(hipMemcpyAsync(d_mean, &mean, sizeof(float), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(np_chunk_sums_kernel<true>, dim3(grid), dim3(64), 0, stream, d_x - first, n / NP_CHUNK, n, chunk_lo,
+                           chunk_hi, (const float*)d_mean, d_csum, d_cmin, d_cmax);
+        NM_HIP_CHECK(hipStreamSynchronize(stream));      // `mean` lives on the caller's stack
+    } else {
+        hipLaunchKernelGGL(np_chunk_sums_kernel<false>, dim3(grid), dim3(64), 0, stream, d_x - first, n / NP_CHUNK, n, chunk_lo,
+                           chunk_hi, (const float*)nullptr, d_csum, d_cmin, d_cmax);
+    }
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nm_np_finish(const float* d_csum, const float* d_cmin, const float* d_cmax, int64_t chunks, int64_t n,
+                            int32_t squared_deviation, float* d_out6, float* h_out6, void* stream_) {
+    NM_REQUIRE(d_csum && d_out6 && h_out6 && chunks > 0 && n > 0, "bad argument");
+    NM_REQUIRE(squared_deviation || (d_cmin && d_cmax), "np_finish: the first pass folds the chunks' min / max");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (squared_deviation)
+        hipLaunchKernelGGL(np_finish_kernel<true>, dim3(1), dim3(256), 0, stream, d_csum, d_cmin, d_cmax, chunks, n, d_out6);
+    else
+        hipLaunchKernelGGL(np_finish_kernel<false>, dim3(1), dim3(256), 0, stream, d_csum, d_cmin, d_cmax, chunks, n, d_out6);
+    NM_HIP_CHECK(hipGetLastError());
+    NM_HIP_CHECK(hipMemcpyAsync(h_out6, d_out6, 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
     NM_HIP_CHECK(hipStreamSynchronize(stream));
     return 0;
 }

@@ -154,6 +154,63 @@ def density_grid_sharded(query_fn, n0, n1, n2):
     return all_gather_rows(query_fn(lo, hi), counts).view(n0, n1, n2)
 
 
+def all_gather_ragged(local):
+    """All-gather of tensors whose first dimension differs per rank (the counts travel first)."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = torch.empty(ws, dtype=torch.int64, device=local.device)
+    all_gather_into(counts, mine)
+    return all_gather_rows(local, [int(c) for c in counts.tolist()])
+
+
+def slab_layers(n0, rank, world_size):
+    """Marching cubes per slab: the cube layers [lo, hi) of rank `rank` (the n0 - 1 layers split like any range), whether
+    a ghost layer below / above goes with them, and the voxel planes [p_lo, p_hi) it needs for that."""
+    lo, hi = split_range(n0 - 1, rank, world_size)
+    below, above = int(lo > 0 and hi > lo), int(hi < n0 - 1 and hi > lo)
+    return lo, hi, below, above, lo - below, hi + 1 + above
+
+
+def marching_cubes_sharded(query_fn, n0, n1, n2, iso_fn):
+    """Mesh of an (n0, n1, n2) density grid without assembling the grid anywhere (BASELINE north_star: "all-gather of ...
+    emitted triangles"; replaces the grid all-gather in front of marching cubes, /root/reference/src/mesh_nerf.py:73-79).
+    Rank r evaluates the planes of its own cube layers plus one ghost plane on either side -- `query_fn(p_lo, p_hi)` ->
+    ((p_hi - p_lo) * n1 * n2,) densities; the 2 - 3 shared planes per boundary are recomputed rather than exchanged --,
+    `iso_fn(slab, p_lo, own_lo, own_hi)` returns the iso level (collectively: numpy's statistics of the whole grid from
+    per-rank chunk sums), every rank meshes its slab (nm_mc_count_slab / nm_mc_emit_slab: vertex ownership by GLOBAL plane
+    index, vertex ids offset by the vertex counts of the lower ranks, which are all-gathered), and the four arrays are
+    all-gathered in rank order.  The result equals the single-GPU mesh bit for bit, vertex numbering included.
+    Returns (vertices, faces, normals, values, local slab (planes p_lo .. p_hi))."""
+    from . import hip_ops
+    rank, ws = world()
+    lo, hi, below, above, p_lo, p_hi = slab_layers(n0, rank, ws)
+    plane = n1 * n2
+    empty = hi == lo                          # more ranks than cube layers
+    slab = query_fn(p_lo, p_hi).view(p_hi - p_lo, n1, n2) if not empty else None
+    # voxel planes this rank accounts for in whole-grid statistics: its layers' lower planes; the last non-empty rank also
+    # the top plane
+    own_lo, own_hi = lo * plane, (hi + (1 if hi == n0 - 1 else 0)) * plane if not empty else lo * plane
+    iso = iso_fn(slab, p_lo, own_lo, own_hi)
+    dev = slab.device if slab is not None else torch.device("cuda", torch.cuda.current_device())
+    if empty:
+        v = torch.empty(0, 3, dtype=torch.float32, device=dev)
+        parts = [v, torch.empty(0, 3, dtype=torch.int32, device=dev), v.clone(), torch.empty(0, dtype=torch.float32, device=dev)]
+        mine = torch.zeros(1, dtype=torch.int64, device=dev)
+        counts = torch.empty(ws, dtype=torch.int64, device=dev)
+        all_gather_into(counts, mine)
+    else:
+        piece = hip_ops.marching_cubes_slab(slab, iso, p_lo, below, above)
+        mine = torch.tensor([piece.vertices], dtype=torch.int64, device=dev)
+        counts = torch.empty(ws, dtype=torch.int64, device=dev)
+        all_gather_into(counts, mine)
+        base = int(counts[:rank].sum())
+        parts = list(piece.emit(base - piece.ghost_vertices))
+    out = [all_gather_ragged(p.contiguous()) for p in parts]
+    return out[0], out[1], out[2], out[3], slab
+
+
 def all_reduce_gradients(parameters, bucket_bytes=64 << 20):
     """Data-parallel training: average the `.grad` of `parameters` over the ranks in
     place.  Every rank trains on its own ray batch; the two 8x256 networks have 1.19 M parameters = 4.8 MB, so

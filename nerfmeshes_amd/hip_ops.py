@@ -384,6 +384,41 @@ def np_stats(x):
     return dict(zip(("sum", "mean", "var", "std", "min", "max"), (np.float32(v) for v in out)))
 
 
+def np_stats_sharded(x_local, first, n_total, own_lo, own_hi, gather):
+    """`np_stats` of an array of `n_total` elements that is spread over several ranks, numpy's fp32 result bit for bit
+    (nm_np_chunk_sums / nm_np_finish).  `x_local` holds the global elements [first, first + x_local.numel()); this rank is
+    responsible for the 8192-element chunks that START in [own_lo, own_hi) (their elements must be among the ones it
+    holds: slabs carry a halo).  `gather(t)`: all-gather of a ragged 1-D float tensor in rank order (identity on one
+    rank).  Every rank returns the same dict."""
+    lib = _lib.load()
+    x = _dev32(x_local, name="x").reshape(-1)
+    dev = x.device
+    chunk = 8192
+    chunks = int(lib.nm_np_chunk_count(int(n_total)))
+    c_lo, c_hi = -(-int(own_lo) // chunk), min(-(-int(own_hi) // chunk), chunks)
+    m = max(c_hi - c_lo, 0)
+    out = np.zeros(6, dtype=np.float32)
+    d_out = torch.empty(8, dtype=torch.float32, device=dev)
+    mine = torch.empty(3, m + 1, dtype=torch.float32, device=dev)
+    result = {}
+    for second in (0, 1):
+        if m:
+            check(lib.nm_np_chunk_sums(_ptr(x), int(first), x.numel(), int(n_total), c_lo, c_hi, second,
+                                       float(result.get("mean", 0.0)), _ptr(mine[0]), _ptr(mine[1]), _ptr(mine[2]), _stream()),
+                  "nm_np_chunk_sums")
+        rows = [gather(mine[r, :m].contiguous()) for r in range(1 if second else 3)]
+        if rows[0].numel() != chunks:
+            raise RuntimeError(f"np_stats_sharded: the ranks cover {rows[0].numel()} of {chunks} chunks")
+        check(lib.nm_np_finish(_ptr(rows[0]), _ptr(rows[1]) if not second else None, _ptr(rows[2]) if not second else None,
+                               chunks, int(n_total), second, _ptr(d_out), out.ctypes.data_as(_lib.c_float_p), _stream()),
+              "nm_np_finish")
+        if not second:
+            result.update(sum=np.float32(out[0]), mean=np.float32(out[1]), min=np.float32(out[4]), max=np.float32(out[5]))
+        else:
+            result.update(var=np.float32(out[2]), std=np.float32(out[3]))
+    return result
+
+
 def marching_cubes(volume, level):
     """skimage.measure.marching_cubes(volume, level) on the GPU (nm_mc_count + nm_mc_emit).
     volume: (n0,n1,n2) fp32 CUDA tensor.  Returns (verts (V,3) f32, faces (F,3) i32, normals (V,3) f32,

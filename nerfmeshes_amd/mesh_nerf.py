@@ -95,8 +95,55 @@ def extract_iso_level(density, args):
     return iso_value
 
 
+def extract_iso_level_sharded(slab, first_plane, own_lo, own_hi, nums, args):
+    """`extract_iso_level` of a grid that lives in slabs on several ranks: numpy's fp32 statistics of the WHOLE grid from
+    per-rank chunk sums (hip_ops.np_stats_sharded), so that every rank gets the single-GPU level bit for bit."""
+    from . import dist as nd
+    n_total = nums[0] * nums[1] * nums[2]
+    plane = nums[1] * nums[2]
+    dev = slab.device if slab is not None else torch.device("cuda", torch.cuda.current_device())
+    if plane < 8192:
+        # numpy's 8192-element chunks are wider than the one-plane halo: a grid this small is simply assembled
+        own = slab.reshape(-1)[own_lo - first_plane * plane:own_hi - first_plane * plane] if slab is not None else torch.empty(0, device=dev)
+        st = hip_ops.np_stats(nd.all_gather_ragged(own.contiguous()))
+    else:
+        x = slab if slab is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+        st = hip_ops.np_stats_sharded(x, first_plane * plane, n_total, own_lo, own_hi, nd.all_gather_ragged)
+    iso_value = min(max(args.iso_level, st["min"] + st["std"]), st["max"] - st["std"])
+    print(f"Min density {st['min']}, Max density: {st['max']}, Mean density {st['mean']}")
+    print(f"Querying based on iso level: {iso_value}")
+    return iso_value, st
+
+
 def extract_geometry(model, device, args):
-    """mesh_nerf.py:68-92 -> (vertices (V,3) f32, triangles (F,3) i32, normals (V,3) f32, density grid)."""
+    """mesh_nerf.py:68-92 -> (vertices (V,3) f32, triangles (F,3) i32, normals (V,3) f32, density grid).
+    Under torch.distributed the default is `--gather triangles`: every rank meshes its own slab of cube layers and only
+    the triangles travel (dist.marching_cubes_sharded; the 4th value is then the rank's own slab of the grid);
+    `--gather grid` assembles the density grid on every rank first (extract_density) and meshes it redundantly."""
+    from . import dist as nd
+    rank, world = nd.world()
+    if world > 1 and getattr(args, "gather", "triangles") == "triangles":
+        nums = _nums(args.res)
+        net = model.get_model().hip()
+        ax = _axes(args, nums, device)
+        plane = nums[1] * nums[2]
+        stats = {}
+
+        def iso_fn(slab, p_lo, own_lo, own_hi):
+            iso, st = extract_iso_level_sharded(slab, p_lo, own_lo, own_hi, nums, args)
+            stats.update(st)
+            return iso
+
+        vertices, triangles, normals, _, slab = nd.marching_cubes_sharded(
+            lambda p_lo, p_hi: net.grid_query(ax[0], ax[1], ax[2], first=p_lo * plane, count=(p_hi - p_lo) * plane, density_only=True),
+            *nums, iso_fn)
+        if vertices.shape[0] == 0:              # skimage's two errors, in its order (see hip_ops.marching_cubes)
+            iso = min(max(args.iso_level, stats["min"] + stats["std"]), stats["max"] - stats["std"])
+            if iso < stats["min"] or iso > stats["max"]:
+                raise ValueError("Surface level must be within volume data range.")
+            raise RuntimeError("No surface found at the given iso value.")
+        vertices = args.limit * (vertices / (args.res / 2.0) - 1.0)
+        return vertices, triangles, normals, slab
     density = extract_density(model, args, device, args.res)
     iso_value = extract_iso_level(density, args)
     vertices, triangles, normals, _ = hip_ops.marching_cubes(density, iso_value)
@@ -123,9 +170,12 @@ def export_marching_cubes(model, args, cfg, device):
     else:
         print("Generating mesh geometry...")
         vertices, triangles, normals, density = extract_geometry(model, device, args)
-        if (cache_new or args.override_cache_mesh) and nd.world()[0] == 0:
-            torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(), density.cpu().numpy()), cache_path)
-            print(f"Cached mesh geometry saved to {cache_path}")
+        if cache_new or args.override_cache_mesh:
+            if nd.world()[1] > 1 and density.shape[0] != _nums(args.res)[0]:
+                density = extract_density(model, args, device, args.res)     # the cache holds the whole grid
+            if nd.world()[0] == 0:
+                torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(), density.cpu().numpy()), cache_path)
+                print(f"Cached mesh geometry saved to {cache_path}")
 
     # Appearance: one query per vertex.  Vertices are independent, so under torch.distributed every rank queries a
     # contiguous range of them and one ragged all-gather assembles the (V,3) colours; rank 0 writes the file.
@@ -171,6 +221,9 @@ def build_parser():
     p.add_argument("--use-cached-mesh", action="store_true", default=False)
     p.add_argument("--override-cache-mesh", action="store_true", default=False)
     p.add_argument("--cache-name", type=str, default="mesh_cache.pt")
+    p.add_argument("--gather", choices=("triangles", "grid"), default="triangles",
+                   help="(addition, multi-GPU) what travels between the ranks: the emitted triangles of per-slab marching "
+                        "cubes (default) or the density grid")
     return p
 
 

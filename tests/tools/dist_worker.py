@@ -53,21 +53,26 @@ def model_level_checks(rank, world, dev):
     assert len(ln) == 3 and all(float(a) == float(b) for a, b in zip(l1, ln)) and float(t1) == float(tn), "eval losses differ"
 
     # (2) mesh_nerf: slab-sharded density grid -> marching cubes -> vertex-sharded appearance re-query -> OBJ on rank 0
+    # both exchange strategies: per-slab marching cubes + all-gather of the triangles (default), and the all-gathered grid;
+    # res 44: planes narrower than numpy's 8192-element chunks (statistics from the assembled grid), res 100: the
+    # chunk-sum path; every variant must reproduce the 1-rank mesh bit for bit, vertex numbering included
     out = {}
-    for tag in ("n", "1"):
+    for tag, res, gather in (("n", "44", "triangles"), ("g", "44", "grid"), ("1", "44", "triangles"),
+                             ("N", "100", "triangles"), ("I", "100", "triangles")):
         d = tempfile.mkdtemp(prefix=f"nm_dist_{rank}_{tag}_")
-        args = mesh_nerf.build_parser().parse_args(["--res", "44", "--save-dir", d, "--view-disparity-max-bound", "1.0",
-                                                    "--iso-level", "32", "--batch-size", "4096"])
+        args = mesh_nerf.build_parser().parse_args(["--res", res, "--save-dir", d, "--view-disparity-max-bound", "1.0",
+                                                    "--iso-level", "32", "--batch-size", "4096", "--gather", gather])
         with torch.no_grad(), quiet:
             run = lambda: mesh_nerf.export_marching_cubes(model, args, model.cfg, dev)   # noqa: E731
-            out[tag] = (run() if tag == "n" else single_rank(run)) + (d,)
-    for a, b in zip(out["n"][:3], out["1"][:3]):
-        assert torch.equal(a, b), "sharded mesh geometry differs from the 1-rank mesh"
-    assert (out["n"][3] == out["1"][3]).all() and out["n"][3].shape[0] == out["n"][0].shape[0], "sharded vertex colours differ"
-    if rank == 0:
-        assert open(os.path.join(out["n"][4], "mesh.obj"), "rb").read() == open(os.path.join(out["1"][4], "mesh.obj"), "rb").read()
-    else:
-        assert not os.path.exists(os.path.join(out["n"][4], "mesh.obj")), "only rank 0 writes the OBJ"
+            out[tag] = (single_rank(run) if tag in "1I" else run()) + (d,)
+    for multi, single in (("n", "1"), ("g", "1"), ("N", "I")):
+        for a, b in zip(out[multi][:3], out[single][:3]):
+            assert a.shape == b.shape and torch.equal(a, b), f"sharded mesh ({multi}) differs from the 1-rank mesh"
+        assert (out[multi][3] == out[single][3]).all() and out[multi][3].shape[0] == out[multi][0].shape[0], "sharded vertex colours differ"
+        if rank == 0:
+            assert open(os.path.join(out[multi][4], "mesh.obj"), "rb").read() == open(os.path.join(out[single][4], "mesh.obj"), "rb").read()
+        else:
+            assert not os.path.exists(os.path.join(out[multi][4], "mesh.obj")), "only rank 0 writes the OBJ"
 
     # (3) training: every rank draws its own rays; the all-reduced gradients are the mean of the ranks' own, and the
     # replicas stay identical after the optimizer step
@@ -93,7 +98,7 @@ def model_level_checks(rank, world, dev):
     flat = torch.cat([p.detach().reshape(-1) for p in params])
     copies = nd.all_gather_rows(flat[None].contiguous(), [1] * world)
     assert all(torch.equal(copies[0], copies[r]) for r in range(world)), "replicas diverged after the optimizer step"
-    return int(out["n"][0].shape[0])
+    return int(out["N"][0].shape[0])
 
 
 def main():
