@@ -208,22 +208,51 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
     total_flops = res ** 3 * fine.flops_per_sample(density_only=True)
     out = {
         "workload": f"mesh_nerf --res {res} --limit {limit} --iso-level {iso_request}: density grid + marching cubes, "
-                    + (f"axis-0 slabs over {world} ranks + all-gather of the grid, marching cubes on every rank" if world > 1 else "1 GPU"),
+                    + (f"{world} ranks" if world > 1 else "1 GPU"),
         "grid_query": {"points": res ** 3, "ms": g_wall * 1e3, "planes_per_rank": [c // plane for c in counts],
                        "algorithmic_flops_per_point": fine.flops_per_sample(density_only=True),
                        "roofline": {"bound": "mfma", "achieved": total_flops / g_wall / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS * world,
                                     "unit": "TFLOP/s", "frac": total_flops / g_wall / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
                                     "frac_per_rank": _per_rank(frac_own, dev, world, use_dist),
                                     "note": "whole-job: all ranks' points / slowest rank's wall time, peak x ranks; per rank: own slab / own kernel time"}},
-        "all_gather": {"ms": a_wall * 1e3, "bytes_total": vol_bytes, "GBps_per_rank_received": (vol_bytes * (world - 1) / world) / a_wall / 1e9 if a_wall else None},
         "marching_cubes": {"iso": iso, "vertices": int(v.shape[0]), "faces": int(f.shape[0]), "ms_min": m_min, "ms_avg": m_avg,
                            "algorithmic_bytes": vol_bytes,
                            "roofline": {"bound": "hbm", "achieved": vol_bytes / (m_min * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": vol_bytes / (m_min * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                           "note": "whole nm_mc_count + nm_mc_emit call incl. workspace allocation and the host sync"},
-        "ms_total": g_wall * 1e3 + a_wall * 1e3 + m_min,
-        "all_gather_share_of_total": a_wall * 1e3 / (g_wall * 1e3 + a_wall * 1e3 + m_min),
+                           "note": "whole nm_mc_count + nm_mc_emit call on the full grid incl. workspace allocation and the host sync"},
     }
+    if world > 1:
+        # The two exchange strategies of the sharded script, each end to end (grid query + statistics + marching cubes +
+        # collectives; max over ranks):
+        #   "grid"       axis-0 slabs of the grid all-gathered, marching cubes on the whole grid on every rank;
+        #   "triangles"  (mesh_nerf's default) every rank meshes its own cube layers (+ 2-3 recomputed ghost planes), only the
+        #                vertices / faces / normals / values are all-gathered.
+        from nerfmeshes_amd import mesh_nerf
+
+        class _Model:
+            @staticmethod
+            def get_model():
+                class _N:
+                    hip = staticmethod(lambda: fine)
+                return _N
+
+        def run(gather):
+            args = mesh_nerf.build_parser().parse_args(["--res", str(res), "--limit", str(limit), "--iso-level", str(iso_request), "--gather", gather])
+            with contextlib.redirect_stdout(io.StringIO()):
+                return mesh_nerf.extract_geometry(_Model, dev, args)
+
+        strategies = {}
+        for gather in ("grid", "triangles"):
+            run(gather)
+            wall, (gv, gf, gn, _) = _wall_max(lambda: run(gather), dev, use_dist)
+            same = bool(torch.equal(gf, f) and torch.equal(gn, n) and gv.shape == v.shape)
+            strategies[gather] = {"ms_end_to_end": wall * 1e3, "faces_and_normals_equal_single_grid_mesh": same}
+        mesh_bytes = int(v.numel() * 4 + f.numel() * 4 + n.numel() * 4 + val.numel() * 4)
+        out["sharded"] = {"strategies": strategies, "default": "triangles",
+                          "all_gather_of_the_grid": {"ms": a_wall * 1e3, "bytes_total": vol_bytes,
+                                                     "GBps_per_rank_received": (vol_bytes * (world - 1) / world) / a_wall / 1e9 if a_wall else None},
+                          "all_gather_of_the_triangles": {"bytes_total": mesh_bytes},
+                          "grid_gather_share_of_grid_strategy": a_wall * 1e3 / strategies["grid"]["ms_end_to_end"]}
     if rank != 0:
         return out
     # ---- CPU side: the checker (every N) and the baselines (N = 1 only)

@@ -101,7 +101,11 @@ def test_bench_two_ranks_on_one_gpu_carries_the_sharded_objects(mode):
     assert line["config"]["rays_per_step_per_rank"] == (320000 if mode == "strong" else 640000)
     mesh, buff = line["mesh"], line["buff"]
     assert mesh["grid_query"]["planes_per_rank"] == [60, 60] and len(mesh["grid_query"]["roofline"]["frac_per_rank"]) == 2
-    assert mesh["all_gather"]["ms"] > 0 and mesh["all_gather"]["bytes_total"] == 120 ** 3 * 4
+    sh = mesh["sharded"]
+    assert sh["all_gather_of_the_grid"]["ms"] > 0 and sh["all_gather_of_the_grid"]["bytes_total"] == 120 ** 3 * 4
+    assert sh["default"] == "triangles" and sh["all_gather_of_the_triangles"]["bytes_total"] < 120 ** 3 * 4
+    for strategy in ("grid", "triangles"):      # both end-to-end variants reproduce the single-grid mesh
+        assert sh["strategies"][strategy]["faces_and_normals_equal_single_grid_mesh"] is True and sh["strategies"][strategy]["ms_end_to_end"] > 0
     assert mesh["marching_cubes"]["bitwise_identical_to_oracle"] is True and mesh["marching_cubes"]["iso_equals_numpy_fp32"] is True
     assert buff["rays_per_rank"] == [95256, 95256] and len(buff["roofline"]["frac_per_rank"]) == 2 and buff["value"] > 1e4
     assert "cpu_baseline" not in line and "train" not in line            # N = 1 only
