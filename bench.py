@@ -671,6 +671,21 @@ def main():
                                          f"({threads} torch threads = fastest of 8/16/32/64/{os.cpu_count()} on this host)",
                                "speedup": value / rps}
         out["parity"] = parity.psnr_parity(fb["rgb_map"].cpu(), ref_rgb, chunk=2048)
+        # which rays exceed 1e-4, and why (oracle/parity.py::explain_outliers): the declared ill-conditioned classes only
+        err = (fb["rgb_map"].cpu() - ref_rgb).abs().max(-1).values
+        bad = torch.nonzero(err > 1e-4).reshape(-1)
+        if bad.numel():
+            from oracle import nerf_oracle as O
+            spec, rs = O.MLPSpec(**MLP_KW), O.RenderSpec(num_coarse=NUM_COARSE, num_fine=NUM_FINE)
+            db = d[idx][bad.to(dev)].contiguous()
+            rc, rf = O.render(weights, weights, spec, spec, rs, o.cpu(), db.cpu(), NEAR, FAR)
+            t_c = hip_ops.coarse_intervals(u_c, near, far, db.shape[0])
+            t_f = hip_ops.sample_pdf(t_c, hip_ops.composite(coarse.eval_rays(o, db, t_c), t_c, db)["weights"], u_f)
+            t_r = rf["t"].to(dev).contiguous()
+            on_ref = hip_ops.composite(fine.eval_rays(o, db, t_r), t_r, db)["rgb_map"]
+            why = parity.explain_outliers(err[bad], rc, rf, t_f, on_ref)
+            why.pop("unexplained_rays")
+            out["parity"]["rays_over_1e-4_explained"] = why
     cpu_legs = world == 1 and not args.no_cpu_baseline
     shard = dict(rank=rank, world=world, use_dist=use_dist and world > 1, cpu_legs=cpu_legs)
     # objects every rank takes part in (sharded at N > 1) ...

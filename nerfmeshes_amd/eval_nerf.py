@@ -35,16 +35,13 @@ def render_view(model, pose, height, width, focal, bounds, chunksize, device="cu
     rays inside the kernels from the pose (query_view); other models get get_ray_bundle's rays."""
     rgb, disp = [], []
     n = height * width
-    try_view = hasattr(model, "query_view")
+    in_kernel_rays = hasattr(model, "query_view") and model.can_query_view()   # a failing query_view is an error, not a fallback
     origin = dirs = None
     for s in range(0, n, chunksize):
         count = min(chunksize, n - s)
         out = None
-        if try_view:
-            try:
-                out = model.query_view(pose, height, width, focal, bounds, first=s, count=count)
-            except RuntimeError:
-                try_view = False
+        if in_kernel_rays:
+            out = model.query_view(pose, height, width, focal, bounds, first=s, count=count)
         if out is None:
             if dirs is None:
                 origin, dirs = hip_ops.ray_bundle(pose, height, width, focal, device=device)

@@ -93,6 +93,13 @@ class NeRFModel(BaseModel):
         coarse, fine = self.forward(ray_batch)
         return fine if fine is not None else coarse
 
+    def can_query_view(self):
+        """True when `query_view` applies: deterministic inference (no stratified jitter, no density noise, no autograd)."""
+        nerf_cfg = self.cfg.nerf.train if self.model_coarse.training else self.cfg.nerf.validation
+        vr = self.volume_renderer
+        noise_std = vr.train_radiance_field_noise_std if vr.training else vr.val_radiance_field_noise_std
+        return not (nerf_cfg.perturb or noise_std > 0.0 or self.model_coarse.needs_grad())
+
     def query_view(self, pose, height, width, focal, bounds, first=0, count=None):
         """`query` for pixels [first, first+count) of a camera view, the rays generated inside the kernels from the
         pose (nm_render_view; get_ray_bundle + cfg.dataset.use_ndc's ndc_rays): no ray buffers, no per-chunk H2D

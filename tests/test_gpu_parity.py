@@ -309,6 +309,18 @@ def test_psnr_parity_view8k(ops):
         assert par["abs_dpsnr_db"] <= 1e-4, (pre, par)
         assert par["rays_over_1e-4"] <= 0.002 * par["rays"], par       # reported, and bounded: a handful of rays
     assert float((cb["rgb_map"].cpu() - torch.from_numpy(g["coarse.rgb_map"])).abs().max()) < 1e-4
+    # every ray above 1e-4 must be one of the DECLARED ill-conditioned classes (oracle/parity.py::explain_outliers):
+    # the conditioning argument may not hide an unexplained difference
+    spec, rs = O.MLPSpec(**kw), O.RenderSpec()
+    rc, rf = O.render(w, w, spec, spec, rs, o[None].cpu(), d.cpu(), 2.0, 6.0)
+    t_c = ops.coarse_intervals(torch.linspace(0, 1, 64).cuda(), torch.tensor([2.0]), torch.tensor([6.0]), d.shape[0])
+    stage = ops.composite(mlp.eval_rays(o[None], d, t_c), t_c, d)
+    t_f = ops.sample_pdf(t_c, stage["weights"], torch.linspace(0, 1, 128).cuda())
+    on_ref = ops.composite(mlp.eval_rays(o[None], d, rf["t"].cuda().contiguous()), rf["t"].cuda().contiguous(), d)["rgb_map"]
+    err = (fb["rgb_map"].cpu() - torch.from_numpy(g["fine.rgb_map"])).abs().max(-1).values
+    why = parity.explain_outliers(err, rc, rf, t_f, on_ref)
+    print(why)
+    assert why["unexplained"] == 0, why
 
 
 def test_render_rough_scene_at_the_reference_noise_floor(ops):
