@@ -4,28 +4,33 @@
 //
 // The CPU algorithm is a sequential scan (axis0 outermost, axis2 innermost) with a per-layer vertex
 // cache; vertex ids are "order of first creation", triangle order is "cube scan order, tiling order".
-// Parallel restatement used here:
-//   1. classify   one thread per cube: corner signs -> case/config -> (face / interior tests) -> tiling row
-//                 (offset into the LUT, triangle count) and the number of vertices this cube CREATES.
-//                 An edge vertex is created by the first cube in scan order that contains the edge; every
-//                 tiling of a cube uses exactly its sign-changing edges, so ownership is a pure function of
-//                 the edge position ("no earlier cube contains it").
-//                 Sign patterns are computed by every lane (phase A, brick-shaped workgroups marching in z); the ~1 %
-//                 of cubes the surface cuts go through an LDS queue so the MC33 tests run densely (phase B).
-//                 Per-cube state: ONE byte.
-//   2. scan       exclusive prefix sums of (created vertices, triangles, active cubes) over 1024-cube tiles in
-//                 scan order (1024-tile groups scanned in parallel, then the group totals).
-//   3. compact    active cubes -> list (cube id, vertex base, triangle base), still in scan order.
-//   4. vertices   one thread per ACTIVE cube walks its tiling; every first use of an owned edge (or of the
-//                 centre vertex, edge id 12) creates vertex base+k: position (fp64 inverse-|v| interpolation
-//                 rounded to fp32, as skimage), index stored in an edge->vertex table (int32 volume per axis).
-//      faces      one thread per active cube walks its tiling again and looks the indices up; triples are
-//                 reversed ('descent').
-//   5. normals    one thread per vertex: re-plays, in scan order, the <= 4 cubes sharing its edge and
-//                 accumulates their gradient contributions in fp32 in exactly skimage's order, takes the
-//                 max of the cubes' value ranges, normalises in fp64.
+// Parallel restatement used here (round 3: everything downstream of the volume scan works on the cut cubes only, which are
+// kept in scan order from the start -- no per-cube array, nothing to clear, no global queue):
+//   1. stream     mc_classify_stream: the HBM-bound pass.  Workgroups of 8 rows x 512 voxels march up axis 0; per voxel the
+//                 only work is the sign test, whose 64 results per wavefront are a scalar mask; one wavefront per workgroup
+//                 combines the masks of a step into CUT masks (corner bits neither all 0 nor all 1) and writes them to HBM:
+//                 8 qwords per UNIT = (plane, row, x brick), units in scan order (64 B per 512 cubes).
+//   2. cut        mc_classify_cut, one wavefront per SEGMENT (7 rows of a plane, what a workgroup covers per step): the
+//                 masks become the segment's cut cubes IN SCAN ORDER (a lane owns 4 consecutive cubes; the cubes in front
+//                 of them are a population count), each gets its MC33 tests -> tiling row, triangle count, number of
+//                 vertices it CREATES (an edge vertex is created by the first cube in scan order that contains the edge:
+//                 every tiling uses exactly its sign-changing edges, so ownership is a function of the edge position);
+//                 one 32-bit entry per cut cube in the unit's slot, (vertices, triangles, cubes) per unit.
+//   3. scan       exclusive prefix sums over the units (mc_scan_groups / mc_scan_totals): ~230 k units at 480^3, not
+//                 110 M cubes.
+//   4. compact    mc_compact: cut cubes -> list (cube id | tiling row, vertex base, triangle base), still in scan order.
+//   5. vertices   mc_emit<false>: one thread per cut cube walks its tiling; every first use of an owned edge (or of the
+//                 centre vertex, edge id 12) creates vertex base+k: position (fp64 inverse-|v| interpolation rounded to
+//                 fp32, as skimage), index stored in an edge->vertex table (int32 volume per axis).
+//      faces      mc_emit<true>: walks the tiling again and looks the indices up (no volume access: the tiling row rides in
+//                 the list entry); triples are reversed ('descent').
+//   6. normals    mc_vertex_attributes, one thread per vertex: re-plays, in scan order, the <= 4 cubes sharing its edge and
+//                 accumulates their gradient contributions in fp32 in exactly skimage's order, takes the max of the cubes'
+//                 value ranges, normalises in fp64.
+// A SLAB of a larger grid (per-rank marching cubes, nm_mc_count_slab / nm_mc_emit_slab) runs the same passes with the
+// ownership rule on GLOBAL plane indices and a ghost layer on either side; see McSlab.
 // HBM-bound integer/byte work: 4 B/voxel streamed once for classification is the algorithmic traffic
-// (442 MB at 480^3); the other passes touch only the ~1 % of cubes that are active.
+// (442 MB at 480^3); the other passes touch only the ~1 % of cubes that are cut.
 #include <math.h>
 
 #include "nm_internal.h"
@@ -268,6 +273,23 @@ __device__ __forceinline__ uint32_t pack_code(int nt, int ncreated) { return (ui
 __device__ __forceinline__ int code_nt(uint32_t c) { return c & 0xf; }
 __device__ __forceinline__ int code_created(uint32_t c) { return (c >> 4) & 0xf; }
 
+// slot entry of a cut cube (32 bits): position in its brick (9) | triangles (4) | created vertices (4) | tiling row = offset into
+// MC_LUT (15: the tiling tables end below 2^15).  The tiling row is what the MC33 face / interior tests decide; carrying it
+// along means the emit passes do not repeat the tests (and the faces pass does not touch the volume at all).
+static_assert(MC_TEST3_OFF < (1 << 15), "tiling rows fit 15 bits");
+__device__ __forceinline__ uint32_t pack_entry(uint32_t xoff, int nt, int created, int off) {
+    return xoff | ((uint32_t)nt << 9) | ((uint32_t)created << 13) | ((uint32_t)off << 17);
+}
+__device__ __forceinline__ uint32_t entry_xoff(uint32_t e) { return e & 0x1ffu; }
+__device__ __forceinline__ int entry_nt(uint32_t e) { return (e >> 9) & 0xf; }
+__device__ __forceinline__ int entry_created(uint32_t e) { return (e >> 13) & 0xf; }
+__device__ __forceinline__ int entry_off(uint32_t e) { return (int)(e >> 17); }
+// active-cube ids carry the tiling row and triangle count above bit 40 (cube counts are limited to 2^40)
+constexpr int64_t MC_ID_MASK = (int64_t(1) << 40) - 1;
+__device__ __forceinline__ int64_t pack_id(int64_t id, int nt, int off) { return id | ((int64_t)off << 40) | ((int64_t)nt << 55); }
+__device__ __forceinline__ int id_off(int64_t id) { return (int)((id >> 40) & 0x7fff); }
+__device__ __forceinline__ int id_nt(int64_t id) { return (int)((id >> 55) & 0xf); }
+
 // (z, y, x) of cube `id`; 32-bit arithmetic whenever the cube count allows (64-bit division is emulated)
 __device__ __forceinline__ void cube_coords(const McDims& d, int64_t id, int& z, int& y, int& x) {
     if (d.cubes < (int64_t(1) << 31)) {
@@ -307,8 +329,9 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 }
 
 // ---- pass 1: classify ---------------------------------------------------------------------------------
-// Two kernels (round 2; round 1 did both in one 118-VGPR kernel with a 32 KB LDS queue: 4 workgroups per CU, 0.94 TB/s,
-// 1.42x over-fetch).
+// Two kernels (round 1 did both in one 118-VGPR kernel with a 32 KB LDS queue: 4 workgroups per CU, 0.94 TB/s, 1.42x
+// over-fetch; round 2 appended the cut cubes to a global queue with atomics and sorted nothing, which cost a code byte
+// per cube -- 110 MB memset + 110 MB scan -- downstream).
 //
 // (a) mc_classify_stream -- the HBM-bound part, and nothing else.  A workgroup of 1024 threads = 128 x-groups (512
 //     voxels: a whole row of the 480^3 grid) x 8 adjacent rows marches `zrun` planes up axis 0: per plane every thread
@@ -322,19 +345,17 @@ __device__ __forceinline__ int index_of(const Cube& c) {
 //     bit-parallel logic on those 64-bit masks, and ONE wavefront does it for the whole workgroup: the 16 waves leave
 //     their 4 masks in LDS (32 B each), and after the step's barrier the last wave combines the masks of every
 //     wave-row (its own row and the one above, this step and the previous one, the neighbour wave's first column)
-//     (lane = wave-row x column, 56 lanes) into cut masks with a dozen 64-bit VALU operations -- one pass.  The
-//     owners pick their cut masks up after the NEXT barrier and append the (few) cut cubes lane-parallel to an LDS
-//     staging buffer; a per-wave-row flag lets the ~90 % of wavefront rows that do not touch the surface skip that
-//     with one scalar branch.
+//     (lane = wave-row x column, 56 lanes) into cut masks with a dozen 64-bit VALU operations -- one pass -- and
+//     stores them: 8 qwords per unit (plane, row, brick), 56 lanes x 8 B per step and workgroup.  Nothing else leaves
+//     this kernel; the other 15 wavefronts only load and compare.
 //     History of this kernel at 480^3 (tests/tools/membw.hip streams the same bytes in the same workgroup shape,
 //     barrier per step included, in 76 us; this kernel with the logic removed: 97 us): 8-bit pattern assembled per
 //     cube on the VALU (~30 ops / cube) 244 us; mask logic on the scalar unit of every wave (~60 s_and / s_or per
-//     wave and step: the CU's one scalar ALU becomes the bottleneck) 154 us; one logic wave per workgroup: see
-//     DESIGN.md 3.3.
-//     The staging buffer goes to the global queue (one atomicAdd) at the end of the march, earlier only if it could
-//     overflow.  The code bytes of all other cubes are a memset.
-// (b) mc_classify_cut -- one thread per queued cube: corner pattern, the MC33 face / interior tests (fp64), the tiling
-//     row, the number of vertices the cube creates; writes that cube's code byte.
+//     wave and step: the CU's one scalar ALU becomes the bottleneck) 154 us; one logic wave per workgroup + owners
+//     appending cut cubes to an LDS staging buffer 103 us; masks only (this version) 93 us: see DESIGN.md 3.3.
+// (b) mc_classify_cut -- one wavefront per segment (7 rows of a plane x one brick): turns the 56 masks into the
+//     segment's cut cubes in scan order, runs the MC33 face / interior tests (fp64) for each, and writes one packed
+//     entry per cut cube (x offset, triangle count, vertices created, tiling row) into the unit's slot.
 constexpr int MC_ZRUN_MIN = 8;                     // planes per march: chosen per launch (mc_pick_zrun)
 constexpr int MC_GX = 128, MC_GY = 8;                               // thread grid: x-groups per row, rows (7 cube rows + halo)
 constexpr int MC_STREAM_THREADS = MC_GX * MC_GY;
@@ -503,7 +524,7 @@ __device__ __forceinline__ int mc_segment_row(const McSegment& s, uint32_t e, ui
 }
 
 // (b) mc_classify_cut: the cut masks of a segment -> its cut cubes in scan order -> their MC33 tests.  Per unit, the slot
-// receives one entry per cut cube (position in the brick | triangles << 16 | created vertices << 20) and unit_sums the
+// receives one entry per cut cube (pack_entry: position in the brick | triangles | created vertices | tiling row) and unit_sums the
 // unit's (created vertices, triangles, cut cubes).  Every unit is written (zeros for the untouched ones).
 //   Lane L of a half-row holds cubes 4 L .. 4 L + 3, mask j bit L = cube 4 L + j: the number of cut cubes in front of a
 //   lane's four is the population count of the four masks below bit L, so a wave lists a row in cube order with 8 mbcnt.
@@ -572,7 +593,7 @@ __global__ __launch_bounds__(256) void mc_classify_cut(const float* __restrict__
         int off, nt;
         select_tiling(c, index_of(c), off, nt);
         const int created = count_created(off, nt, z + zg0, y, x);
-        slots[(sg.unit0 + t * sg.ustride) * cap + k] = xoff | (pack_code(nt, created) << 16);
+        slots[(sg.unit0 + t * sg.ustride) * cap + k] = pack_entry(xoff, nt, created, off);
         atomicAdd(&s_acc[wave][t][0], (uint32_t)created);
         atomicAdd(&s_acc[wave][t][1], (uint32_t)nt);
     }
@@ -681,8 +702,7 @@ __global__ __launch_bounds__(256) void mc_compact(McDims d, const uint32_t* __re
             t = mc_segment_row(sg, e, k);
             ent = slots[(sg.unit0 + t * sg.ustride) * cap + k];
         }
-        const uint32_t code = ent >> 16;
-        uint32_t iv = code_created(code), it = code_nt(code);
+        uint32_t iv = live ? entry_created(ent) : 0u, it = live ? entry_nt(ent) : 0u;
         const uint32_t ov = iv, ot = it;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t pv = __shfl_up(iv, o), pt = __shfl_up(it, o);
@@ -695,7 +715,7 @@ __global__ __launch_bounds__(256) void mc_compact(McDims d, const uint32_t* __re
             const int64_t unit = sg.unit0 + t * sg.ustride;
             const uint4 up = unit_prefix[unit], gp = group_prefix[unit >> 10];
             McActive a;
-            a.id = ((int64_t)sg.z * d.c1 + (sg.r0 + t)) * d.c2 + (sg.xb * MC_UNIT + (int)(ent & 0xffffu));
+            a.id = pack_id(((int64_t)sg.z * d.c1 + (sg.r0 + t)) * d.c2 + (sg.xb * MC_UNIT + (int)entry_xoff(ent)), entry_nt(ent), entry_off(ent));
             a.vbase = gp.x + up.x + (ev - s_first[wave][t][0]);
             a.tbase = gp.y + up.y + (et - s_first[wave][t][1]);
             list[gp.z + up.z + k] = a;
@@ -726,12 +746,11 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
     if (a >= (int64_t)totals[2]) return;     // number of active cubes, left on the device by the scan
     const McActive ent = list[a];
     int z, y, x;
-    cube_coords(d, ent.id, z, y, x);
-    Cube c;
-    load_cube(vol, d, z, y, x, iso, c);
-    int off, nt;
-    select_tiling(c, index_of(c), off, nt);
+    cube_coords(d, ent.id & MC_ID_MASK, z, y, x);
+    const int off = id_off(ent.id), nt = id_nt(ent.id);        // the tiling row mc_classify_cut chose
     if constexpr (!FACES) {
+        Cube c;
+        load_cube(vol, d, z, y, x, iso, c);
         unsigned seen = 0;
         uint32_t next = ent.vbase;
         for (int i = 0; i < 3 * nt; ++i) {
@@ -835,13 +854,24 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
     const int64_t home = vertex_cube[vid];
     const int e_home = vertex_edge[vid];
     int hz, hy, hx;
-    cube_coords(dc, home, hz, hy, hx);      // ids count the classified layers; the neighbours may lie in the ghost layer above (d)
+    cube_coords(dc, home & MC_ID_MASK, hz, hy, hx);      // ids count the classified layers; the neighbours may lie in the ghost layer above (d)
     float nx = 0.0f, ny = 0.0f, nz = 0.0f, value = 0.0f;
     int ncubes = 1, axis = 0, lz = 0, ly = 0, lx = 0;
     if (e_home != 12) {
         axis = MC_EDGE_AXIS[e_home];
         lz = hz + MC_EDGE_LO[e_home][0]; ly = hy + MC_EDGE_LO[e_home][1]; lx = hx + MC_EDGE_LO[e_home][2];
         ncubes = 4;
+    }
+    // `strength` of the edge's two ends, 1 / (eps + |v|) rounded to a C float as in skimage: the same two voxels in every
+    // cube that shares the edge (a cube may run the edge the other way round), so the two fp64 divisions are done once per
+    // vertex instead of once per cube
+    float s_lo = 0.0f, s_hi = 0.0f;
+    if (e_home != 12) {
+        const int64_t s1v = d.n2, s0v = (int64_t)d.n1 * d.n2;
+        const float* pl = vol + (int64_t)lz * s0v + (int64_t)ly * s1v + lx;
+        const double v_lo = (double)pl[0] - iso, v_hi = (double)pl[axis == 0 ? 1 : (axis == 1 ? s1v : s0v)] - iso;
+        s_lo = (float)(1.0 / (SK_EPS + fabs(v_lo)));
+        s_hi = (float)(1.0 / (SK_EPS + fabs(v_hi)));
     }
     for (int k = 0; k < ncubes; ++k) {
         int z, y, x, e;
@@ -875,8 +905,6 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
             (void)sx;
             gx = (float)sz; gy = (float)sy; gz = 0.0f;   // skimage's centre gradient: (sum w*gz, sum w*gy, 0)
         } else {
-            const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;
-            const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4;
             const int i1 = bitwise_index(MC_EDGE_A[e]), i2 = bitwise_index(MC_EDGE_B[e]);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
@@ -885,8 +913,9 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
                     ga[a] = i1 == q ? g[3 * q + a] : ga[a];
                     gb[a] = i2 == q ? g[3 * q + a] : gb[a];
                 }
-            s1 = (float)(1.0 / (SK_EPS + fabs(pick(c, ka))));   // `strength` is a C float in skimage
-            s2 = (float)(1.0 / (SK_EPS + fabs(pick(c, kb))));
+            const bool a_is_lo = i1 == bitwise_index(MC_EDGE_LO[e]);     // end A of the cube's local edge = the edge's lower voxel?
+            s1 = a_is_lo ? s_lo : s_hi;
+            s2 = a_is_lo ? s_hi : s_lo;
         }
         bool referenced = false;
         for (int i = 0; i < 3 * nt; ++i) {
