@@ -32,6 +32,7 @@
 // HBM-bound integer/byte work: 4 B/voxel streamed once for classification is the algorithmic traffic
 // (442 MB at 480^3); the other passes touch only the ~1 % of cubes that are cut.
 #include <math.h>
+#include <mutex>
 
 #include "nm_internal.h"
 #include "mc_luts.h"
@@ -227,43 +228,84 @@ __device__ __forceinline__ void select_tiling(const Cube& c, int index, int& off
 }
 
 // ---- edge bookkeeping ------------------------------------------------------------------------------
-// corner offsets (dz,dy,dx) of the two ends of edge e, Lewiner numbering
-__device__ __constant__ signed char MC_EDGE_A[12][3] = {{0,0,0},{0,0,1},{0,1,1},{0,1,0},{1,0,0},{1,0,1},{1,1,1},{1,1,0},{0,0,0},{0,0,1},{0,1,1},{0,1,0}};
-__device__ __constant__ signed char MC_EDGE_B[12][3] = {{0,0,1},{0,1,1},{0,1,0},{0,0,0},{1,0,1},{1,1,1},{1,1,0},{1,0,0},{1,0,0},{1,0,1},{1,1,1},{1,1,0}};
-// axis of the edge (0 = x / axis2, 1 = y / axis1, 2 = z / axis0) and its lower corner offset (dz,dy,dx)
-__device__ __constant__ signed char MC_EDGE_AXIS[12] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2};
-__device__ __constant__ signed char MC_EDGE_LO[12][3] = {{0,0,0},{0,0,1},{0,1,0},{0,0,0},{1,0,0},{1,0,1},{1,1,0},{1,0,0},{0,0,0},{0,0,1},{0,1,1},{0,1,0}};
-// Lewiner corner -> skimage's "bitwise" corner index dz*4+dy*2+dx used for vv[] / vg[]
-__device__ __forceinline__ int bitwise_index(const signed char* o) { return o[0] * 4 + o[1] * 2 + o[2]; }
+// Per-edge constants as packed immediates (a table in memory costs a dependent load wherever the edge id is a run-time
+// value, and every pass over the cut cubes is a chain of such loads): corners are "bitwise" indices dz*4 + dy*2 + dx
+// (skimage's vv[] / vg[] numbering), 3 bits per edge; the axis (0 = x / axis2, 1 = y / axis1, 2 = z / axis0) 2 bits.
+constexpr int MC_EDGE_A_[12] = {0, 1, 3, 2, 4, 5, 7, 6, 0, 1, 3, 2};      // end A of edge e (Lewiner numbering)
+constexpr int MC_EDGE_B_[12] = {1, 3, 2, 0, 5, 7, 6, 4, 4, 5, 7, 6};      // end B
+constexpr int MC_EDGE_LO_[12] = {0, 1, 2, 0, 4, 5, 6, 4, 0, 1, 3, 2};     // the edge's lower corner (the voxel that names the edge)
+constexpr int MC_EDGE_AXIS_[12] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2};
+constexpr uint64_t mc_pack(const int (&v)[12], int bits) {
+    uint64_t r = 0;
+    for (int e = 0; e < 12; ++e) r |= (uint64_t)v[e] << (bits * e);
+    return r;
+}
+constexpr uint64_t MC_PACK_A = mc_pack(MC_EDGE_A_, 3), MC_PACK_B = mc_pack(MC_EDGE_B_, 3), MC_PACK_LO = mc_pack(MC_EDGE_LO_, 3);
+constexpr uint32_t MC_PACK_AXIS = (uint32_t)mc_pack(MC_EDGE_AXIS_, 2);
+__device__ __forceinline__ int edge_a(int e) { return (int)((MC_PACK_A >> (3 * e)) & 7u); }
+__device__ __forceinline__ int edge_b(int e) { return (int)((MC_PACK_B >> (3 * e)) & 7u); }
+__device__ __forceinline__ int edge_lo(int e) { return (int)((MC_PACK_LO >> (3 * e)) & 7u); }
+__device__ __forceinline__ int edge_axis(int e) { return (int)((MC_PACK_AXIS >> (2 * e)) & 3u); }
 
-// this cube creates the vertex on edge e iff no cube earlier in scan order contains that edge
-__device__ __forceinline__ bool owns_edge(int e, int z, int y, int x) {
-    switch (e) {
-        case 0: return y == 0 && z == 0;
-        case 2: return z == 0;
-        case 4: return y == 0;
-        case 6: return true;
-        case 3: return x == 0 && z == 0;
-        case 1: return z == 0;
-        case 7: return x == 0;
-        case 5: return true;
-        case 8: return x == 0 && y == 0;
-        case 9: return y == 0;
-        case 11: return x == 0;
-        default: return true;   // 10, and the centre vertex (12)
-    }
+// this cube creates the vertex on edge e iff no cube earlier in scan order contains that edge: bit e of the mask
+// (bit 12 = the centre vertex of the MC33 tilings that have one)
+__device__ __forceinline__ uint32_t owned_edges(int z, int y, int x) {
+    const uint32_t z0 = z == 0, y0 = y == 0, x0 = x == 0;
+    return ((y0 & z0) << 0) | (z0 << 1) | (z0 << 2) | ((x0 & z0) << 3) | (y0 << 4) | (1u << 5) | (1u << 6) | (x0 << 7) |
+           ((x0 & y0) << 8) | (y0 << 9) | (1u << 10) | (x0 << 11) | (1u << 12);
 }
 
-__device__ __forceinline__ int count_created(int offset, int nt, int z, int y, int x) {
-    unsigned seen = 0;
-    int n = 0;
-    for (int i = 0; i < 3 * nt; ++i) {
-        const int e = lut(offset + i);
-        if (seen & (1u << e)) continue;
-        seen |= 1u << e;
-        n += owns_edge(e, z, y, x) ? 1 : 0;
+// A tiling row (3 bytes per triangle, <= 12 triangles) in registers.  The rows are walked byte by byte in every pass
+// over the cut cubes; fetched one byte per step that walk is a chain of 3 nt dependent loads per lane (30 us per
+// wavefront in the faces pass, PMC round 3) -- fetched whole it is one round trip (unaligned dword loads; bytes past
+// the row belong to the next rows of MC_LUT and are never looked at).
+struct TilingRow { uint32_t w[9]; };
+static_assert(MC_TEST3_OFF + 36 <= MC_LUT_SIZE, "row loads stay inside MC_LUT (tiling rows end where the test tables begin)");
+__device__ __forceinline__ void load_row(int off, int nt, TilingRow& r) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) __builtin_memcpy(&r.w[q], MC_LUT + off + 4 * q, 4);
+#pragma unroll
+    for (int q = 3; q < 9; ++q) r.w[q] = 0u;
+    if (nt > 4) {
+#pragma unroll
+        for (int q = 3; q < 9; ++q) __builtin_memcpy(&r.w[q], MC_LUT + off + 4 * q, 4);
     }
-    return n;
+}
+__device__ __forceinline__ int row_edge(const TilingRow& r, int i) { return (int)((r.w[i >> 2] >> (8 * (i & 3))) & 0xffu); }   // i: compile-time
+
+// edges the row uses (bit mask)
+__device__ __forceinline__ uint32_t row_edges_used(const TilingRow& r, int nt) {
+    uint32_t used = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) used |= i < 3 * nt ? 1u << (row_edge(r, i) & 31) : 0u;
+    if (nt > 4) {
+#pragma unroll
+        for (int i = 12; i < 36; ++i) used |= i < 3 * nt ? 1u << (row_edge(r, i) & 31) : 0u;
+    }
+    return used;
+}
+
+// the vertices a cube creates, in creation order = order of first use in its tiling: 4 bits per edge id, `n` of them
+__device__ __forceinline__ uint64_t row_created(const TilingRow& r, int nt, uint32_t owned, int& n) {
+    uint32_t seen = 0;
+    uint64_t list = 0;
+    int cnt = 0;
+    auto step = [&](int i) {
+        const int e = row_edge(r, i) & 15;
+        const uint32_t bit = 1u << e;
+        const bool take = i < 3 * nt && !(seen & bit) && (owned & bit);
+        list |= take ? (uint64_t)e << (4 * cnt) : 0ull;
+        cnt += take ? 1 : 0;
+        seen |= bit;
+    };
+#pragma unroll
+    for (int i = 0; i < 12; ++i) step(i);
+    if (nt > 4) {
+#pragma unroll
+        for (int i = 12; i < 36; ++i) step(i);
+    }
+    n = cnt;
+    return list;
 }
 
 // code byte per cube: low nibble = triangles (<= 12), high nibble = vertices this cube creates (<= 13).
@@ -592,7 +634,9 @@ __global__ __launch_bounds__(256) void mc_classify_cut(const float* __restrict__
         load_cube(vol, d, z, y, x, iso, c);
         int off, nt;
         select_tiling(c, index_of(c), off, nt);
-        const int created = count_created(off, nt, z + zg0, y, x);
+        TilingRow row;
+        load_row(off, nt, row);
+        const int created = __popc(row_edges_used(row, nt) & owned_edges(z + zg0, y, x));
         slots[(sg.unit0 + t * sg.ustride) * cap + k] = pack_entry(xoff, nt, created, off);
         atomicAdd(&s_acc[wave][t][0], (uint32_t)created);
         atomicAdd(&s_acc[wave][t][1], (uint32_t)nt);
@@ -737,6 +781,26 @@ struct McSlab {
     int64_t index_base;
 };
 
+// two triangles of a cube's tiling (2 TP, 2 TP + 1): six table reads in flight together, two 12-byte rows out
+template <int TP>
+__device__ __forceinline__ void emit_pair(const TilingRow& row, int nt, int centre, int32_t ib, int z, int y, int x,
+                                          const McDims& d, const McOut& out, int32_t* f) {
+    const bool two = 2 * TP + 1 < nt;
+    int idx[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int e = (two || j < 3) ? row_edge(row, 6 * TP + j) : row_edge(row, 6 * TP + (j < 3 ? j : j - 3));
+        const int ee = e == 12 ? 0 : (e & 15), lo = edge_lo(ee), axis = edge_axis(ee);
+        const int64_t vox = ((int64_t)(z + (lo >> 2)) * d.n1 + (y + ((lo >> 1) & 1))) * d.n2 + (x + (lo & 1));
+        const int32_t* table = axis == 0 ? out.edge_vertex[0] : (axis == 1 ? out.edge_vertex[1] : out.edge_vertex[2]);
+        const int v = table[vox];
+        idx[j] = e == 12 ? centre : v;
+    }
+    int32_t* g = f + 6 * TP;                      // gradient_direction='descent' reverses each triple
+    g[0] = idx[2] + ib; g[1] = idx[1] + ib; g[2] = idx[0] + ib;
+    if (two) { g[3] = idx[5] + ib; g[4] = idx[4] + ib; g[5] = idx[3] + ib; }
+}
+
 template <bool FACES>
 __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, McDims d, double iso, McSlab sl,
                                                const McActive* __restrict__ list, const uint32_t* __restrict__ totals,
@@ -748,79 +812,67 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
     int z, y, x;
     cube_coords(d, ent.id & MC_ID_MASK, z, y, x);
     const int off = id_off(ent.id), nt = id_nt(ent.id);        // the tiling row mc_classify_cut chose
+    TilingRow row;
+    load_row(off, nt, row);
+    int ncreated;
+    const uint64_t created = row_created(row, nt, owned_edges(z + sl.zg0, y, x), ncreated);
     if constexpr (!FACES) {
         Cube c;
         load_cube(vol, d, z, y, x, iso, c);
-        unsigned seen = 0;
-        uint32_t next = ent.vbase;
-        for (int i = 0; i < 3 * nt; ++i) {
-            const int e = lut(off + i);
-            if (seen & (1u << e)) continue;
-            seen |= 1u << e;
-            if (!owns_edge(e, z + sl.zg0, y, x)) continue;
+        for (int k = 0; k < ncreated; ++k) {
+            const int e = (int)((created >> (4 * k)) & 15u);
+            const uint32_t next = ent.vbase + (uint32_t)k;
             double px, py, pz;
             if (e == 12) {
                 double fx = 0, fy = 0, fz = 0, ff = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double w = 1.0 / (SK_EPS + fabs(c.v[k]));
-                    const int cx = (k == 1 || k == 2 || k == 5 || k == 6), cy = (k == 2 || k == 3 || k == 6 || k == 7), cz = k >> 2;
+                for (int q = 0; q < 8; ++q) {
+                    const double w = 1.0 / (SK_EPS + fabs(c.v[q]));
+                    const int cx = (q == 1 || q == 2 || q == 5 || q == 6), cy = (q == 2 || q == 3 || q == 6 || q == 7), cz = q >> 2;
                     fx += (double)cx * w; fy += (double)cy * w; fz += (double)cz * w; ff += w;
                 }
                 px = x + fx / ff; py = y + fy / ff; pz = (z + sl.zg0) + fz / ff;
             } else {
-                const signed char* ea = MC_EDGE_A[e];
-                const signed char* eb = MC_EDGE_B[e];
+                const int ea = edge_a(e), eb = edge_b(e), lo = edge_lo(e);    // dz*4 + dy*2 + dx
                 const int ka = e < 8 ? ((e & 3)) + (e & 4) : e - 8;           // Lewiner corner of end A
                 const int kb = e < 8 ? (((e & 3) + 1) & 3) + (e & 4) : e - 4; // Lewiner corner of end B
                 const double w1 = 1.0 / (SK_EPS + fabs(pick(c, ka))), w2 = 1.0 / (SK_EPS + fabs(pick(c, kb)));
                 double fx = 0, fy = 0, fz = 0, ff = 0;
-                fx += (double)ea[2] * w1; fy += (double)ea[1] * w1; fz += (double)ea[0] * w1; ff += w1;
-                fx += (double)eb[2] * w2; fy += (double)eb[1] * w2; fz += (double)eb[0] * w2; ff += w2;
+                fx += (double)(ea & 1) * w1; fy += (double)((ea >> 1) & 1) * w1; fz += (double)(ea >> 2) * w1; ff += w1;
+                fx += (double)(eb & 1) * w2; fy += (double)((eb >> 1) & 1) * w2; fz += (double)(eb >> 2) * w2; ff += w2;
                 px = x + fx / ff; py = y + fy / ff; pz = (z + sl.zg0) + fz / ff;
-                const signed char* lo = MC_EDGE_LO[e];
-                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
-                out.edge_vertex[MC_EDGE_AXIS[e]][vox] = (int32_t)next;
+                const int64_t vox = ((int64_t)(z + (lo >> 2)) * d.n1 + (y + ((lo >> 1) & 1))) * d.n2 + (x + (lo & 1));
+                const int axis = edge_axis(e);
+                int32_t* table = axis == 0 ? out.edge_vertex[0] : (axis == 1 ? out.edge_vertex[1] : out.edge_vertex[2]);
+                table[vox] = (int32_t)next;
             }
             if (z >= sl.ghost) {
-                const int64_t row = (int64_t)next - sl.ghost_v;
+                const int64_t r = (int64_t)next - sl.ghost_v;
                 // wrapper: vertices flipped to (axis0, axis1, axis2) = (z, y, x)
-                out.verts[3 * row] = (float)pz;
-                out.verts[3 * row + 1] = (float)py;
-                out.verts[3 * row + 2] = (float)px;
-                vertex_cube[row] = ent.id;
-                vertex_edge[row] = (int8_t)e;
+                out.verts[3 * r] = (float)pz;
+                out.verts[3 * r + 1] = (float)py;
+                out.verts[3 * r + 2] = (float)px;
+                vertex_cube[r] = ent.id;
+                vertex_edge[r] = (int8_t)e;
             }
-            ++next;
         }
     } else {
         if (z < sl.ghost) return;
-        // the centre vertex (if any) is created by this cube: its id = vbase + #owned first-uses before it
+        // the centre vertex (if any) is created by this cube: its id = vbase + its place in the creation order
         int centre = -1;
-        {
-            unsigned seen = 0;
-            int k = 0;
-            for (int i = 0; i < 3 * nt; ++i) {
-                const int e = lut(off + i);
-                if (seen & (1u << e)) continue;
-                seen |= 1u << e;
-                if (e == 12) { centre = (int)ent.vbase + k; break; }
-                k += owns_edge(e, z + sl.zg0, y, x) ? 1 : 0;
-            }
-        }
-        for (int t = 0; t < nt; ++t) {
-            int idx[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = lut(off + 3 * t + j);
-                if (e == 12) { idx[j] = centre; continue; }
-                const signed char* lo = MC_EDGE_LO[e];
-                const int64_t vox = ((int64_t)(z + lo[0]) * d.n1 + (y + lo[1])) * d.n2 + (x + lo[2]);
-                idx[j] = out.edge_vertex[MC_EDGE_AXIS[e]][vox];
-            }
-            int32_t* f = out.faces + 3 * ((int64_t)ent.tbase - sl.ghost_f + t);
-            const int32_t ib = (int32_t)sl.index_base;
-            f[0] = idx[2] + ib; f[1] = idx[1] + ib; f[2] = idx[0] + ib;   // gradient_direction='descent' reverses each triple
+        for (int k = 0; k < 13; ++k) centre = (k < ncreated && ((created >> (4 * k)) & 15u) == 12u) ? (int)ent.vbase + k : centre;
+        const int32_t ib = (int32_t)sl.index_base;
+        int32_t* f = out.faces + 3 * ((int64_t)ent.tbase - sl.ghost_f);
+        // two triangles per step: their six table reads are in flight together (a lone last triangle reads its own
+        // entries twice); the steps are unrolled so that the row bytes are register selects
+        emit_pair<0>(row, nt, centre, ib, z, y, x, d, out, f);
+        if (nt > 2) emit_pair<1>(row, nt, centre, ib, z, y, x, d, out, f);
+        if (nt > 4) {
+            emit_pair<2>(row, nt, centre, ib, z, y, x, d, out, f);
+            if (nt > 6) emit_pair<3>(row, nt, centre, ib, z, y, x, d, out, f);
+            if (nt > 8) emit_pair<4>(row, nt, centre, ib, z, y, x, d, out, f);
+            if (nt > 10) emit_pair<5>(row, nt, centre, ib, z, y, x, d, out, f);
         }
     }
 }
@@ -838,15 +890,49 @@ __device__ __forceinline__ void corner_gradients(const Cube& c, double (&g)[24])
     g[21] = v[7] - v[6]; g[22] = v[4] - v[7]; g[23] = v[3] - v[7];
 }
 
-// the cubes sharing an edge, as offsets (dz,dy,dx) from the creating... from the edge's LOWER CORNER voxel,
-// in scan order, with the edge's local id inside each: [axis][k] -> {dz, dy, dx, local edge}
-__device__ __constant__ signed char MC_SHARE[3][4][4] = {
-    {{-1, -1, 0, 6}, {-1, 0, 0, 4}, {0, -1, 0, 2}, {0, 0, 0, 0}},     // x edge
-    {{-1, 0, -1, 5}, {-1, 0, 0, 7}, {0, 0, -1, 1}, {0, 0, 0, 3}},     // y edge
-    {{0, -1, -1, 10}, {0, -1, 0, 11}, {0, 0, -1, 9}, {0, 0, 0, 8}}};  // z edge
+// The slot entry of cube (z, y, x) -- what mc_classify_cut decided for it -- found from the cut masks: the entry's place in
+// its unit's slot is the number of cut cubes in front of it in the row (mask 4 h + j, bit L <-> cube 256 h + 4 L + j of the
+// brick).  Two dependent round trips (64 B of masks, then the entry) instead of repeating the MC33 tests.  0 = not cut.
+struct McLookup { const uint64_t* masks; const uint32_t* slots; int cap, bx; };
+__device__ __forceinline__ uint32_t cube_entry(const McLookup& lk, const McDims& dc, int z, int y, int x) {
+    const int64_t unit = ((int64_t)z * dc.c1 + y) * lk.bx + (x / MC_UNIT);
+    const int xo = x % MC_UNIT, h = xo >> 8, L = (xo & 255) >> 2, j = xo & 3;
+    struct __attribute__((aligned(16))) Q2 { uint64_t a, b; };
+    const Q2* mp = reinterpret_cast<const Q2*>(lk.masks + unit * 8);
+    const Q2 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
+    const uint64_t m[8] = {q0.a, q0.b, q1.a, q1.b, q2.a, q2.b, q3.a, q3.b};
+    const uint64_t below = (1ull << L) - 1ull;
+    uint32_t rank = 0;
+    bool cut = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool mine = (q >> 2) == h;
+        const uint64_t before = (q >> 2) < h ? m[q] : (mine ? (m[q] & (below | ((q & 3) < j ? 1ull << L : 0ull))) : 0ull);
+        rank += (uint32_t)__popcll(before);
+        cut = cut || (mine && (q & 3) == j && ((m[q] >> L) & 1ull));
+    }
+    if (!cut) return 0u;
+    return lk.slots[unit * lk.cap + rank];
+}
+
+// ---- pass 5: normals + values (one thread per vertex, replaying the <= 4 cubes around its edge in scan order) ----------
+// The cubes sharing an edge, as offsets (dz, dy, dx) from the edge's LOWER CORNER voxel, in scan order, with the edge's
+// local id inside each:   x edge {-1,-1,0, 6} {-1,0,0, 4} {0,-1,0, 2} {0,0,0, 0}
+//                         y edge {-1,0,-1, 5} {-1,0,0, 7} {0,0,-1, 1} {0,0,0, 3}
+//                         z edge {0,-1,-1,10} {0,-1,0,11} {0,0,-1, 9} {0,0,0, 8}
+// (selected per axis from immediates: k is a compile-time index once the loop over the cubes is unrolled).
+__device__ __forceinline__ void shared_cube(int axis, int k, int& dz, int& dy, int& dx, int& e) {
+    constexpr signed char S[3][4][4] = {{{-1, -1, 0, 6}, {-1, 0, 0, 4}, {0, -1, 0, 2}, {0, 0, 0, 0}},
+                                        {{-1, 0, -1, 5}, {-1, 0, 0, 7}, {0, 0, -1, 1}, {0, 0, 0, 3}},
+                                        {{0, -1, -1, 10}, {0, -1, 0, 11}, {0, 0, -1, 9}, {0, 0, 0, 8}}};
+    dz = axis == 0 ? S[0][k][0] : (axis == 1 ? S[1][k][0] : S[2][k][0]);
+    dy = axis == 0 ? S[0][k][1] : (axis == 1 ? S[1][k][1] : S[2][k][1]);
+    dx = axis == 0 ? S[0][k][2] : (axis == 1 ? S[1][k][2] : S[2][k][2]);
+    e = axis == 0 ? S[0][k][3] : (axis == 1 ? S[1][k][3] : S[2][k][3]);
+}
 
 __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restrict__ vol, McDims d, McDims dc, double iso,
-                                                            const int64_t* __restrict__ vertex_cube,
+                                                            McLookup lk, const int64_t* __restrict__ vertex_cube,
                                                             const int8_t* __restrict__ vertex_edge, int64_t nverts,
                                                             McOut out) {
     const int64_t vid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -856,11 +942,33 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
     int hz, hy, hx;
     cube_coords(dc, home & MC_ID_MASK, hz, hy, hx);      // ids count the classified layers; the neighbours may lie in the ghost layer above (d)
     float nx = 0.0f, ny = 0.0f, nz = 0.0f, value = 0.0f;
-    int ncubes = 1, axis = 0, lz = 0, ly = 0, lx = 0;
+    int axis = 0, lz = hz, ly = hy, lx = hx;
     if (e_home != 12) {
-        axis = MC_EDGE_AXIS[e_home];
-        lz = hz + MC_EDGE_LO[e_home][0]; ly = hy + MC_EDGE_LO[e_home][1]; lx = hx + MC_EDGE_LO[e_home][2];
-        ncubes = 4;
+        const int lo = edge_lo(e_home);
+        axis = edge_axis(e_home);
+        lz = hz + (lo >> 2); ly = hy + ((lo >> 1) & 1); lx = hx + (lo & 1);
+    }
+    // ---- the cubes around the edge (the centre vertex: its own cube, as k = 3) and what the classification pass chose for
+    // them: all four lookups are in flight together
+    int cz[4], cy[4], cx[4], ce[4], coff[4], cnt[4];
+    bool live[4], tests[4];
+    uint32_t entry[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int dz, dy, dx, e;
+        shared_cube(axis, k, dz, dy, dx, e);
+        if (e_home == 12) { dz = dy = dx = 0; e = 12; }
+        cz[k] = lz + dz; cy[k] = ly + dy; cx[k] = lx + dx; ce[k] = e;
+        live[k] = (e_home != 12 || k == 3) && cz[k] >= 0 && cy[k] >= 0 && cx[k] >= 0 && cz[k] < d.c0 && cy[k] < d.c1 && cx[k] < d.c2;
+        tests[k] = live[k] && cz[k] >= dc.c0;           // ghost layer above: classified by the next slab, not here
+        entry[k] = 0u;
+        if (live[k] && !tests[k]) entry[k] = cube_entry(lk, dc, cz[k], cy[k], cx[k]);
+    }
+    TilingRow row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        coff[k] = entry_off(entry[k]); cnt[k] = entry_nt(entry[k]);
+        load_row(coff[k], cnt[k], row[k]);
     }
     // `strength` of the edge's two ends, 1 / (eps + |v|) rounded to a C float as in skimage: the same two voxels in every
     // cube that shares the edge (a cube may run the edge the other way round), so the two fp64 divisions are done once per
@@ -873,19 +981,27 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
         s_lo = (float)(1.0 / (SK_EPS + fabs(v_lo)));
         s_hi = (float)(1.0 / (SK_EPS + fabs(v_hi)));
     }
-    for (int k = 0; k < ncubes; ++k) {
-        int z, y, x, e;
-        if (e_home == 12) { z = hz; y = hy; x = hx; e = 12; }
-        else {
-            const signed char* s = MC_SHARE[axis][k];
-            z = lz + s[0]; y = ly + s[1]; x = lx + s[2]; e = s[3];
-            if (z < 0 || y < 0 || x < 0 || z >= d.c0 || y >= d.c1 || x >= d.c2) continue;
-        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!live[k]) continue;
+        const int z = cz[k], y = cy[k], x = cx[k], e = ce[k];
         Cube c;
         load_cube(vol, d, z, y, x, iso, c);
-        int off, nt;
-        select_tiling(c, index_of(c), off, nt);
+        int off = coff[k], nt = cnt[k];
+        if (tests[k]) {
+            select_tiling(c, index_of(c), off, nt);
+            load_row(off, nt, row[k]);
+        }
         if (nt == 0) continue;
+        // how often the cube's tiling references the edge
+        int uses = 0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) uses += (i < 3 * nt && row_edge(row[k], i) == e) ? 1 : 0;
+        if (nt > 4) {
+#pragma unroll
+            for (int i = 12; i < 36; ++i) uses += (i < 3 * nt && row_edge(row[k], i) == e) ? 1 : 0;
+        }
+        if (uses == 0) continue;
         // vmax of the cube = max(v,0) - min(v,0)
         double lo = 0.0, hi = 0.0;
 #pragma unroll
@@ -905,7 +1021,7 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
             (void)sx;
             gx = (float)sz; gy = (float)sy; gz = 0.0f;   // skimage's centre gradient: (sum w*gz, sum w*gy, 0)
         } else {
-            const int i1 = bitwise_index(MC_EDGE_A[e]), i2 = bitwise_index(MC_EDGE_B[e]);
+            const int i1 = edge_a(e), i2 = edge_b(e);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -913,21 +1029,18 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
                     ga[a] = i1 == q ? g[3 * q + a] : ga[a];
                     gb[a] = i2 == q ? g[3 * q + a] : gb[a];
                 }
-            const bool a_is_lo = i1 == bitwise_index(MC_EDGE_LO[e]);     // end A of the cube's local edge = the edge's lower voxel?
+            const bool a_is_lo = i1 == edge_lo(e);     // end A of the cube's local edge = the edge's lower voxel?
             s1 = a_is_lo ? s_lo : s_hi;
             s2 = a_is_lo ? s_hi : s_lo;
         }
-        bool referenced = false;
-        for (int i = 0; i < 3 * nt; ++i) {
-            if (lut(off + i) != e) continue;
-            referenced = true;
+        for (int u = 0; u < uses; ++u) {
             if (e == 12) { nx += gx; ny += gy; nz += gz; }
             else {
                 nx += (float)(ga[0] * (double)s1); ny += (float)(ga[1] * (double)s1); nz += (float)(ga[2] * (double)s1);
                 nx += (float)(gb[0] * (double)s2); ny += (float)(gb[1] * (double)s2); nz += (float)(gb[2] * (double)s2);
             }
         }
-        if (referenced && vmax > (double)value) value = (float)vmax;
+        if (vmax > (double)value) value = (float)vmax;
     }
     const double len = sqrt((double)nx * nx + (double)ny * ny + (double)nz * nz);
     if (len > 0.0) { nx = (float)(nx / len); ny = (float)(ny / len); nz = (float)(nz / len); }
@@ -970,6 +1083,29 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
 }  // namespace nm
 
 using namespace nm;
+
+// Side stream for the two passes that can overlap (nm_mc_emit_slab); one per device, created on first use.
+struct McFork { hipStream_t side = nullptr; hipEvent_t forked = nullptr, joined = nullptr; std::mutex lock; };
+static McFork* mc_fork() {
+    static McFork per_device[16];
+    static std::mutex create;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    McFork* f = &per_device[dev];
+    std::lock_guard<std::mutex> hold(create);
+    if (!f->side) {
+        hipStream_t s = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;          // the passes then run one after the other
+        }
+        f->forked = a; f->joined = b; f->side = s;
+    }
+    return f;
+}
 
 extern "C" {
 
@@ -1083,11 +1219,28 @@ int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, d
                        segments, ws.unit_sums, ws.group_sums, ws.active);
     hipLaunchKernelGGL(mc_emit<false>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
                        ws.vertex_cube, ws.vertex_edge);
-    hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
-                       ws.vertex_cube, ws.vertex_edge);
-    if (own_v > 0)
-        hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((own_v + 255) / 256)), dim3(256), 0, stream, d_volume, d, dc, iso,
-                           ws.vertex_cube, ws.vertex_edge, own_v, out);
+    // the faces pass and the attribute pass both depend on the vertex pass only, and both are latency-bound walks over
+    // ~1 % of the cubes: they run side by side (fork / join through a per-device side stream; the pair of events is
+    // enqueued under a lock so two host threads cannot interleave their record / wait pairs; capturable)
+    const McLookup lk{ws.masks, ws.slots, ws.cap, ws.bx};
+    McFork* fk = own_v > 0 ? mc_fork() : nullptr;
+    if (fk) {
+        std::lock_guard<std::mutex> hold(fk->lock);
+        NM_HIP_CHECK(hipEventRecord(fk->forked, stream));
+        NM_HIP_CHECK(hipStreamWaitEvent(fk->side, fk->forked, 0));
+        hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((own_v + 255) / 256)), dim3(256), 0, fk->side, d_volume, d, dc, iso,
+                           lk, ws.vertex_cube, ws.vertex_edge, own_v, out);
+        NM_HIP_CHECK(hipEventRecord(fk->joined, fk->side));
+        hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
+                           ws.vertex_cube, ws.vertex_edge);
+        NM_HIP_CHECK(hipStreamWaitEvent(stream, fk->joined, 0));
+    } else {
+        hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
+                           ws.vertex_cube, ws.vertex_edge);
+        if (own_v > 0)
+            hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((own_v + 255) / 256)), dim3(256), 0, stream, d_volume, d, dc, iso,
+                               lk, ws.vertex_cube, ws.vertex_edge, own_v, out);
+    }
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
