@@ -528,6 +528,8 @@ __global__ __launch_bounds__(MC_STREAM_THREADS, 8) void mc_classify_stream(const
 // Planes per march: 24 (halo planes cost 25/24; 1380 workgroups at 480^3), fewer for volumes that would not give every
 // CU its two workgroups.  (Choosing zrun to make the launch a whole number of "rounds" -- 22 at 480^3 -- measures
 // slower, 124.5 vs 121 us: workgroups do not run in lockstep rounds, the extra halo planes are what counts.)
+// (measured at 480^3, round 3: 24 planes -> 96 us, 35 -> 92, 48 -> 106, 60 -> 124, 69 = one resident round -> 92, 120 -> 127:
+// the pass is not limited by the tail of its last round)
 static int mc_pick_zrun(int64_t bricks_xy, int c_march, int num_cus) {
     const int64_t slots = 2 * (int64_t)(num_cus > 0 ? num_cus : 256);
     int z = 24;
@@ -574,7 +576,7 @@ constexpr int MC_SEG_MAX = (MC_GY - 1) * MC_UNIT;      // 3584 cubes per segment
 __global__ __launch_bounds__(256) void mc_classify_cut(const float* __restrict__ vol, McDims d, double iso, int zg0,
                                                        const uint64_t* __restrict__ cut_masks, uint32_t* __restrict__ slots,
                                                        const int cap, int bx, int by, int64_t segments,
-                                                       uint4* __restrict__ unit_sums) {
+                                                       uint4* __restrict__ unit_sums, uint32_t* __restrict__ cube_entries) {
     __shared__ uint16_t s_x[4][MC_SEG_MAX];             // position in the brick of every cut cube of the segment, in order
     __shared__ uint32_t s_acc[4][MC_GY - 1][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -637,7 +639,9 @@ __global__ __launch_bounds__(256) void mc_classify_cut(const float* __restrict__
         TilingRow row;
         load_row(off, nt, row);
         const int created = __popc(row_edges_used(row, nt) & owned_edges(z + zg0, y, x));
-        slots[(sg.unit0 + t * sg.ustride) * cap + k] = pack_entry(xoff, nt, created, off);
+        const uint32_t entry = pack_entry(xoff, nt, created, off);
+        slots[(sg.unit0 + t * sg.ustride) * cap + k] = entry;       // in scan order, for the numbering passes
+        cube_entries[((int64_t)z * d.c1 + y) * d.c2 + x] = entry;   // by position, for the attribute pass
         atomicAdd(&s_acc[wave][t][0], (uint32_t)created);
         atomicAdd(&s_acc[wave][t][1], (uint32_t)nt);
     }
@@ -682,8 +686,11 @@ __global__ __launch_bounds__(1024) void mc_scan_groups(uint4* __restrict__ tile_
     if (threadIdx.x == 0) group_sums[blockIdx.x] = make_uint4(tot[0], tot[1], tot[2], 0);
 }
 
+// `host` (pinned, device-mapped): (vertices, triangles, cut cubes, vertices and triangles in front of unit `ghost_unit`) for
+// the caller, who only has to wait for the stream -- no copy to stage
 __global__ __launch_bounds__(1024) void mc_scan_totals(uint4* __restrict__ group_sums, int64_t groups,
-                                                       uint32_t* __restrict__ totals) {
+                                                       uint32_t* __restrict__ totals, const uint4* __restrict__ unit_prefix,
+                                                       int64_t ghost_unit, uint32_t* __restrict__ host) {
     __shared__ uint32_t s_w[3][16];
     uint32_t carry[3] = {0, 0, 0};
     for (int64_t start = 0; start < groups; start += 1024) {      // one round up to 1M tiles = 1G cubes
@@ -696,7 +703,15 @@ __global__ __launch_bounds__(1024) void mc_scan_totals(uint4* __restrict__ group
         for (int k = 0; k < 3; ++k) carry[k] += tot[k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { totals[0] = carry[0]; totals[1] = carry[1]; totals[2] = carry[2]; }
+    if (threadIdx.x == 0) {
+        totals[0] = carry[0]; totals[1] = carry[1]; totals[2] = carry[2];
+        uint32_t gv = 0, gf = 0;
+        if (ghost_unit >= 0) {     // exclusive prefix of that unit = what the layers in front of it account for
+            const uint4 u = unit_prefix[ghost_unit], g = group_sums[ghost_unit >> 10];
+            gv = u.x + g.x; gf = u.y + g.y;
+        }
+        host[0] = carry[0]; host[1] = carry[1]; host[2] = carry[2]; host[3] = gv; host[4] = gf;
+    }
 }
 
 struct McOut {
@@ -877,7 +892,7 @@ __global__ __launch_bounds__(256) void mc_emit(const float* __restrict__ vol, Mc
     }
 }
 
-// ---- pass 5: normals + values (one thread per vertex, replaying its cubes in scan order) ---------------------
+// skimage's per-corner gradients (forward differences along the cube edges)
 __device__ __forceinline__ void corner_gradients(const Cube& c, double (&g)[24]) {
     const double* v = c.v;
     g[0] = v[0] - v[1];  g[1] = v[0] - v[3];  g[2] = v[0] - v[4];
@@ -890,29 +905,16 @@ __device__ __forceinline__ void corner_gradients(const Cube& c, double (&g)[24])
     g[21] = v[7] - v[6]; g[22] = v[4] - v[7]; g[23] = v[3] - v[7];
 }
 
-// The slot entry of cube (z, y, x) -- what mc_classify_cut decided for it -- found from the cut masks: the entry's place in
-// its unit's slot is the number of cut cubes in front of it in the row (mask 4 h + j, bit L <-> cube 256 h + 4 L + j of the
-// brick).  Two dependent round trips (64 B of masks, then the entry) instead of repeating the MC33 tests.  0 = not cut.
-struct McLookup { const uint64_t* masks; const uint32_t* slots; int cap, bx; };
+// What mc_classify_cut decided for cube (z, y, x): its entry in the per-cube table (written for cut cubes only and never
+// cleared: whether the cube IS cut comes from its bit in the cut masks -- mask 4 h + j, bit L <-> cube 256 h + 4 L + j of the
+// brick).  Both reads are issued together: one round trip instead of repeating the MC33 tests.  0 = not cut.
+struct McLookup { const uint64_t* masks; const uint32_t* entries; int bx; };
 __device__ __forceinline__ uint32_t cube_entry(const McLookup& lk, const McDims& dc, int z, int y, int x) {
-    const int64_t unit = ((int64_t)z * dc.c1 + y) * lk.bx + (x / MC_UNIT);
-    const int xo = x % MC_UNIT, h = xo >> 8, L = (xo & 255) >> 2, j = xo & 3;
-    struct __attribute__((aligned(16))) Q2 { uint64_t a, b; };
-    const Q2* mp = reinterpret_cast<const Q2*>(lk.masks + unit * 8);
-    const Q2 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
-    const uint64_t m[8] = {q0.a, q0.b, q1.a, q1.b, q2.a, q2.b, q3.a, q3.b};
-    const uint64_t below = (1ull << L) - 1ull;
-    uint32_t rank = 0;
-    bool cut = false;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool mine = (q >> 2) == h;
-        const uint64_t before = (q >> 2) < h ? m[q] : (mine ? (m[q] & (below | ((q & 3) < j ? 1ull << L : 0ull))) : 0ull);
-        rank += (uint32_t)__popcll(before);
-        cut = cut || (mine && (q & 3) == j && ((m[q] >> L) & 1ull));
-    }
-    if (!cut) return 0u;
-    return lk.slots[unit * lk.cap + rank];
+    const int64_t row = (int64_t)z * dc.c1 + y;
+    const int xo = x % MC_UNIT;
+    const uint64_t m = lk.masks[(row * lk.bx + x / MC_UNIT) * 8 + ((xo >> 8) * 4 + (xo & 3))];
+    const uint32_t ent = lk.entries[row * dc.c2 + x];
+    return (m >> ((xo & 255) >> 2)) & 1ull ? ent : 0u;
 }
 
 // ---- pass 5: normals + values (one thread per vertex, replaying the <= 4 cubes around its edge in scan order) ----------
@@ -1051,7 +1053,7 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
 static inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct McWorkspace {
-    uint64_t* masks; uint32_t* slots; uint4* unit_sums; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
+    uint64_t* masks; uint32_t* slots; uint32_t* entries; uint4* unit_sums; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
     McActive* active;
     int64_t units;     // (plane, row, x brick) triples, in scan order
     int cap, bx, by;   // entries per unit; x bricks per row; row groups per plane
@@ -1072,6 +1074,7 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
     char* p;
     p = take((size_t)units * 64); if (ws) ws->masks = (uint64_t*)p;
     p = take((size_t)units * cap * 4); if (ws) ws->slots = (uint32_t*)p;
+    p = take((size_t)d.cubes * 4); if (ws) ws->entries = (uint32_t*)p;
     p = take((size_t)units * 16); if (ws) ws->unit_sums = (uint4*)p;
     p = take((size_t)((units + 1023) / 1024) * 16); if (ws) ws->group_sums = (uint4*)p;
     p = take(256); if (ws) ws->totals = (uint32_t*)p;
@@ -1083,6 +1086,28 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
 }  // namespace nm
 
 using namespace nm;
+
+// Where the count pass leaves its totals for the host: a ring of 64-byte slots in pinned, device-mapped memory per device
+// (concurrent calls on different streams take different slots; 64 of them in flight is far beyond any caller).
+struct McHostRing { uint32_t* host = nullptr; uint32_t* dev = nullptr; unsigned next = 0; };
+static bool mc_host_slot(uint32_t** host, uint32_t** dev) {
+    static McHostRing per_device[16];
+    static std::mutex lock;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return false;
+    std::lock_guard<std::mutex> hold(lock);
+    McHostRing& r = per_device[d];
+    if (!r.host) {
+        void* h = nullptr;
+        void* dv = nullptr;
+        if (hipHostMalloc(&h, 64 * 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
+        r.host = static_cast<uint32_t*>(h); r.dev = static_cast<uint32_t*>(dv);
+    }
+    const unsigned k = r.next++ % 64u;
+    *host = r.host + 16 * k; *dev = r.dev + 16 * k;
+    return true;
+}
 
 // Side stream for the two passes that can overlap (nm_mc_emit_slab); one per device, created on first use.
 struct McFork { hipStream_t side = nullptr; hipEvent_t forked = nullptr, joined = nullptr; std::mutex lock; };
@@ -1151,7 +1176,6 @@ int nm_mc_count_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, 
     const int zrun = mc_pick_zrun((int64_t)bx * by, c_march, dev >= 0 && dev < 64 ? cus_of_device[dev] : 0);
     const dim3 bricks(bx, by, (unsigned)((c_march + zrun - 1) / zrun));
     NM_REQUIRE(bricks.y <= 65535u && bricks.z <= 65535u, "volume too large");
-    NM_HIP_CHECK(hipMemsetAsync(ws.totals, 0, 256, stream));
     float thr = (float)iso;                        // largest float <= iso (exact equivalence of the sign test)
     if ((double)thr > iso) thr = nextafterf(thr, -INFINITY);
     const bool vec = n2 % 4 == 0, xhalo = bricks.x > 1;
@@ -1163,24 +1187,21 @@ int nm_mc_count_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, 
 #undef NM_STREAM
     const int64_t segments = (int64_t)dc.c0 * by * bx;
     hipLaunchKernelGGL(mc_classify_cut, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0, stream, d_volume, dc, iso, (int)z_global,
-                       ws.masks, ws.slots, ws.cap, (int)bx, (int)by, segments, ws.unit_sums);
+                       ws.masks, ws.slots, ws.cap, (int)bx, (int)by, segments, ws.unit_sums, ws.entries);
     const int64_t groups = (units + 1023) / 1024;
     hipLaunchKernelGGL(mc_scan_groups, dim3((unsigned)groups), dim3(1024), 0, stream, ws.unit_sums, units, ws.group_sums);
-    hipLaunchKernelGGL(mc_scan_totals, dim3(1), dim3(1024), 0, stream, ws.group_sums, groups, ws.totals);
+    uint32_t* h_slot = nullptr;
+    uint32_t* d_slot = nullptr;
+    NM_REQUIRE(mc_host_slot(&h_slot, &d_slot), "mc: no pinned host memory for the totals");
+    const int64_t ghost_unit = ghost_below ? (int64_t)d.c1 * ws.bx : -1;   // first unit of the second layer
+    hipLaunchKernelGGL(mc_scan_totals, dim3(1), dim3(1024), 0, stream, ws.group_sums, groups, ws.totals, ws.unit_sums, ghost_unit, d_slot);
     NM_HIP_CHECK(hipGetLastError());
-    uint32_t totals[3];
-    uint4 ghost_unit = make_uint4(0, 0, 0, 0), ghost_group = make_uint4(0, 0, 0, 0);
-    NM_HIP_CHECK(hipMemcpyAsync(totals, ws.totals, sizeof(totals), hipMemcpyDeviceToHost, stream));
-    if (ghost_below) {      // what the first layer accounts for = the exclusive prefix of the first unit of the second layer
-        const int64_t u1 = (int64_t)d.c1 * ws.bx;
-        NM_HIP_CHECK(hipMemcpyAsync(&ghost_unit, ws.unit_sums + u1, sizeof(uint4), hipMemcpyDeviceToHost, stream));
-        NM_HIP_CHECK(hipMemcpyAsync(&ghost_group, ws.group_sums + (u1 >> 10), sizeof(uint4), hipMemcpyDeviceToHost, stream));
-    }
     NM_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint32_t totals[5] = {h_slot[0], h_slot[1], h_slot[2], h_slot[3], h_slot[4]};
     *h_vertices = totals[0];
     *h_faces = totals[1];
-    *h_ghost_vertices = (int64_t)ghost_unit.x + ghost_group.x;
-    *h_ghost_faces = (int64_t)ghost_unit.y + ghost_group.y;
+    *h_ghost_vertices = totals[3];
+    *h_ghost_faces = totals[4];
     return 0;
 }
 
@@ -1222,7 +1243,7 @@ int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, d
     // the faces pass and the attribute pass both depend on the vertex pass only, and both are latency-bound walks over
     // ~1 % of the cubes: they run side by side (fork / join through a per-device side stream; the pair of events is
     // enqueued under a lock so two host threads cannot interleave their record / wait pairs; capturable)
-    const McLookup lk{ws.masks, ws.slots, ws.cap, ws.bx};
+    const McLookup lk{ws.masks, ws.entries, ws.bx};
     McFork* fk = own_v > 0 ? mc_fork() : nullptr;
     if (fk) {
         std::lock_guard<std::mutex> hold(fk->lock);

@@ -419,6 +419,28 @@ def np_stats_sharded(x_local, first, n_total, own_lo, own_hi, gather):
     return result
 
 
+def _mc_outputs(nv, nf, dev):
+    """The four output arrays of a marching-cubes call as ONE allocation (256-byte aligned pieces): the host work between
+    the count and the emit pass -- during which the GPU waits -- is two allocations and some integer arithmetic; the typed
+    views are made after the kernels are launched.  Returns (buffer, device pointers, views())."""
+    al = lambda b: (b + 255) & ~255
+    sizes = (nv * 12, nf * 12, nv * 12, nv * 4)
+    offs, total = [], 0
+    for b in sizes:
+        offs.append(total)
+        total += al(b)
+    out = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+    base = out.data_ptr()
+    ptrs = tuple(C.c_void_p(base + o) for o in offs)
+
+    def views():
+        piece = lambda k, dt: out[offs[k]:offs[k] + sizes[k]].view(dt)
+        return (piece(0, torch.float32).view(nv, 3), piece(1, torch.int32).view(nf, 3), piece(2, torch.float32).view(nv, 3),
+                piece(3, torch.float32))
+
+    return out, ptrs, views
+
+
 def marching_cubes(volume, level):
     """skimage.measure.marching_cubes(volume, level) on the GPU (nm_mc_count + nm_mc_emit).
     volume: (n0,n1,n2) fp32 CUDA tensor.  Returns (verts (V,3) f32, faces (F,3) i32, normals (V,3) f32,
@@ -443,13 +465,11 @@ def marching_cubes(volume, level):
         if level < lo or level > hi:
             raise ValueError("Surface level must be within volume data range.")
         raise RuntimeError("No surface found at the given iso value.")
-    verts = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)
-    normals = torch.empty(nv.value, 3, dtype=torch.float32, device=dev)
-    values = torch.empty(nv.value, dtype=torch.float32, device=dev)
-    faces = torch.empty(nf.value, 3, dtype=torch.int32, device=dev)
+    out, (p_verts, p_faces, p_normals, p_values), views = _mc_outputs(nv.value, nf.value, dev)
     scratch = torch.empty(int(lib.nm_mc_vertex_scratch_bytes(nv.value, nf.value)) + 256, dtype=torch.uint8, device=dev)
-    check(lib.nm_mc_emit(_ptr(vol), n0, n1, n2, level, _ptr(ws), _ptr(scratch), nv.value, nf.value, _ptr(verts),
-                         _ptr(faces), _ptr(normals), _ptr(values), _stream()), "nm_mc_emit")
+    check(lib.nm_mc_emit(_ptr(vol), n0, n1, n2, level, _ptr(ws), _ptr(scratch), nv.value, nf.value, p_verts, p_faces, p_normals,
+                         p_values, _stream()), "nm_mc_emit")
+    verts, faces, normals, values = views()
     return verts, faces, normals, values
 
 
