@@ -1242,18 +1242,21 @@ int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, d
                        ws.vertex_cube, ws.vertex_edge);
     // the faces pass and the attribute pass both depend on the vertex pass only, and both are latency-bound walks over
     // ~1 % of the cubes: they run side by side (fork / join through a per-device side stream; the pair of events is
-    // enqueued under a lock so two host threads cannot interleave their record / wait pairs; capturable)
+    // enqueued under a lock so two host threads cannot interleave their record / wait pairs; capturable).  The longer
+    // one (attributes) stays on the caller's stream: a cross-stream dependency takes 7-14 us to resolve (kernel trace,
+    // round 3), which the shorter faces pass can afford and which the join, long since satisfied, then does not add.
+    // (Both passes as ONE launch with alternating workgroups measured slower: 95 us against 87 for the pair.)
     const McLookup lk{ws.masks, ws.entries, ws.bx};
     McFork* fk = own_v > 0 ? mc_fork() : nullptr;
     if (fk) {
         std::lock_guard<std::mutex> hold(fk->lock);
         NM_HIP_CHECK(hipEventRecord(fk->forked, stream));
         NM_HIP_CHECK(hipStreamWaitEvent(fk->side, fk->forked, 0));
-        hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((own_v + 255) / 256)), dim3(256), 0, fk->side, d_volume, d, dc, iso,
+        hipLaunchKernelGGL(mc_vertex_attributes, dim3((unsigned)((own_v + 255) / 256)), dim3(256), 0, stream, d_volume, d, dc, iso,
                            lk, ws.vertex_cube, ws.vertex_edge, own_v, out);
-        NM_HIP_CHECK(hipEventRecord(fk->joined, fk->side));
-        hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
+        hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, fk->side, d_volume, dc, iso, sl, ws.active, ws.totals, out,
                            ws.vertex_cube, ws.vertex_edge);
+        NM_HIP_CHECK(hipEventRecord(fk->joined, fk->side));
         NM_HIP_CHECK(hipStreamWaitEvent(stream, fk->joined, 0));
     } else {
         hipLaunchKernelGGL(mc_emit<true>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,

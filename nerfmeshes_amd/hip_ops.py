@@ -456,7 +456,8 @@ def marching_cubes(volume, level):
     dev = vol.device
     ws = torch.empty(int(lib.nm_mc_workspace_bytes(n0, n1, n2)), dtype=torch.uint8, device=dev)
     nv, nf = C.c_int64(), C.c_int64()
-    check(lib.nm_mc_count(_ptr(vol), n0, n1, n2, level, _ptr(ws), C.byref(nv), C.byref(nf), _stream()), "nm_mc_count")
+    p_vol, p_ws, stream = _ptr(vol), _ptr(ws), _stream()       # the GPU idles between the two calls: nothing is looked up twice
+    check(lib.nm_mc_count(p_vol, n0, n1, n2, level, p_ws, C.byref(nv), C.byref(nf), stream), "nm_mc_count")
     if nv.value == 0:
         # skimage checks the level against the data range first (ValueError) and only then finds no surface
         # (RuntimeError).  A level outside [min, max] cannot produce a vertex, so the 442 MB min/max pass is only
@@ -467,8 +468,8 @@ def marching_cubes(volume, level):
         raise RuntimeError("No surface found at the given iso value.")
     out, (p_verts, p_faces, p_normals, p_values), views = _mc_outputs(nv.value, nf.value, dev)
     scratch = torch.empty(int(lib.nm_mc_vertex_scratch_bytes(nv.value, nf.value)) + 256, dtype=torch.uint8, device=dev)
-    check(lib.nm_mc_emit(_ptr(vol), n0, n1, n2, level, _ptr(ws), _ptr(scratch), nv.value, nf.value, p_verts, p_faces, p_normals,
-                         p_values, _stream()), "nm_mc_emit")
+    check(lib.nm_mc_emit(p_vol, n0, n1, n2, level, p_ws, _ptr(scratch), nv.value, nf.value, p_verts, p_faces, p_normals,
+                         p_values, stream), "nm_mc_emit")
     verts, faces, normals, values = views()
     return verts, faces, normals, values
 
