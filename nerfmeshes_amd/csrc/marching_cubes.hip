@@ -733,11 +733,13 @@ struct McActive {      // one entry per cube that emits triangles, in scan order
 // the scan over the units (which are in scan order: (plane, row, x brick)).
 __global__ __launch_bounds__(256) void mc_compact(McDims d, const uint32_t* __restrict__ slots, const int cap, int bx, int by,
                                                   int64_t segments, const uint4* __restrict__ unit_prefix,
-                                                  const uint4* __restrict__ group_prefix, McActive* __restrict__ list) {
+                                                  const uint4* __restrict__ group_prefix, McActive* __restrict__ list,
+                                                  const uint32_t* __restrict__ totals, uint32_t list_capacity) {
     __shared__ uint32_t s_first[4][MC_GY - 1][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
     if (seg >= segments) return;
+    if (totals[1] > list_capacity) return;     // launched ahead of the host's look at the totals: the list may not fit (see nm_mc_emit_slab)
     // counts of the 7 units: .w of the scanned entries (mc_scan_groups keeps each unit's own count there)
     McSegment sg;
     mc_segment_place(d, seg, bx, by, sg);
@@ -1053,7 +1055,7 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
 static inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct McWorkspace {
-    uint64_t* masks; uint32_t* slots; uint32_t* entries; uint4* unit_sums; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
+    uint64_t* masks; uint32_t* slots; uint32_t* entries; McActive* list; uint32_t list_capacity; uint4* unit_sums; uint4* group_sums; uint32_t* totals; int32_t* edge[3]; int64_t* vertex_cube; int8_t* vertex_edge;
     McActive* active;
     int64_t units;     // (plane, row, x brick) triples, in scan order
     int cap, bx, by;   // entries per unit; x bricks per row; row groups per plane
@@ -1075,6 +1077,11 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
     p = take((size_t)units * 64); if (ws) ws->masks = (uint64_t*)p;
     p = take((size_t)units * cap * 4); if (ws) ws->slots = (uint32_t*)p;
     p = take((size_t)d.cubes * 4); if (ws) ws->entries = (uint32_t*)p;
+    // the cut cubes in scan order, built by the count call while the host is still waiting for the totals -- if the surface
+    // has at most cubes / 16 triangles (a closed surface cuts ~1 % of a grid's cubes, two triangles each); beyond that the
+    // emit call builds the list in its own scratch, as it did before round 3
+    const size_t list_capacity = (size_t)(d.cubes / 16 > 65536 ? d.cubes / 16 : 65536);
+    p = take(list_capacity * sizeof(McActive)); if (ws) { ws->list = (McActive*)p; ws->list_capacity = (uint32_t)(list_capacity < 0xffffffffu ? list_capacity : 0xffffffffu); }
     p = take((size_t)units * 16); if (ws) ws->unit_sums = (uint4*)p;
     p = take((size_t)((units + 1023) / 1024) * 16); if (ws) ws->group_sums = (uint4*)p;
     p = take(256); if (ws) ws->totals = (uint32_t*)p;
@@ -1087,10 +1094,11 @@ static size_t carve(const McDims& d, char* base, McWorkspace* ws) {
 
 using namespace nm;
 
-// Where the count pass leaves its totals for the host: a ring of 64-byte slots in pinned, device-mapped memory per device
-// (concurrent calls on different streams take different slots; 64 of them in flight is far beyond any caller).
-struct McHostRing { uint32_t* host = nullptr; uint32_t* dev = nullptr; unsigned next = 0; };
-static bool mc_host_slot(uint32_t** host, uint32_t** dev) {
+// Where the count pass leaves its totals for the host: a ring of 64-byte slots in pinned, device-mapped memory per device,
+// each with the event the host waits on (concurrent calls on different streams take different slots; 64 of them in flight
+// is far beyond any caller).
+struct McHostRing { uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t done[64] = {}; unsigned next = 0; };
+static bool mc_host_slot(uint32_t** host, uint32_t** dev, hipEvent_t* done) {
     static McHostRing per_device[16];
     static std::mutex lock;
     int d = 0;
@@ -1105,7 +1113,8 @@ static bool mc_host_slot(uint32_t** host, uint32_t** dev) {
         r.host = static_cast<uint32_t*>(h); r.dev = static_cast<uint32_t*>(dv);
     }
     const unsigned k = r.next++ % 64u;
-    *host = r.host + 16 * k; *dev = r.dev + 16 * k;
+    if (!r.done[k] && hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    *host = r.host + 16 * k; *dev = r.dev + 16 * k; *done = r.done[k];
     return true;
 }
 
@@ -1192,11 +1201,16 @@ int nm_mc_count_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, 
     hipLaunchKernelGGL(mc_scan_groups, dim3((unsigned)groups), dim3(1024), 0, stream, ws.unit_sums, units, ws.group_sums);
     uint32_t* h_slot = nullptr;
     uint32_t* d_slot = nullptr;
-    NM_REQUIRE(mc_host_slot(&h_slot, &d_slot), "mc: no pinned host memory for the totals");
+    hipEvent_t counted = nullptr;
+    NM_REQUIRE(mc_host_slot(&h_slot, &d_slot, &counted), "mc: no pinned host memory for the totals");
     const int64_t ghost_unit = ghost_below ? (int64_t)d.c1 * ws.bx : -1;   // first unit of the second layer
     hipLaunchKernelGGL(mc_scan_totals, dim3(1), dim3(1024), 0, stream, ws.group_sums, groups, ws.totals, ws.unit_sums, ghost_unit, d_slot);
+    // the host waits for the totals only; the list of cut cubes is built while it allocates the outputs
+    NM_HIP_CHECK(hipEventRecord(counted, stream));
+    hipLaunchKernelGGL(mc_compact, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0, stream, dc, ws.slots, ws.cap, ws.bx, ws.by,
+                       segments, ws.unit_sums, ws.group_sums, ws.list, ws.totals, ws.list_capacity);
     NM_HIP_CHECK(hipGetLastError());
-    NM_HIP_CHECK(hipStreamSynchronize(stream));
+    NM_HIP_CHECK(hipEventSynchronize(counted));
     const uint32_t totals[5] = {h_slot[0], h_slot[1], h_slot[2], h_slot[3], h_slot[4]};
     *h_vertices = totals[0];
     *h_faces = totals[1];
@@ -1236,8 +1250,11 @@ int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, d
     McSlab sl{(int)z_global, (int)ghost_below, (uint32_t)ghost_vertices, (uint32_t)ghost_faces, index_base};
     const unsigned ablocks = (unsigned)((faces + 255) / 256);   // active cubes <= faces; surplus threads exit
     const int64_t segments = (int64_t)dc.c0 * ws.by * ws.bx;
-    hipLaunchKernelGGL(mc_compact, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0, stream, dc, ws.slots, ws.cap, ws.bx, ws.by,
-                       segments, ws.unit_sums, ws.group_sums, ws.active);
+    if ((uint64_t)faces > ws.list_capacity)     // the count call could not build the list (same test as the kernel's, on the same number)
+        hipLaunchKernelGGL(mc_compact, dim3((unsigned)((segments + 3) / 4)), dim3(256), 0, stream, dc, ws.slots, ws.cap, ws.bx, ws.by,
+                           segments, ws.unit_sums, ws.group_sums, ws.active, ws.totals, 0xffffffffu);
+    else
+        ws.active = ws.list;
     hipLaunchKernelGGL(mc_emit<false>, dim3(ablocks), dim3(256), 0, stream, d_volume, dc, iso, sl, ws.active, ws.totals, out,
                        ws.vertex_cube, ws.vertex_edge);
     // the faces pass and the attribute pass both depend on the vertex pass only, and both are latency-bound walks over
