@@ -171,6 +171,20 @@ def _per_rank(value, dev, world, use_dist):
     return [float(x) for x in nd.all_gather_rows(mine, [1] * world).reshape(-1)]
 
 
+def _mc_traffic_from_profile(res):
+    """HBM bytes of one marching-cubes call from the committed PMC profile (480^3 only; never measured inside this run)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_mc_traffic.json")
+    if res != 480 or not os.path.exists(path):
+        return {"traffic": None}
+    try:
+        t = json.load(open(path))
+        return {"traffic": t["total_bytes_fetch_x2_everywhere"],
+                "traffic_source": "profiles/r03_mc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over "
+                                  "tests/tools/bench_mesh.py, all 8 kernels of a call (committed profile, NOT measured inside this run)"}
+    except (OSError, ValueError, KeyError):
+        return {"traffic": None}
+
+
 def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_points=262144, rank=0, world=1,
                use_dist=False, cpu_legs=True):
     """BASELINE config 4 (`mesh_nerf.py --res 480 --limit 1.2 --iso-level 32`, /root/reference/src/mesh_nerf.py:27-92):
@@ -218,7 +232,8 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
         "marching_cubes": {"iso": iso, "vertices": int(v.shape[0]), "faces": int(f.shape[0]), "ms_min": m_min, "ms_avg": m_avg,
                            "algorithmic_bytes": vol_bytes,
                            "roofline": {"bound": "hbm", "achieved": vol_bytes / (m_min * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": vol_bytes / (m_min * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                        "unit": "GB/s", "frac": vol_bytes / (m_min * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        **_mc_traffic_from_profile(res)},
                            "note": "whole nm_mc_count + nm_mc_emit call on the full grid incl. workspace allocation and the host sync"},
     }
     if world > 1:

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 GO = os.path.join(ROOT, "gpurun_out")
 PR = os.path.join(ROOT, "profiles")
 KERNEL = "mlp_kernel"
@@ -40,6 +40,22 @@ if os.path.exists(trace):
                                        for g, v in per.items()}
     full = [x for g, v in per.items() if g == 524288 for x in v]
     summary["mlp_avg_ms_full_size_launches"] = mean(full)
+    # the headline's own launches: bench.py renders the headline first -- (warmup + steps) views x 10 chunks x (coarse, fine)
+    # launches of mlp_kernel3 -- and times the last `steps` views; this is the number roofline.avg_launch_ms must agree with
+    ordered = sorted(((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+                      for r in csv.DictReader(open(trace)) if "mlp_kernel3" in r["Kernel_Name"]))
+    line = None
+    log_ = os.path.join(GO, f"bench_{tag}_profiled.log")
+    if os.path.exists(log_):
+        for l in open(log_):
+            if l.startswith('{"metric"'):
+                line = json.loads(l)
+    if line and len(ordered) >= 20 * (line["warmup"] + line["steps"]):
+        timed = [d for _, d in ordered[20 * line["warmup"]:20 * (line["warmup"] + line["steps"])]]
+        summary["headline_timed_launches"] = {
+            "launches": len(timed), "avg_ms_kernel_trace": mean(timed),
+            "avg_ms_hip_events_same_run": line["roofline"]["avg_launch_ms"],
+            "note": "the 60 launches inside bench.py's timed region: rocprofv3 kernel trace vs the HIP events bench.py records on the launch stream"}
 log = os.path.join(GO, f"bench_{tag}_profiled.log")
 if os.path.exists(log):
     for line in open(log):

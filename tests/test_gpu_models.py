@@ -155,6 +155,45 @@ def test_buff_model_with_random_sampling(pkg):
     assert bundle.rgb_map.shape == (rays, 3) and bool(torch.isfinite(bundle.rgb_map).all())
 
 
+def test_buff_random_branch_missed_rays_do_not_reach_the_tree(pkg):
+    """nm_buff_intersect_random zero-fills the rows of rays that cross nothing where the reference leaves
+    arbitrary ids.  The only consumer of the ids, tree maintenance (model_buff.py:66-68 -> ray_batch_integration), is fed
+    `indices[mask]`: a training forward updates `memm` exactly as if the missed rows held any other ids, and voxel 0
+    receives nothing from them."""
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=48, num_fine=64, near=0.0, far=1.2, dataset_type="colmap")
+    hp["tree.use_random_sampling"] = True
+    hp["tree.step_size_integration_offset"] = 0
+    gen = torch.Generator().manual_seed(5)
+    rays = 256
+    o = torch.nn.functional.normalize(torch.randn(rays, 3, generator=gen), dim=-1) * (0.75 + 0.5 * torch.rand(rays, 1, generator=gen))
+    d = torch.nn.functional.normalize((torch.rand(rays, 3, generator=gen) - 0.5) * 0.9 - o, dim=-1)
+    o[::2] = torch.nn.functional.normalize(o[::2], dim=-1) * 1.3      # every other ray looks away from the voxel cube
+    d[::2] = torch.nn.functional.normalize(o[::2], dim=-1)
+    memms = []
+    for poison in (False, True):
+        torch.manual_seed(20)                                                        # the same network both times
+        model = pkg["models"].BuFFModel(hp).cuda().train()
+        tree = model.tree
+        real = tree.batch_ray_voxel_intersect
+
+        def intersect(*a, _real=real, _poison=poison, **k):
+            z, idx, mask = _real(*a, **k)
+            assert not bool(mask[::2].any()) and bool(mask[1::2].any())
+            assert not bool(idx[~mask].any()) and not bool(z[~mask].any())          # zero-filled rows
+            if _poison:
+                idx = idx.clone()
+                idx[~mask] = 7                                                       # what the reference might hold there
+            return z, idx, mask
+
+        tree.batch_ray_voxel_intersect = intersect
+        torch.manual_seed(21)
+        before = tree.memm.clone()
+        model((o.cuda(), d.cuda(), torch.tensor([0.0, 1.2])))
+        assert not torch.equal(tree.memm, before), "the hit rays must have been integrated"
+        memms.append(tree.memm.clone())
+    assert torch.equal(memms[0], memms[1])
+
+
 def test_buff_sampled_tree_reference_tie_order(pkg):
     """R9 end to end on the GPU: BuFFModel.forward in train mode with tree.tie_order = "reference" samples (nm_buff_intersect_ex,
     NM_TIES_REFERENCE), renders and integrates three ray batches; memm after every step and the consolidated voxel set
