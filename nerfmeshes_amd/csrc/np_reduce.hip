@@ -13,8 +13,8 @@
 //     elements; a block runs 8 interleaved accumulators r[j] += a[8 i + j] and combines them as
 //     ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then adds the < 8 left-over elements one by one; n < 8: plain loop;
 //   * mean = sum / float32(n);  var: x = a - mean (fp32), x*x (fp32, two roundings), the same sum, / float32(n); sqrt.
-// A full 8192-chunk is a perfect binary tree over 64 blocks of 128: one wavefront per chunk, lane = (block, accumulator),
-// shuffles for the trees.  The ragged last chunk runs the generic recursion on one lane (< 8192 elements).
+// A full 8192-chunk is a perfect binary tree over 64 blocks of 128: one wavefront per chunk, lane = (block, half of the
+// block's accumulators), shuffles for the trees.  The ragged last chunk runs the generic recursion on one lane (< 8192 elements).
 // HBM-bound: 2 passes over the array (8 B / element algorithmic).
 #include "nm_internal.h"
 
@@ -81,7 +81,6 @@ __global__ __launch_bounds__(64) void np_chunk_sums_kernel(const float* __restri
     // `a` is addressed with GLOBAL element indices (the caller offsets the pointer when it holds a slice of the array);
     // chunks [chunk_lo, chunk_hi) of the global array are summed, results at csum[chunk - chunk_lo]
     const int lane = threadIdx.x;
-    const int blk = lane >> 3, j = lane & 7;          // block of this iteration's 8, accumulator
     const float mean = SQDEV ? *mean_ptr : 0.0f;
     csum -= chunk_lo; cmin -= chunk_lo; cmax -= chunk_lo;
     for (int64_t c = chunk_lo + blockIdx.x; c < chunk_hi; c += gridDim.x) {
@@ -97,36 +96,63 @@ __global__ __launch_bounds__(64) void np_chunk_sums_kernel(const float* __restri
             }
             continue;
         }
-        float sub[8];
+        // lane = (block of this half, half of the block's 8 accumulators): accumulator j of a block sums the elements
+        // 8 i + j in order of i -- four accumulators per lane, one 16-byte load per step (lane pairs read 32 contiguous
+        // bytes, the 32 blocks of a half are 512 B apart; every byte of the chunk is fetched exactly once)
+        float sub[2];
         float lo = INFINITY, hi = -INFINITY;
+        bool nan = false;
+        const int blk32 = lane >> 1, half = lane & 1;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {                // 8 blocks of 128 elements per iteration
-            const float* p = a + base + (int64_t)(it * 8 + blk) * 128 + j;
-            float r = 0.0f;
+        for (int it = 0; it < 2; ++it) {                // 32 blocks of 128 elements per iteration
+            const float* p = a + base + (int64_t)(it * 32 + blk32) * 128 + 4 * half;
+            float r[4];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = p[8 * i];
-                if (!SQDEV) { lo = np_min(lo, v); hi = np_max(hi, v); }
-                float e = v;
-                if (SQDEV) { const float d = v - mean; e = d * d; }
-                r = i == 0 ? e : r + e;
+                struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };   // a rank's slice may start at any element
+                const F4 v4 = *reinterpret_cast<const F4*>(p + 8 * i);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!SQDEV) { lo = fminf(lo, v[q]); hi = fmaxf(hi, v[q]); nan = nan || (v[q] != v[q]); }
+                    float e = v[q];
+                    if (SQDEV) { const float d = v[q] - mean; e = d * d; }
+                    r[q] = i == 0 ? e : r[q] + e;
+                }
             }
-            // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) over the 8 accumulator lanes, then the tree over the 8 blocks
-            r += __shfl_xor(r, 1);
-            r += __shfl_xor(r, 2);
-            r += __shfl_xor(r, 4);
-            r += __shfl_xor(r, 8);
-            r += __shfl_xor(r, 16);
-            r += __shfl_xor(r, 32);
-            sub[it] = r;                                 // sum of elements [1024 it, 1024 (it + 1)) of the chunk
+            // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): the two halves of a block, then the tree over the 32 blocks
+            float t = (r[0] + r[1]) + (r[2] + r[3]);
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 8);
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            sub[it] = t;                                 // sum of elements [4096 it, 4096 (it + 1)) of the chunk
         }
-        const float s = ((sub[0] + sub[1]) + (sub[2] + sub[3])) + ((sub[4] + sub[5]) + (sub[6] + sub[7]));
+        const float s = sub[0] + sub[1];
         if (lane == 0) csum[c] = s;
         if (!SQDEV) {
-            for (int off = 32; off > 0; off >>= 1) { lo = np_min(lo, __shfl_xor(lo, off)); hi = np_max(hi, __shfl_xor(hi, off)); }
+            for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+            if (__ballot(nan) != 0ull) lo = hi = NAN;    // numpy's minimum / maximum propagate NaN
             if (lane == 0) { cmin[c] = lo; cmax[c] = hi; }
         }
     }
+}
+
+// Sequential fp32 sum of 64 addends, one per lane, on top of `carry`: lane l ends up with the sum through addend l.
+// One instruction per addend: P[l] = P[l - 1] + x[l] for ALL lanes at once (DPP wave_shr:1; lane 0, which has no source,
+// keeps its value).  After step k lanes <= k hold their final value -- lane k because lane k - 1 did after step k - 1, the
+// lanes in front because they recompute the same sum from inputs that no longer change -- and the lanes behind hold
+// numbers nobody reads.  63 steps; the s_nop is the two wait states gfx9 wants between a VALU write and a DPP read of a VGPR.
+#define NM_NP_STEP "v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+#define NM_R3(x) x x x
+#define NM_R4(x) x x x x
+#define NM_R16(x) NM_R4(NM_R4(x))
+__device__ __forceinline__ float np_chain64(float x, float carry, bool first, int lane) {
+    float P = lane == 0 ? (first ? x : carry + x) : 0.0f;
+    asm volatile("s_nop 1\n" NM_R3(NM_R16(NM_NP_STEP)) NM_R3(NM_R4(NM_NP_STEP)) NM_R3(NM_NP_STEP) : "+v"(P) : "v"(x));
+    return P;
 }
 
 // the sequential fp32 accumulation of the chunk sums (what the reduction iterator does between buffer fills) + the
@@ -135,30 +161,68 @@ template <bool SQDEV>
 __global__ __launch_bounds__(256) void np_finish_kernel(const float* __restrict__ csum, const float* __restrict__ cmin,
                                                         const float* __restrict__ cmax, int64_t chunks, int64_t n,
                                                         float* __restrict__ out /* [sum, mean, var, std, min, max] */) {
-    __shared__ float tile[8192];
-    __shared__ float red[2][256];
-    float acc = 0.0f;
-    float lo = INFINITY, hi = -INFINITY;
-    for (int64_t base = 0; base < chunks; base += 8192) {
-        const int m = (int)((chunks - base) < 8192 ? (chunks - base) : 8192);
-        for (int i = threadIdx.x; i < m; i += 256) {
-            tile[i] = csum[base + i];
-            if (!SQDEV) { lo = np_min(lo, cmin[base + i]); hi = np_max(hi, cmax[base + i]); }
+    // A chain of `chunks` dependent fp32 additions (13 500 at 480^3) on wavefront 0, every lane computing the same
+    // accumulator.  The addends arrive 1024 at a time, one coalesced load per lane and 64 addends, the NEXT batch in
+    // flight while the current one is added (a batch is ~2.5 us of chain, a load ~2 us for a lone wavefront), and reach the
+    // chain one DPP addition each (np_chain64).  Measured per addend: lane 0 reading an LDS tile element by element 31
+    // cycles; v_readlane + v_add_f32 with a scalar operand 21; the DPP form: see DESIGN.md 3.3.  Wavefronts 1-3 fold the
+    // chunks' min / max (order-free) meanwhile.
+    constexpr int U = 16;
+    __shared__ float red[2][192];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave > 0) {
+        if (!SQDEV) {
+            float lo = INFINITY, hi = -INFINITY;
+            const int t = threadIdx.x - 64;
+            for (int64_t base = 0; base < chunks; base += 192 * 8) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = base + 192 * u + t;
+                    a[u] = i < chunks ? cmin[i] : INFINITY;
+                    b[u] = i < chunks ? cmax[i] : -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { lo = np_min(lo, a[u]); hi = np_max(hi, b[u]); }
+            }
+            red[0][t] = lo; red[1][t] = hi;
         }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int i = 0; i < m; ++i) acc = (base == 0 && i == 0) ? tile[0] : acc + tile[i];
-        __syncthreads();
     }
-    if (!SQDEV) {
-        red[0][threadIdx.x] = lo; red[1][threadIdx.x] = hi;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int i = 1; i < 256; ++i) { lo = np_min(lo, red[0][i]); hi = np_max(hi, red[1][i]); }
+    float acc = 0.0f;
+    if (wave == 0) {
+        float cur[U], nxt[U];
+        auto fetch = [&](float (&v)[U], int64_t base) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = base + 64 * u + lane;
+                v[u] = i < chunks ? csum[i] : 0.0f;
+            }
+        };
+        fetch(cur, 0);
+        for (int64_t base = 0; base < chunks; base += 64 * U) {
+            const int64_t left = chunks - base;
+            if (left > 64 * U) fetch(nxt, base + 64 * U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = left - 64 * u;                    // addends of this group of 64 (uniform)
+                if (m > 0) {
+                    const bool first = base == 0 && u == 0;
+                    const float p63 = np_chain64(cur[u], acc, first, lane);
+                    if (m >= 64) acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p63), 63));
+                    else acc = __shfl(p63, (int)m - 1);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!SQDEV) {
+            float lo = red[0][0], hi = red[1][0];
+            for (int i = 1; i < 192; ++i) { lo = np_min(lo, red[0][i]); hi = np_max(hi, red[1][i]); }
             out[4] = lo; out[5] = hi;
         }
-    }
-    if (threadIdx.x == 0) {
         const float count = (float)n;                   // float32(n), round to nearest, as numpy casts the divisor
         if (!SQDEV) { out[0] = acc; out[1] = acc / count; }
         else { const float var = acc / count; out[2] = var; out[3] = sqrtf(var); }
