@@ -44,11 +44,15 @@ typedef struct nm_mlp_desc {
     int32_t num_encoding_fn_dir;  /* models.py:11  */
     int32_t include_input_xyz;    /* models.py:12  */
     int32_t include_input_dir;    /* models.py:13  */
-    int32_t use_viewdirs;         /* models.py:16 -- only 1 is implemented (all shipped configs) */
+    int32_t use_viewdirs;         /* models.py:16 -- 1: all shipped configs.  0 (models.py:77-79, trunk -> fc_out): inference entry
+                                   * points only, fp32; the training entry points refuse such a handle */
 } nm_mlp_desc;
 
 /* Host pointers to the tensors of FlexibleNeRFModel.state_dict(), torch.nn.Linear layout
- * (out_features, in_features) row-major fp32.  layers_xyz_* have num_layers-1 entries. */
+ * (out_features, in_features) row-major fp32.  layers_xyz_* have num_layers-1 entries.
+ * use_viewdirs = 0: the network ends in fc_out (4, hidden_size): pass its colour rows as fc_rgb_w = fc_out.weight (rows
+ * 0..2, i.e. 3 x hidden_size contiguous floats) / fc_rgb_b = fc_out.bias, and its density row as fc_alpha_w =
+ * fc_out.weight + 3 * hidden_size / fc_alpha_b = fc_out.bias + 3; layers_dir0_*, fc_feat_* and freq_dir are ignored. */
 typedef struct nm_mlp_weights {
     const float* layer1_w;            const float* layer1_b;
     const float* const* layers_xyz_w; const float* const* layers_xyz_b;

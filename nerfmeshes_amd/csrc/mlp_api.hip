@@ -180,12 +180,15 @@ struct ProfRec { hipEvent_t start, stop; double flops; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
+// density_only: 0 full evaluation | 1 sigma only.  For a use_viewdirs = 0 handle the full evaluation is the kernels' mode 2:
+// the trunk as in mode 1, then all four rows of fc_out (models.py:77-79).
 static int launch_mlp_timed(const nm_mlp* m, const MlpArgs& a, int density_only, hipStream_t stream) {
+    if (!density_only && !m->desc.use_viewdirs) density_only = 2;
     if (!g_prof_on || a.n <= 0) return launch_mlp(m, a, density_only, stream);
     ProfRec r;
     NM_HIP_CHECK(hipEventCreate(&r.start));
     NM_HIP_CHECK(hipEventCreate(&r.stop));
-    r.flops = (double)a.n * (double)(density_only ? m->flops_density : m->flops_full);
+    r.flops = (double)a.n * (double)(density_only == 1 ? m->flops_density : m->flops_full);
     NM_HIP_CHECK(hipEventRecord(r.start, stream));
     const int rc = launch_mlp(m, a, density_only, stream);
     NM_HIP_CHECK(hipEventRecord(r.stop, stream));
@@ -201,8 +204,8 @@ static int64_t mlp_macs(const nm_mlp_desc& d, bool density_only) {
         const bool skip = i % d.skip_step == 0 && i > 0 && i != d.num_layers - 1;
         macs += (H + (skip ? dx : 0)) * H;
     }
-    macs += H;  // fc_alpha
-    if (!density_only) macs += H * H + (H + dd) * (H / 2) + (H / 2) * 3;
+    macs += H;  // fc_alpha (use_viewdirs = 0: row 3 of fc_out)
+    if (!density_only) macs += d.use_viewdirs ? H * H + (H + dd) * (H / 2) + (H / 2) * 3 : 3 * H;   // else: rows 0..2 of fc_out
     return macs;
 }
 
@@ -251,11 +254,14 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     NM_REQUIRE(desc && w && out, "null argument");
     NM_REQUIRE(precision == NM_PREC_F32 || precision == NM_PREC_BF16X3, "unknown precision");
     const nm_mlp_desc& d = *desc;
-    NM_REQUIRE(d.use_viewdirs == 1, "only use_viewdirs=True networks are implemented on the HIP path");
+    NM_REQUIRE(d.use_viewdirs == 0 || d.use_viewdirs == 1, "use_viewdirs is 0 or 1");
+    const bool no_view = d.use_viewdirs == 0;      // models.py:77-79: trunk -> fc_out (4 rows), no view branch
+    NM_REQUIRE(!no_view || precision == NM_PREC_F32, "use_viewdirs=0 networks run in fp32 only");
     NM_REQUIRE(d.num_layers >= 2 && d.num_layers <= 32, "num_layers out of range");
     NM_REQUIRE(d.skip_step >= 1, "skip_step must be >= 1");
     NM_REQUIRE(d.num_encoding_fn_xyz <= MAX_FREQ_XYZ && d.num_encoding_fn_dir <= MAX_FREQ_DIR, "too many encoding fns");
-    const MlpPlan* plan = find_mlp_plan(d.hidden_size, d.num_encoding_fn_xyz, d.num_encoding_fn_dir);
+    // a network without view directions has no direction encoding: any instantiated kernel of that width / xyz encoding runs it
+    const MlpPlan* plan = find_mlp_plan(d.hidden_size, d.num_encoding_fn_xyz, no_view ? 4 : d.num_encoding_fn_dir);
     if (!plan) {
         set_error("no gfx950 kernel instantiated for hidden_size=" + std::to_string(d.hidden_size) +
                   " num_encoding_fn_xyz=" + std::to_string(d.num_encoding_fn_xyz) +
@@ -288,15 +294,20 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
             skip_mask |= 1u << i;
         }
     }
-    pack_gemm(index, T_FEATW, H, H, NT, hid);
-    pack_gemm(index, T_DIRW, H + dd, H / 2, NTD, dir_steps);
+    if (!no_view) {
+        pack_gemm(index, T_FEATW, H, H, NT, hid);
+        pack_gemm(index, T_DIRW, H + dd, H / 2, NTD, dir_steps);
+    }
     index.resize(index.size() + 1024, -1);  // DMA granularity padding (4 KiB)
     pad_to(index, 64);
     const size_t off_bias = index.size();
     pack_range(index, T_L1B, H);
     for (int i = 0; i < L - 1; ++i) pack_range(index, T_XYZ0 + 2 * i + 1, H);
-    pack_range(index, T_FEATB, H);
-    pack_range(index, T_DIRB, H / 2);
+    if (no_view) index.resize(index.size() + H + H / 2, -1);       // the kernels' bias layout is the same for both kinds
+    else {
+        pack_range(index, T_FEATB, H);
+        pack_range(index, T_DIRB, H / 2);
+    }
     pack_range(index, T_ALPHAB, 1);
     pack_range(index, T_RGBB, 3);
     pad_to(index, 64);
@@ -306,16 +317,24 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         for (int s = 0; s < H / 4; ++s) index.push_back((T_ALPHAW << 24) | (16 * (s >> 2) + 4 * g + (s & 3)));
     pad_to(index, 64);
     const size_t off_wr = index.size();
-    for (int c = 0; c < 3; ++c)
-        for (int g = 0; g < 4; ++g)
-            for (int s = 0; s < H / 8; ++s)
-                index.push_back((T_RGBW << 24) | (c * (H / 2) + 16 * (s >> 2) + 4 * g + (s & 3)));
+    if (no_view) {     // rows 0..2 of fc_out over the trunk output: three GEMV operands in fc_alpha's layout
+        for (int c = 0; c < 3; ++c)
+            for (int g = 0; g < 4; ++g)
+                for (int s = 0; s < H / 4; ++s) index.push_back((T_RGBW << 24) | (c * H + 16 * (s >> 2) + 4 * g + (s & 3)));
+    } else {
+        for (int c = 0; c < 3; ++c)
+            for (int g = 0; g < 4; ++g)
+                for (int s = 0; s < H / 8; ++s)
+                    index.push_back((T_RGBW << 24) | (c * (H / 2) + 16 * (s >> 2) + 4 * g + (s & 3)));
+    }
     pad_to(index, 64);
     // backward (delta propagation): the same layers transposed, in reverse order, hidden columns only
     const size_t off_bwd = index.size();
-    pack_gemm(index, T_DIRW, H + dd, H, NT, hid_half, true);
-    pack_gemm(index, T_FEATW, H, H, NT, hid, true);
-    for (int i = L - 2; i >= 0; --i) pack_gemm(index, T_XYZ0 + 2 * i, H + (is_skip(d, i) ? dx : 0), H, NT, hid, true);
+    if (!no_view) {    // (training a use_viewdirs = 0 network is not implemented: nm_mlp_forward_train rejects the handle)
+        pack_gemm(index, T_DIRW, H + dd, H, NT, hid_half, true);
+        pack_gemm(index, T_FEATW, H, H, NT, hid, true);
+        for (int i = L - 2; i >= 0; --i) pack_gemm(index, T_XYZ0 + 2 * i, H + (is_skip(d, i) ? dx : 0), H, NT, hid, true);
+    }
     index.resize(index.size() + 1024, -1);
     pad_to(index, 64);
 
@@ -392,10 +411,16 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         stage(T_XYZ0 + 2 * i, w->layers_xyz_w[i], (size_t)H * (H + (is_skip(d, i) ? dx : 0)));
         stage(T_XYZ0 + 2 * i + 1, w->layers_xyz_b[i], H);
     }
-    stage(T_FEATW, w->fc_feat_w, (size_t)H * H); stage(T_FEATB, w->fc_feat_b, H);
+    NM_REQUIRE(w->layer1_w && w->layer1_b && w->fc_alpha_w && w->fc_alpha_b && w->fc_rgb_w && w->fc_rgb_b, "missing weight tensor");
+    NM_REQUIRE(no_view || (w->fc_feat_w && w->fc_feat_b && w->layers_dir0_w && w->layers_dir0_b), "missing view-branch weight tensor");
     stage(T_ALPHAW, w->fc_alpha_w, H); stage(T_ALPHAB, w->fc_alpha_b, 1);
-    stage(T_DIRW, w->layers_dir0_w, (size_t)(H / 2) * (H + dd)); stage(T_DIRB, w->layers_dir0_b, H / 2);
-    stage(T_RGBW, w->fc_rgb_w, (size_t)3 * (H / 2)); stage(T_RGBB, w->fc_rgb_b, 3);
+    if (no_view) stage(T_RGBW, w->fc_rgb_w, (size_t)3 * H);
+    else {
+        stage(T_FEATW, w->fc_feat_w, (size_t)H * H); stage(T_FEATB, w->fc_feat_b, H);
+        stage(T_DIRW, w->layers_dir0_w, (size_t)(H / 2) * (H + dd)); stage(T_DIRB, w->layers_dir0_b, H / 2);
+        stage(T_RGBW, w->fc_rgb_w, (size_t)3 * (H / 2));
+    }
+    stage(T_RGBB, w->fc_rgb_b, 3);
     float* d_flat = nullptr;
     NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_flat), flat.size() * 4));
     NM_HIP_CHECK(hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
@@ -418,7 +443,8 @@ int nm_mlp_refresh(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream) {
     WeightPtrs ptrs;
     weight_pointers(m->desc, *d_weights, ptrs);
     for (int t = 0; t < T_COUNT; ++t) {
-        const bool used = t < T_XYZ0 + 2 * (m->desc.num_layers - 1) || t >= T_FEATW;
+        const bool view_branch = t == T_FEATW || t == T_FEATB || t == T_DIRW || t == T_DIRB;
+        const bool used = (t < T_XYZ0 + 2 * (m->desc.num_layers - 1) || t >= T_FEATW) && !(view_branch && !m->desc.use_viewdirs);
         NM_REQUIRE(!used || ptrs.p[t], "nm_mlp_refresh: missing tensor");
     }
     return launch_gather(m, ptrs, static_cast<hipStream_t>(stream));

@@ -218,6 +218,23 @@ __device__ __forceinline__ float alpha_gemv(const float (&in)[H / 4], const floa
     return group_sum(part);
 }
 
+// A network without view directions (models.py:77-79): the colour rows of fc_out over the trunk output, three more GEMVs
+// in fc_alpha's operand layout, sigmoid, and the (rgb, sigma) row -- `density_only` == 2 in the kernels below.
+template <int H>
+__device__ __forceinline__ void flat_head(const MlpArgs& args, const float (&in)[H / 4], const float* wrows,
+                                          const float* tail_bias, float sigma, int64_t sample, bool valid, int g) {
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float x = alpha_gemv<H>(in, wrows + ch * H, g) + tail_bias[1 + ch];
+        rgb[ch] = 1.0f / (1.0f + expf(-x));
+    }
+    if (valid && g == 0) {
+        f32x4 o4 = {rgb[0], rgb[1], rgb[2], sigma};
+        *reinterpret_cast<f32x4*>(args.out + 4 * sample) = o4;
+    }
+}
+
 // ---- training tape helpers ---------------------------------------------------------------------------------
 // D-layout registers (tile nt, register r = feature 16*nt + 4*g + r of this lane's sample) <-> row-major [sample][width]
 template <int NT>
@@ -280,7 +297,9 @@ __device__ __forceinline__ SamplePD fetch_sample(const MlpArgs& args, int64_t si
 }
 
 // ---- the fused forward kernel (TAPE: also records the activations the backward pass needs) ---------------
-template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD, int ABL, bool TAPE>
+// FLAT: the instantiation that also serves use_viewdirs = 0 networks (`density_only` == 2, see flat_head); a separate
+// instantiation so that the production kernels compile exactly as they did without it
+template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD, int ABL, bool TAPE, bool FLAT = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, const int num_layers,
                                                       const int density_only) {
     using N = Net<H, FX, FD, KCH>;
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
     if constexpr (LBIAS) {
         for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
         for (int i = threadIdx.x; i < H; i += NW * 64) lds_walpha[i] = args.walpha[i];
-        for (int i = threadIdx.x; i < 3 * H / 2; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+        for (int i = threadIdx.x; i < ((FLAT && density_only == 2) ? 3 * H : 3 * H / 2); i += NW * 64) lds_wrgb[i] = args.wrgb[i];
     }
     const float* bias_src = LBIAS ? lds_bias : args.bias;
     const float* walpha_src = LBIAS ? lds_walpha : args.walpha;
@@ -386,7 +405,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
 
         if (density_only) {
             sigma = alpha_gemv<H>(in, walpha_src, g) + tail_bias[0];
-            if (valid && g == 0) args.out[sample] = sigma;
+            if (FLAT && density_only == 2) flat_head<H>(args, in, wrgb_src, tail_bias, sigma, sample, valid, g);   // use_viewdirs = 0
+            else if (valid && g == 0) args.out[sample] = sigma;
             gw = args.wstream;
             continue;
         }

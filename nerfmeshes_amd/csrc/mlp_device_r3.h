@@ -99,7 +99,7 @@ __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[
     carry[1] = ab[(TOTAL + 1) % 3];
 }
 
-template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0>
+template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0, bool FLAT = false>   // FLAT: see mlp_kernel
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, const int num_layers,
                                                           const int density_only) {
     using N = Net<H, FX, FD, KCH>;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
     float* lds_wrgb = lds_walpha + H;
     for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
     for (int i = threadIdx.x; i < H; i += NW * 64) lds_walpha[i] = args.walpha[i];
-    for (int i = threadIdx.x; i < 3 * H / 2; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    for (int i = threadIdx.x; i < ((FLAT && density_only == 2) ? 3 * H : 3 * H / 2); i += NW * 64) lds_wrgb[i] = args.wrgb[i];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
 
         if (density_only) {
             sigma = alpha_gemv<H>(in, lds_walpha, g) + tail_bias[0];
-            if (valid && g == 0) args.out[sample] = sigma;
+            if (FLAT && density_only == 2) flat_head<H>(args, in, lds_wrgb, tail_bias, sigma, sample, valid, g);   // use_viewdirs = 0
+            else if (valid && g == 0) args.out[sample] = sigma;
             continue;
         }
 

@@ -44,18 +44,20 @@ struct MlpPlan {
     void (*kernel)(const MlpArgs, const int, const int);
     int wg_samples;      // samples one workgroup evaluates per iteration
     int wg_per_cu;       // workgroups co-resident on a CU
+    void (*kernel_flat)(const MlpArgs, const int, const int);   // the FLAT instantiation (use_viewdirs = 0 networks), or null
 };
 
 template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD = false, int ABL = 0>
 static MlpPlan make_plan(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
-                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>, NW * 16, 8 / NW};
+                   &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>, NW * 16, 8 / NW,
+                   (ABL == 0 && LBIAS) ? &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false, true> : nullptr};
 }
 
 template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0>
 static MlpPlan make_plan3(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 3 * Net<H, FX, FD, KCH>::LDSBUF, true, &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL>,
-                   NW * 16, 8 / NW};
+                   NW * 16, 8 / NW, ABL == 0 ? &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL, true> : nullptr};
 }
 
 // variant 0 is the production choice and the ONLY one in libnerfmeshes_hip.so.  The others exist for within-process
@@ -147,6 +149,8 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     if (args.n <= 0) return 0;
     DeviceGuard guard(m->device);
     const int L = m->desc.num_layers, H = m->desc.hidden_size;
+    NM_REQUIRE(density_only != 2 || (m->precision == NM_PREC_F32 && p->kernel_flat), "no kernel for use_viewdirs=0 networks in this plan");
+    auto kernel = density_only == 2 ? p->kernel_flat : p->kernel;
     if (m->precision == NM_PREC_BF16X3) {
         const B3Plan* b = find_b3_plan(H, m->desc.num_encoding_fn_xyz, m->desc.num_encoding_fn_dir);
         NM_REQUIRE(b && m->d_stream_b3, "no bf16x3 kernel for this network");
@@ -165,13 +169,16 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
         NM_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255) : 0);
+    // bias cache + fc_alpha + fc_rgb rows; a use_viewdirs = 0 network (mode 2) keeps three H-wide fc_out rows where fc_rgb's
+    // three H/2-wide ones go
+    const int rgb_floats = density_only == 2 ? 3 * H : 3 * H / 2;
+    const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + rgb_floats) * 4 + 255) & ~255) : 0);
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     // the dynamic-LDS attribute is per device: tracked per (device, plan)
-    static int attr_bytes[64][sizeof(g_plans) / sizeof(g_plans[0])] = {};
-    const int idx = (int)(p - g_plans), dev = (m->device >= 0 && m->device < 64) ? m->device : 0;
+    static int attr_bytes[64][2 * sizeof(g_plans) / sizeof(g_plans[0])] = {};
+    const int idx = 2 * (int)(p - g_plans) + (density_only == 2 ? 1 : 0), dev = (m->device >= 0 && m->device < 64) ? m->device : 0;
     if (attr_bytes[dev][idx] < lds_bytes) {
-        NM_HIP_CHECK(hipFuncSetAttribute((const void*)p->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_bytes[dev][idx] = lds_bytes;
     }
     const int64_t wg_iters = (args.n + p->wg_samples - 1) / p->wg_samples;
@@ -183,7 +190,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
         const int64_t rounds = (wg_iters + grid - 1) / grid;
         grid = (wg_iters + rounds - 1) / rounds;
     }
-    hipLaunchKernelGGL(p->kernel, dim3((unsigned)grid), dim3(p->NW * 64), lds_bytes, stream, args,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(p->NW * 64), lds_bytes, stream, args,
                        (int)m->desc.num_layers, density_only);
     NM_HIP_CHECK(hipGetLastError());
     return 0;

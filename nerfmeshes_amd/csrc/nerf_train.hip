@@ -251,6 +251,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
     NM_REQUIRE(tape->d_h && tape->d_feat && tape->d_v && tape->d_mask_h && tape->d_mask_v, "incomplete tape");
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
+    NM_REQUIRE(m->desc.use_viewdirs == 1, "training a use_viewdirs=0 network is not implemented on the HIP path (inference only)");
     const nm_mlp_desc& d = m->desc;
     const TrainPlan* plan = nullptr;
     for (const TrainPlan& p : g_train_plans)
@@ -282,6 +283,7 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
     NM_REQUIRE(tape->d_mask_h && tape->d_mask_v, "incomplete tape");
     NM_REQUIRE(deltas->d_h && deltas->d_feat && deltas->d_v && deltas->d_last, "incomplete delta buffers");
     if (n == 0) return 0;
+    NM_REQUIRE(m->desc.use_viewdirs == 1, "training a use_viewdirs=0 network is not implemented on the HIP path (inference only)");
     const nm_mlp_desc& d = m->desc;
     const BwdPlan* plan = nullptr;
     for (const BwdPlan& p : g_bwd_plans)

@@ -71,15 +71,25 @@ class HipMLP:
         d = MlpDesc(L, int(desc["hidden_size"]), int(desc["skip_step"]), fx, fd,
                     int(bool(desc.get("include_input_xyz", True))), int(bool(desc.get("include_input_dir", True))),
                     int(bool(desc.get("use_viewdirs", True))))
-        if not d.use_viewdirs:
-            raise _lib.HipLibraryError("use_viewdirs=False networks are not implemented on the HIP path")
         xs_w = (C.c_void_p * (L - 1))(*[arr(f"layers_xyz.{i}.weight") for i in range(L - 1)])
         xs_b = (C.c_void_p * (L - 1))(*[arr(f"layers_xyz.{i}.bias") for i in range(L - 1)])
-        w = MlpWeights(arr("layer1.weight"), arr("layer1.bias"), xs_w, xs_b,
-                       arr("layers_dir.0.weight"), arr("layers_dir.0.bias"),
-                       arr("fc_alpha.weight"), arr("fc_alpha.bias"), arr("fc_rgb.weight"), arr("fc_rgb.bias"),
-                       arr("fc_feat.weight"), arr("fc_feat.bias"),
-                       arr("encode_xyz.frequency_bands"), arr("encode_dir.frequency_bands"))
+        if d.use_viewdirs:
+            w = MlpWeights(arr("layer1.weight"), arr("layer1.bias"), xs_w, xs_b,
+                           arr("layers_dir.0.weight"), arr("layers_dir.0.bias"),
+                           arr("fc_alpha.weight"), arr("fc_alpha.bias"), arr("fc_rgb.weight"), arr("fc_rgb.bias"),
+                           arr("fc_feat.weight"), arr("fc_feat.bias"),
+                           arr("encode_xyz.frequency_bands"), arr("encode_dir.frequency_bands"))
+        else:
+            # models.py:77-79: the trunk ends in fc_out (4, H): rows 0..2 are the colour rows, row 3 the density row
+            if precision != "f32":
+                raise _lib.HipLibraryError("use_viewdirs=False networks run in fp32 only")
+            arr("fc_out.weight"), arr("fc_out.bias")
+            H = int(desc["hidden_size"])
+            ow, ob = host["fc_out.weight"].ctypes.data, host["fc_out.bias"].ctypes.data
+            w = MlpWeights(arr("layer1.weight"), arr("layer1.bias"), xs_w, xs_b, C.c_void_p(None), C.c_void_p(None),
+                           C.c_void_p(ow + 3 * H * 4), C.c_void_p(ob + 3 * 4), C.c_void_p(ow), C.c_void_p(ob),
+                           C.c_void_p(None), C.c_void_p(None),
+                           arr("encode_xyz.frequency_bands"), arr("encode_dir.frequency_bands"))
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         check(lib.nm_mlp_create_ex(C.byref(d), C.byref(w), idx, PRECISIONS[precision], C.byref(self._h)), "nm_mlp_create_ex")

@@ -33,6 +33,20 @@ def param_names(num_layers):
 def refresh(mlp, params):
     """Re-pack `mlp` (hip_ops.HipMLP) from live device tensors: dict name -> CUDA fp32 tensor."""
     L = int(mlp.desc["num_layers"])
+    if not mlp.desc.get("use_viewdirs", True):
+        # models.py:77-79: fc_out (4, H) supplies the colour rows (0..2) and the density row (3), see nm_mlp_weights
+        names = ["layer1.weight", "layer1.bias", "fc_out.weight", "fc_out.bias"]
+        names += [f"layers_xyz.{i}.{k}" for i in range(L - 1) for k in ("weight", "bias")]
+        keep = {k: _dev32(params[k], mlp.device, k) for k in names}
+        p = lambda k: C.c_void_p(keep[k].data_ptr())  # noqa: E731
+        H = int(mlp.desc["hidden_size"])
+        xs_w = (C.c_void_p * (L - 1))(*[p(f"layers_xyz.{i}.weight") for i in range(L - 1)])
+        xs_b = (C.c_void_p * (L - 1))(*[p(f"layers_xyz.{i}.bias") for i in range(L - 1)])
+        ow, ob = keep["fc_out.weight"].data_ptr(), keep["fc_out.bias"].data_ptr()
+        w = MlpWeights(p("layer1.weight"), p("layer1.bias"), xs_w, xs_b, None, None, C.c_void_p(ow + 3 * H * 4),
+                       C.c_void_p(ob + 3 * 4), C.c_void_p(ow), C.c_void_p(ob), None, None, None, None)
+        check(_lib.load().nm_mlp_refresh(mlp.handle, C.byref(w), _stream()), "nm_mlp_refresh")
+        return
     keep = {k: _dev32(params[k], mlp.device, k) for k in param_names(L)}
     p = lambda k: C.c_void_p(keep[k].data_ptr())  # noqa: E731
     xs_w = (C.c_void_p * (L - 1))(*[p(f"layers_xyz.{i}.weight") for i in range(L - 1)])

@@ -116,6 +116,77 @@ def test_mlp_sample_points_vs_oracle(ops, kw, n):
     _close(got[:, 3], ref[:, 3], 2e-5 * scale, what="sigma")
 
 
+FLAT_CONFIGS = [
+    dict(use_viewdirs=False),                                                       # 8x256, trunk -> fc_out
+    dict(use_viewdirs=False, hidden_size=128, num_layers=6, skip_step=2, num_encoding_fn_xyz=6),
+    dict(use_viewdirs=False, hidden_size=64, num_layers=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=2),   # 2-slot dataflow
+]
+
+
+@pytest.mark.parametrize("kw", FLAT_CONFIGS)
+@pytest.mark.parametrize("n", [1, 777, 5000])
+def test_mlp_without_view_directions_vs_oracle(ops, kw, n):
+    """FlexibleNeRFModel(use_viewdirs=False) (models.py:52-55, 77-79): the trunk ends in fc_out (4 rows); the kernels' mode 2
+    evaluates its colour rows next to the density row.  Full output, density-only output, the ray-batch entry point and the
+    grid entry point against the oracle; no direction encoding is read (any num_encoding_fn_dir is accepted)."""
+    spec = O.MLPSpec(**kw)
+    w = S.make_mlp_weights(23, density_gain=40.0, density_bias=1.0, **kw)
+    desc = dict(_desc(spec), use_viewdirs=False)
+    mlp = ops.HipMLP(w, desc, "cuda")
+    assert mlp.flops_per_sample() == mlp.flops_per_sample(density_only=True) + 2 * 3 * spec.hidden_size
+    g = torch.Generator().manual_seed(n)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * 4.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    ref = O.mlp_forward(w, spec, pts, dirs)
+    got = mlp.sample_points(pts.cuda(), dirs.cuda())
+    scale = float(ref[:, 3].abs().max()) + 1.0
+    _close(got[:, :3], ref[:, :3], 2e-5, what="rgb")
+    _close(got[:, 3], ref[:, 3], 2e-5 * scale, what="sigma")
+    # rays: o + d t in the prologue
+    rays, samples = max(1, n // 7), 7
+    o = (torch.rand(rays, 3, generator=g) - 0.5) * 2.0
+    d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1)
+    t = torch.sort(torch.rand(rays, samples, generator=g) * 3.0, dim=-1).values
+    ray_pts = o[:, None, :] + d[:, None, :] * t[..., None]
+    ref_r = O.mlp_forward(w, spec, ray_pts.reshape(-1, 3), d[:, None, :].expand(rays, samples, 3).reshape(-1, 3))
+    got_r = mlp.eval_rays(o.cuda(), d.cuda(), t.cuda()).reshape(-1, 4)
+    _close(got_r[:, :3], ref_r[:, :3], 2e-5, what="rgb (rays)")
+    _close(got_r[:, 3], ref_r[:, 3], 2e-5 * (float(ref_r[:, 3].abs().max()) + 1.0), what="sigma (rays)")
+    if n == 777:
+        ax = torch.linspace(-1.2, 1.2, 9)
+        full = mlp.grid_query(ax, ax, ax, density_only=False)
+        dens = mlp.grid_query(ax, ax, ax, density_only=True)
+        assert torch.equal(full[:, 3], dens), "density-only and full evaluation share the trunk bit for bit"
+        grid = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3)
+        ref_g = O.mlp_forward(w, spec, grid, grid)
+        _close(full[:, :3], ref_g[:, :3], 2e-5, what="rgb (grid)")
+        _close(dens, ref_g[:, 3], 2e-5 * (float(ref_g[:, 3].abs().max()) + 1.0), what="sigma (grid)")
+
+
+def test_model_without_view_directions_follows_parameter_updates_and_refuses_training(ops):
+    """The nn.Module mirror: forward under no_grad runs the HIP path, an in-place parameter edit is picked up by the
+    on-device re-pack (nm_mlp_refresh with fc_out's rows), the differentiable path raises instead of falling back."""
+    from nerfmeshes_amd.nerf import FlexibleNeRFModel
+    torch.manual_seed(4)
+    kw = dict(num_layers=4, hidden_size=128, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4, use_viewdirs=False)
+    net = FlexibleNeRFModel(**kw).cuda()
+    spec = O.MLPSpec(**kw)
+    pts = (torch.rand(999, 3) - 0.5) * 3.0
+    with torch.no_grad():
+        a = net(pts.cuda())
+        w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        _close(a, O.mlp_forward(w, spec, pts, pts), 3e-5, what="fc_out network")
+        net.fc_out.weight.mul_(1.7)
+        net.fc_out.bias.add_(0.25)
+        net.layers_xyz[1].weight.mul_(0.9)
+        b = net(pts.cuda())
+        w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        _close(b, O.mlp_forward(w, spec, pts, pts), 3e-5, what="fc_out network after the update")
+        assert not torch.equal(a, b)
+    with pytest.raises(NotImplementedError, match="use_viewdirs=False"):
+        net(pts.cuda())
+
+
 def test_mlp_points_golden(ops):
     g = load_golden("mlp_8x256_points")
     w = gen_weights(g["seed"], g["gain"], g["bias"])
