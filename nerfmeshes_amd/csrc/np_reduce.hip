@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void np_finish_kernel(const float* __restrict_
     // accumulator.  The addends arrive 1024 at a time, one coalesced load per lane and 64 addends, the NEXT batch in
     // flight while the current one is added (a batch is ~2.5 us of chain, a load ~2 us for a lone wavefront), and reach the
     // chain one DPP addition each (np_chain64).  Measured per addend: lane 0 reading an LDS tile element by element 31
-    // cycles; v_readlane + v_add_f32 with a scalar operand 21; the DPP form: see DESIGN.md 3.3.  Wavefronts 1-3 fold the
+    // cycles; v_readlane + v_add_f32 with a scalar operand 21; the DPP form ~14 incl. the hand-over between batches.  Wavefronts 1-3 fold the
     // chunks' min / max (order-free) meanwhile.
     constexpr int U = 16;
     __shared__ float red[2][192];
