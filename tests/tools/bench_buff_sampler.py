@@ -39,7 +39,8 @@ u_pick = torch.rand(rays, samples, dtype=torch.float64, device=dev)
 u_pos = torch.rand(rays, samples, device=dev)
 out = {
     "rays": rays, "samples": samples, "voxels": int(tree.voxels.shape[0]),
-    "deterministic_stable_ms": timed(lambda: hip_ops.buff_intersect(tree.voxels, o, d, 0.0, 1.2, samples)),
+    "deterministic_stable_ms": timed(lambda: hip_ops.buff_intersect(tree.voxels, o, d, 0.0, 1.2, samples, ids="stable")),
+    "deterministic_reference_order_ms": timed(lambda: hip_ops.buff_intersect(tree.voxels, o, d, 0.0, 1.2, samples, ids="reference")),
     "random_given_draws_ms": timed(lambda: hip_ops.buff_intersect_random(tree.voxels, o, d, 0.0, 1.2, u_pick, u_pos)),
     "random_draws_ms": timed(lambda: (torch.rand(rays, samples, dtype=torch.float64, device=dev),
                                       torch.rand(rays, samples, device=dev))),
