@@ -893,7 +893,19 @@ extern "C" int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const f
                     if (dev >= 0 && dev < 64) attr[pass][dev] = lds;
                 }
             }
-            const int64_t want = 256 * 12;                // persistent: the LDS footprint admits ~9 rays per CU
+            // persistent, one wavefront per ray in flight, EXACTLY as many as are resident: the kernel is latency-bound (its
+            // time is inversely proportional to the rays in flight: 2 / 4 / 6 / 9 per CU -> 20.9 / 11.6 / 7.9 / 5.7 ms), and a
+            // grid a third larger than the residency (round 3's first version) ran 7.6 ms -- a second, mostly empty round.
+            // (More rays in flight would help further -- a 512-voxel tree, 6 KB per ray: 9 / 12 / 16 / 24 per CU -> 2.76 / 2.35 /
+            // 2.03 / 1.94 ms -- but keeping only the rightmost len / 2 + 2 right stoppers in a ring, 17.0 -> 15.2 KB per ray,
+            // did not get a tenth ray onto a CU and cost 5 % in the partition loop: not kept.)
+            int cus = 0, lds_cu = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds_cu < 65536) lds_cu = 65536;
+            const size_t granule = (lds + 1279) / 1280 * 1280;    // LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128)
+            int per_cu = (int)((size_t)lds_cu / granule);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu);
+            const int64_t want = (int64_t)cus * per_cu;
             const dim3 grid((unsigned)(rays < want ? rays : want));
             if (pass == 0)
                 hipLaunchKernelGGL(buff_reference_ids_kernel<REF_FAST_HITS>, grid, dim3(64), lds, stream, d_voxels, nvox, npad, spad,
