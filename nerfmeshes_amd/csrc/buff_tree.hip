@@ -898,7 +898,11 @@ extern "C" int nm_buff_intersect_ex(const float* d_voxels, int32_t nvox, const f
             // grid a third larger than the residency (round 3's first version) ran 7.6 ms -- a second, mostly empty round.
             // (More rays in flight would help further -- a 512-voxel tree, 6 KB per ray: 9 / 12 / 16 / 24 per CU -> 2.76 / 2.35 /
             // 2.03 / 1.94 ms -- but keeping only the rightmost len / 2 + 2 right stoppers in a ring, 17.0 -> 15.2 KB per ray,
-            // did not get a tenth ray onto a CU and cost 5 % in the partition loop: not kept.)
+            // did not get a tenth ray onto a CU and cost 5 % in the partition loop: not kept.  Nor was a register-resident
+            // version of the introsort loop for ranges of <= 64 elements (stopper lists as ballot masks, j-th stopper by bit
+            // select, swaps as cross-lane reads: bit-exact, 5.98 ms against 5.72): the per-call cost is the length of the
+            // dependent instruction chain, not the LDS round trips.  Phase shares (wall-clock counters): box test 6 %,
+            // sort 1 48 %, ranking 6 %, sort 2 18 %, sample placement 4 %, sort 3 18 %.)
             int cus = 0, lds_cu = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
             if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds_cu < 65536) lds_cu = 65536;
