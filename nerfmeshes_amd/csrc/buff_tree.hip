@@ -740,12 +740,24 @@ __global__ __launch_bounds__(64) void buff_reference_ids_kernel(const float* __r
         }
         __builtin_amdgcn_wave_barrier();
         // ---- sort 3 (tree.py:335): the sample depths ascending, every slot needed
-        WaveSort<CmpAsc> s3{p_z, p_ix, la, lb, stack, lane, CmpAsc(), eq_table};
-        s3.loop(samples, [](int, int) -> bool { return true; });
-        for (int j = lane; j < samples; j += 64) {
-            const int f = s3.final_slot(j, samples);
-            z_out[ray * samples + f] = p_z[j];
-            idx_out[ray * samples + f] = p_vid[p_ix[j]];
+        // The depths are placed bucket by bucket along the ray, so they usually arrive strictly increasing -- and a sequence
+        // of DISTINCT keys has one sorted order whatever the algorithm (an unstable sort only decides ties): the sort is
+        // then the identity.  Any tie, inversion or NaN takes the real thing.
+        bool rising = true;
+        for (int j = lane; j + 1 < samples; j += 64) rising = rising && (p_z[j] < p_z[j + 1]);
+        if (__ballot(!rising) == 0ull) {
+            for (int j = lane; j < samples; j += 64) {
+                z_out[ray * samples + j] = p_z[j];
+                idx_out[ray * samples + j] = p_vid[j];
+            }
+        } else {
+            WaveSort<CmpAsc> s3{p_z, p_ix, la, lb, stack, lane, CmpAsc(), eq_table};
+            s3.loop(samples, [](int, int) -> bool { return true; });
+            for (int j = lane; j < samples; j += 64) {
+                const int f = s3.final_slot(j, samples);
+                z_out[ray * samples + f] = p_z[j];
+                idx_out[ray * samples + f] = p_vid[p_ix[j]];
+            }
         }
         if (lane == 0) mask_out[ray] = K > 0 ? 1 : 0;
         __builtin_amdgcn_wave_barrier();
