@@ -318,7 +318,7 @@ def buff_intersect(voxels, origins, dirs, near, far, samples, ids="stable"):
     (z (R,S) f32, voxel ids (R,S) i64, ray_mask (R,) bool).  ids="stable" (default): every id is the voxel its
     sample lies in; ids="reference": ties ordered as the reference's three unstable torch.sort calls order them on
     the CPU (libstdc++ introsort, evaluated wave-parallel in the kernel) -- the reference's ids bit for bit; what
-    TreeSampling uses while training (tie_order="auto"), ~4x the stable order's time."""
+    TreeSampling uses while training (tie_order="auto"), ~3x the stable order's time."""
     if ids not in TIE_ORDERS:
         raise ValueError(f"ids must be one of {sorted(TIE_ORDERS)}, got {ids!r}")
     lib = _lib.load()
