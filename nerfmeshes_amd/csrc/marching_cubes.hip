@@ -925,6 +925,19 @@ __device__ __forceinline__ uint32_t cube_entry(const McLookup& lk, const McDims&
 //                         y edge {-1,0,-1, 5} {-1,0,0, 7} {0,0,-1, 1} {0,0,0, 3}
 //                         z edge {0,-1,-1,10} {0,-1,0,11} {0,0,-1, 9} {0,0,0, 8}
 // (selected per axis from immediates: k is a compile-time index once the loop over the cubes is unrolled).
+struct EdgeEnds { signed char a[3][4], b[3][4]; bool a_is_lo[3][4]; };     // [axis][k]: end corners (bitwise index) of the shared edge inside cube k
+constexpr EdgeEnds edge_ends_of_shared_cubes() {
+    constexpr signed char E[3][4] = {{6, 4, 2, 0}, {5, 7, 1, 3}, {10, 11, 9, 8}};     // the local edge ids of shared_cube below
+    EdgeEnds t{};
+    for (int ax = 0; ax < 3; ++ax)
+        for (int k = 0; k < 4; ++k) {
+            t.a[ax][k] = (signed char)MC_EDGE_A_[E[ax][k]];
+            t.b[ax][k] = (signed char)MC_EDGE_B_[E[ax][k]];
+            t.a_is_lo[ax][k] = MC_EDGE_A_[E[ax][k]] == MC_EDGE_LO_[E[ax][k]];
+        }
+    return t;
+}
+
 __device__ __forceinline__ void shared_cube(int axis, int k, int& dz, int& dy, int& dx, int& e) {
     constexpr signed char S[3][4][4] = {{{-1, -1, 0, 6}, {-1, 0, 0, 4}, {0, -1, 0, 2}, {0, 0, 0, 0}},
                                         {{-1, 0, -1, 5}, {-1, 0, 0, 7}, {0, 0, -1, 1}, {0, 0, 0, 3}},
@@ -1025,15 +1038,16 @@ __global__ __launch_bounds__(256) void mc_vertex_attributes(const float* __restr
             (void)sx;
             gx = (float)sz; gy = (float)sy; gz = 0.0f;   // skimage's centre gradient: (sum w*gz, sum w*gy, 0)
         } else {
-            const int i1 = edge_a(e), i2 = edge_b(e);
+            // the cube's local edge id is one of three compile-time values once k is unrolled (one per axis, shared_cube):
+            // its end corners are a 3-way select on the axis instead of an 8-way select on the corner (96 -> 24 v_cndmask)
+            constexpr EdgeEnds ET = edge_ends_of_shared_cubes();
+            const int qa0 = ET.a[0][k], qa1 = ET.a[1][k], qa2 = ET.a[2][k], qb0 = ET.b[0][k], qb1 = ET.b[1][k], qb2 = ET.b[2][k];
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    ga[a] = i1 == q ? g[3 * q + a] : ga[a];
-                    gb[a] = i2 == q ? g[3 * q + a] : gb[a];
-                }
-            const bool a_is_lo = i1 == edge_lo(e);     // end A of the cube's local edge = the edge's lower voxel?
+            for (int a = 0; a < 3; ++a) {
+                ga[a] = axis == 0 ? g[3 * qa0 + a] : (axis == 1 ? g[3 * qa1 + a] : g[3 * qa2 + a]);
+                gb[a] = axis == 0 ? g[3 * qb0 + a] : (axis == 1 ? g[3 * qb1 + a] : g[3 * qb2 + a]);
+            }
+            const bool a_is_lo = axis == 0 ? ET.a_is_lo[0][k] : (axis == 1 ? ET.a_is_lo[1][k] : ET.a_is_lo[2][k]);   // end A = the edge's lower voxel?
             s1 = a_is_lo ? s_lo : s_hi;
             s2 = a_is_lo ? s_hi : s_lo;
         }
