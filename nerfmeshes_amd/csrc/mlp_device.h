@@ -182,19 +182,39 @@ __device__ __forceinline__ void acc_to_operand(const f32x4 (&acc)[NT], float (&o
 // Positional encoding, laid out as MFMA B operands.  k-step s < STEPS-1 carries two encoding
 // arguments a0 = 2s, a1 = 2s+1 (a = coord * F + freq, the reference's coordinate-major order):
 // lane group 0: sin(a0)  1: cos(a0)  2: sin(a1)  3: cos(a1).  The last step carries (x, y, z, 0).
+// sincosf yields both halves, and a sin group and its cos group (lanes l, l ^ 16) want the two halves of the SAME
+// arguments: over a pair of k-steps (s, s + 1) the sin group evaluates the argument of step s, the cos group that of
+// step s + 1, each keeps the half it needs and hands the other across with one ds_swizzle -- 11 sincosf per lane for the
+// 8x256 network instead of 21, the same function on the same products, so the results are bit for bit what they were.
+// (Round 3: VALU issue time adds to matrix time -- DESIGN.md 3.1 -- and 58 % of a narrow network's VALU work was this.)
 template <int F, int STEPS, int ABL = 0>
 __device__ __forceinline__ void encode(float (&enc)[STEPS], const float (&x)[3], const float* bands, int g) {
     const bool hi = (g >> 1) != 0;
     const bool want_cos = (g & 1) != 0;
-#pragma unroll
-    for (int s = 0; s < STEPS - 1; ++s) {
+    constexpr int NS = STEPS - 1;
+    auto argument = [&](int s) -> float {      // what this lane's pair of groups encodes at k-step s (s: compile-time)
         const int a0 = 2 * s, a1 = 2 * s + 1;
         const float x0 = x[a0 / F] * bands[a0 % F];
         const float x1 = (a1 < 3 * F) ? x[(a1 < 3 * F ? a1 : 0) / F] * bands[(a1 < 3 * F ? a1 : 0) % F] : 0.0f;
+        return hi ? x1 : x0;
+    };
+#pragma unroll
+    for (int s = 0; s + 1 < NS; s += 2) {
+        const float mine = want_cos ? argument(s + 1) : argument(s);
         float sv, cv;
-        if constexpr (ABL & 1) { sv = hi ? x1 : x0; cv = sv + 1.0f; }
-        else sincosf(hi ? x1 : x0, &sv, &cv);
-        enc[s] = want_cos ? cv : sv;
+        if constexpr (ABL & 1) { sv = mine; cv = mine + 1.0f; }
+        else sincosf(mine, &sv, &cv);
+        const float give = want_cos ? sv : cv;
+        const float got = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(give), 0x401f));   // lane ^ 16
+        enc[s] = want_cos ? got : sv;
+        enc[s + 1] = want_cos ? cv : got;
+    }
+    if constexpr (NS % 2 == 1) {
+        float sv, cv;
+        const float mine = argument(NS - 1);
+        if constexpr (ABL & 1) { sv = mine; cv = mine + 1.0f; }
+        else sincosf(mine, &sv, &cv);
+        enc[NS - 1] = want_cos ? cv : sv;
     }
     enc[STEPS - 1] = g == 0 ? x[0] : (g == 1 ? x[1] : (g == 2 ? x[2] : 0.0f));
 }
