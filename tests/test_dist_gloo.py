@@ -64,6 +64,28 @@ def test_split_range_is_a_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+@pytest.mark.parametrize("n0", [2, 3, 7, 33, 480])
+@pytest.mark.parametrize("ws", [1, 2, 3, 8, 11])
+def test_slab_layers_cover_the_cube_layers_once_with_the_right_ghosts(n0, ws):
+    """Per-slab marching cubes (dist.slab_layers): the n0 - 1 cube layers are dealt out exactly once, in rank order; a
+    non-empty slab carries a ghost layer below unless it starts at layer 0 and one above unless it ends at the top, and
+    asks for exactly the voxel planes those layers touch; ranks beyond the layer count get empty slabs and no planes'
+    worth of work.  (The kernels behind it need a GPU: tests/test_gpu_mc.py, tests/test_gpu_dist.py.)"""
+    covered = []
+    for r in range(ws):
+        lo, hi, below, above, p_lo, p_hi = nd.slab_layers(n0, r, ws)
+        assert 0 <= lo <= hi <= n0 - 1
+        covered += list(range(lo, hi))
+        if hi == lo:
+            assert below == 0 and above == 0
+            continue
+        assert below == int(lo > 0) and above == int(hi < n0 - 1)
+        assert (p_lo, p_hi) == (lo - below, hi + 1 + above) and 0 <= p_lo and p_hi <= n0
+        # a slab with ghosts still has a cube layer of its own (nm_mc_count_slab's precondition)
+        assert (p_hi - p_lo) - 1 - below - above == hi - lo >= 1
+    assert covered == list(range(n0 - 1))
+
+
 def test_single_process_is_identity():
     assert nd.world() == (0, 1)
     out = nd.render_view_sharded(_fake_pixels, 10)
