@@ -163,6 +163,21 @@ def test_mlp_without_view_directions_vs_oracle(ops, kw, n):
         _close(dens, ref_g[:, 3], 2e-5 * (float(ref_g[:, 3].abs().max()) + 1.0), what="sigma (grid)")
 
 
+def test_mlp_without_view_directions_vs_reference_golden(ops):
+    """The kernels' mode 2 against outputs of the UNMODIFIED reference's FlexibleNeRFModel(use_viewdirs=False)
+    (tests/golden/mlp_flat_points.npz, three shapes incl. a 64-wide network on the 2-slot dataflow)."""
+    g = load_golden("mlp_flat_points")
+    pts = torch.from_numpy(g["points"]).cuda()
+    for tag in ("a", "b", "c"):
+        kw = {k: int(g[f"{k}_{tag}"]) for k in ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz", "num_encoding_fn_dir")}
+        kw["use_viewdirs"] = False
+        w = S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw)
+        got = ops.HipMLP(w, kw, "cuda").sample_points(pts, pts)
+        ref = g["radiance_" + tag]
+        _close(got[:, :3], ref[:, :3], 2e-5, what=f"rgb ({tag})")
+        _close(got[:, 3], ref[:, 3], 2e-5 * (float(np.abs(ref[:, 3]).max()) + 1.0), what=f"sigma ({tag})")
+
+
 def test_model_without_view_directions_follows_parameter_updates_and_refuses_training(ops):
     """The nn.Module mirror: forward under no_grad runs the HIP path, an in-place parameter edit is picked up by the
     on-device re-pack (nm_mlp_refresh with fc_out's rows), the differentiable path raises instead of falling back."""

@@ -64,6 +64,24 @@ def test_mlp_points_match_reference():
     np.testing.assert_allclose(out[:, 3], g["radiance"][:, 3], rtol=2e-5, atol=2e-3)  # sigma ~ 1e2
 
 
+def _flat_cases():
+    g = load_golden("mlp_flat_points")
+    for tag in ("a", "b", "c"):
+        kw = {k: int(g[f"{k}_{tag}"]) for k in ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz", "num_encoding_fn_dir")}
+        kw["use_viewdirs"] = False
+        w = S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw)
+        yield tag, kw, w, g["points"], g["radiance_" + tag]
+
+
+def test_mlp_without_view_directions_matches_reference():
+    """The oracle's use_viewdirs=False branch (models.py:52-55, 77-79) against the UNMODIFIED reference's
+    FlexibleNeRFModel(use_viewdirs=False) on three shapes (tests/golden/make_flat_golden.py): bit for bit -- it is the same
+    op sequence on the same library."""
+    for tag, kw, w, pts, ref in _flat_cases():
+        got = O.mlp_forward(w, O.MLPSpec(**kw), torch.from_numpy(pts), None)
+        assert np.array_equal(got.numpy(), ref), (tag, float(np.abs(got.numpy() - ref).max()))
+
+
 def test_grid_radiance_and_iso_match_reference():
     g = load_golden("grid_8x256_res20")
     w = gen_weights(g["seed"], g["gain"], g["bias"])
