@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 1
+/* 2 (round 3): + nm_mc_count_slab / nm_mc_emit_slab, nm_np_chunk_count / nm_np_chunk_sums / nm_np_finish, use_viewdirs = 0
+ * handles; nm_mc_workspace_bytes grew (per-cube decision table, cut-cube list).  Everything in version 1 is unchanged. */
+#define NM_ABI_VERSION 2
 
 const char* nm_last_error(void);
 int nm_abi_version(void);
