@@ -41,7 +41,7 @@ def test_c_program_through_the_c_abi(tmp_path):
     res = subprocess.run([str(exe), str(tmp_path / "weights.bin"), str(tmp_path / "points.bin"), str(n), str(tmp_path / "out.bin")],
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
-    assert "abi 1" in res.stdout
+    assert "abi 2" in res.stdout
     blob = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     assert blob.size == n * (4 + 4 + 64 + 4)
     got, taped, d_h0, d_last = np.split(blob, [4 * n, 8 * n, 8 * n + 64 * n])
