@@ -1245,8 +1245,13 @@ int nm_mc_emit_slab(const float* d_volume, int32_t n0, int32_t n1, int32_t n2, d
                     int32_t ghost_below, int32_t ghost_above, void* d_workspace, void* d_vertex_scratch, int64_t vertices,
                     int64_t faces, int64_t ghost_vertices, int64_t ghost_faces, int64_t index_base, float* d_verts,
                     int32_t* d_faces, float* d_normals, float* d_values, void* stream_) {
-    NM_REQUIRE(d_volume && d_workspace && d_vertex_scratch && d_verts && d_faces && d_normals && d_values, "bad argument");
+    NM_REQUIRE(d_volume && d_workspace && d_vertex_scratch, "bad argument");
     NM_REQUIRE(ghost_vertices >= 0 && ghost_vertices <= vertices && ghost_faces >= 0 && ghost_faces <= faces, "mc slab: bad ghost counts");
+    // a slab whose only vertices belong to the ghost layer below (the surface's topmost tip ends inside that layer) owns
+    // nothing: its output arrays have no elements and their pointers may be null
+    NM_REQUIRE(vertices == ghost_vertices || (d_verts && d_normals && d_values), "mc slab: null vertex outputs");
+    NM_REQUIRE(faces == ghost_faces || d_faces, "mc slab: null face output");
+    if (vertices == ghost_vertices && faces == ghost_faces) return 0;
     NM_REQUIRE(index_base + vertices < (int64_t(1) << 31) && index_base + ghost_vertices >= 0, "mc slab: vertex ids do not fit int32");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (vertices == 0) return 0;

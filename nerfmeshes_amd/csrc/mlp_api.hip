@@ -261,6 +261,14 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     NM_REQUIRE(d.skip_step >= 1, "skip_step must be >= 1");
     NM_REQUIRE(d.num_encoding_fn_xyz <= MAX_FREQ_XYZ && d.num_encoding_fn_dir <= MAX_FREQ_DIR, "too many encoding fns");
     // a network without view directions has no direction encoding: any instantiated kernel of that width / xyz encoding runs it
+    // every tensor the packer will read, checked before anything dereferences one
+    NM_REQUIRE(w->layer1_w && w->layer1_b && w->fc_alpha_w && w->fc_alpha_b && w->fc_rgb_w && w->fc_rgb_b, "missing weight tensor");
+    NM_REQUIRE(no_view || (w->fc_feat_w && w->fc_feat_b && w->layers_dir0_w && w->layers_dir0_b), "missing view-branch weight tensor");
+    NM_REQUIRE(w->layers_xyz_w && w->layers_xyz_b, "missing layers_xyz tensor tables");
+    for (int i = 0; i < d.num_layers - 1; ++i)
+        NM_REQUIRE(w->layers_xyz_w[i] && w->layers_xyz_b[i], "missing layers_xyz weight tensor");
+    NM_REQUIRE(d.num_encoding_fn_xyz == 0 || w->freq_xyz, "missing xyz frequency bands");
+    NM_REQUIRE(no_view || d.num_encoding_fn_dir == 0 || w->freq_dir, "missing direction frequency bands");
     const MlpPlan* plan = find_mlp_plan(d.hidden_size, d.num_encoding_fn_xyz, no_view ? 4 : d.num_encoding_fn_dir);
     if (!plan) {
         set_error("no gfx950 kernel instantiated for hidden_size=" + std::to_string(d.hidden_size) +
@@ -411,8 +419,6 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         stage(T_XYZ0 + 2 * i, w->layers_xyz_w[i], (size_t)H * (H + (is_skip(d, i) ? dx : 0)));
         stage(T_XYZ0 + 2 * i + 1, w->layers_xyz_b[i], H);
     }
-    NM_REQUIRE(w->layer1_w && w->layer1_b && w->fc_alpha_w && w->fc_alpha_b && w->fc_rgb_w && w->fc_rgb_b, "missing weight tensor");
-    NM_REQUIRE(no_view || (w->fc_feat_w && w->fc_feat_b && w->layers_dir0_w && w->layers_dir0_b), "missing view-branch weight tensor");
     stage(T_ALPHAW, w->fc_alpha_w, H); stage(T_ALPHAB, w->fc_alpha_b, 1);
     if (no_view) stage(T_RGBW, w->fc_rgb_w, (size_t)3 * H);
     else {

@@ -28,6 +28,8 @@
 // kernel issues 9 280 MFMAs (1 024 MAC each) per 16-sample tile = 99.9 % useful work.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "nm_internal.h"
 #include "mlp_device.h"
 #include "mlp_device_r3.h"
@@ -175,11 +177,16 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + rgb_floats) * 4 + 255) & ~255) : 0);
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     // the dynamic-LDS attribute is per device: tracked per (device, plan)
+    // (two host threads creating / launching models race on it otherwise: the table is read and written under a lock)
     static int attr_bytes[64][2 * sizeof(g_plans) / sizeof(g_plans[0])] = {};
+    static std::mutex attr_lock;
     const int idx = 2 * (int)(p - g_plans) + (density_only == 2 ? 1 : 0), dev = (m->device >= 0 && m->device < 64) ? m->device : 0;
-    if (attr_bytes[dev][idx] < lds_bytes) {
-        NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_bytes[dev][idx] = lds_bytes;
+    {
+        std::lock_guard<std::mutex> hold(attr_lock);
+        if (attr_bytes[dev][idx] < lds_bytes) {
+            NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            attr_bytes[dev][idx] = lds_bytes;
+        }
     }
     const int64_t wg_iters = (args.n + p->wg_samples - 1) / p->wg_samples;
     const int64_t resident = (int64_t)m->num_cus * p->wg_per_cu;   // workgroups co-resident on the chip

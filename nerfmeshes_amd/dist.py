@@ -94,6 +94,18 @@ def all_reduce(t, op=None):
     return t
 
 
+def broadcast(t, src=0):
+    """`dist.broadcast(t, src)` in place; device tensors under gloo go through the host."""
+    dist = _dist()
+    if _via_host(t):
+        host = t.cpu()
+        dist.broadcast(host, src=src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def round_robin_counts(n, world_size):
     """Items per rank when item i goes to rank i % world_size."""
     return [len(range(r, n, world_size)) for r in range(world_size)]
@@ -114,7 +126,9 @@ def slab_range(n0, rank, world_size):
 def all_gather_rows(local, counts):
     """All-gather a ragged first dimension: `local` is this rank's (counts[rank], ...) tensor; returns the
     concatenation over ranks on every rank.  Equal shards take the single-collective fast path
-    (all_gather_into_tensor -> one RCCL ring over xGMI); ragged shards are padded to the largest."""
+    (all_gather_into_tensor -> one RCCL ring over xGMI); ragged shards are an all-gatherv (`all_gather_v`): every
+    rank's rows land in their slice of ONE exact-size output -- no padding to the largest shard, no copy afterwards: a
+    surface that lives in the middle slabs moves sum(counts) rows per rank, not world * max(counts)."""
     dist = _dist()
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
@@ -127,13 +141,29 @@ def all_gather_rows(local, counts):
     if len(set(counts)) == 1:
         out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
         return all_gather_into(out, local)
-    m = max(counts)
-    padded = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
-    padded[:local.shape[0]] = local
-    out = torch.empty((ws * m,) + tail, dtype=local.dtype, device=local.device)
-    all_gather_into(out, padded)
-    out = out.view((ws, m) + tail)
-    return torch.cat([out[r, :counts[r]] for r in range(ws)], 0)
+    return all_gather_v(local, counts)
+
+
+def all_gather_v(local, counts):
+    """The ragged case of `all_gather_rows` as an all-gatherv: ONE exact-size output (sum(counts) rows); rank r's rows are
+    broadcast from r straight into their slice of it (`counts` is known everywhere, so empty shards are simply skipped --
+    no zero-size collective).  Same calls under RCCL and gloo (gloo's own all_gather insists on equal sizes); device
+    tensors under gloo are staged through the host."""
+    dist = _dist()
+    rank, ws = world()
+    tail = tuple(local.shape[1:])
+    host = _via_host(local)
+    out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device="cpu" if host else local.device)
+    lo = 0
+    for r in range(ws):
+        hi = lo + counts[r]
+        if hi > lo:
+            piece = out[lo:hi]
+            if r == rank:
+                piece.copy_(local)
+            dist.broadcast(piece, src=r)
+        lo = hi
+    return out.to(local.device) if host else out
 
 
 def render_view_sharded(render_fn, num_rays):

@@ -311,6 +311,7 @@ def mlp_profile_read():
 
 
 TIE_ORDERS = {"stable": 0, "reference": 1}
+BUFF_REFERENCE_MAX_VOXELS = 8192      # nm_buff_intersect_ex(NM_TIES_REFERENCE): sort keys of every voxel per ray in LDS
 
 
 def buff_intersect(voxels, origins, dirs, near, far, samples, ids="stable"):

@@ -125,12 +125,25 @@ class TensorBoardLogger:
     def root_dir(self):
         return os.path.join(self.save_dir, self.name)
 
+    def _next_free_version(self):
+        taken = [int(d.split("_")[1]) for d in (os.listdir(self.root_dir) if os.path.isdir(self.root_dir) else [])
+                 if d.startswith("version_") and d.split("_")[1].isdigit()]
+        return max(taken) + 1 if taken else 0
+
     @property
     def version(self):
+        """`version_N` with N the next free index.  Under a launcher (one process per GPU) rank 0 picks it and the
+        others take rank 0's answer: every rank scanning the directory for itself races -- the first one through creates
+        `version_N/checkpoints` (PathParser.parse) and the next one then numbers itself N + 1."""
         if self._version is None:
-            taken = [int(d.split("_")[1]) for d in (os.listdir(self.root_dir) if os.path.isdir(self.root_dir) else [])
-                     if d.startswith("version_") and d.split("_")[1].isdigit()]
-            self._version = max(taken) + 1 if taken else 0
+            from . import dist as nd
+            rank, world, _ = nd.init_from_env()          # no-op without a launcher environment
+            if world > 1:
+                box = [self._next_free_version() if rank == 0 else None]
+                torch.distributed.broadcast_object_list(box, src=0)
+                self._version = box[0]
+            else:
+                self._version = self._next_free_version()
         return self._version
 
     @property
@@ -302,6 +315,27 @@ class Trainer:
         self._fire("on_validation_end")
         model.train(was_training)
 
+    @staticmethod
+    def _sync_replicas(model, nd, rank, world):
+        """What DDP does when it wraps a module, and what the gradient averaging below presupposes: every replica starts
+        from RANK 0's parameters and buffers (train_nerf.py builds the model from an unseeded generator unless
+        `--deterministic` is given, so the ranks' initial weights differ).  Then the ranks' random streams are moved
+        apart -- `--deterministic` seeds every rank alike and the loaders are not sharded, so identical streams would
+        have every rank draw the same rays of the same image and data parallelism would be a no-op: rank r continues from
+        `initial_seed + r` (ray sampling, perturbation, noise)."""
+        if world <= 1:
+            return
+        with torch.no_grad():
+            for t in list(model.parameters()) + list(model.buffers()):
+                nd.broadcast(t.data, src=0)
+        tree = getattr(model, "tree", None)      # BuFF: the voxel set and its running weights are replica state too
+        if tree is not None and getattr(tree, "memm", None) is not None:
+            nd.broadcast(tree.memm, src=0)
+        seed = int(torch.initial_seed()) + rank
+        random.seed(seed)
+        np.random.seed(seed % (1 << 32))
+        torch.manual_seed(seed)
+
     def fit(self, model):
         from . import dist as nd
         rank, world, device = nd.init_from_env()
@@ -309,6 +343,7 @@ class Trainer:
         self.model = model
         model.trainer, model.logger = self, self.logger
         model.to(device)
+        self._sync_replicas(model, nd, rank, world)
         model.setup("fit")                       # BaseModel.setup: datasets + min/max steps + validation period
         if self.logger is not None and rank == 0:
             self.logger.log_hyperparams(model.hparams)

@@ -151,6 +151,23 @@ def extract_geometry(model, device, args):
     return vertices, triangles, normals, density
 
 
+def _assemble_grid_from_slabs(slab, nums, device):
+    """The whole density grid from the slabs `--gather triangles` left on the ranks (only the mesh cache wants it): every
+    rank contributes the planes it accounts for -- the lower planes of its own cube layers, the last non-empty rank also the
+    top plane -- through ONE ragged all-gather; nothing is evaluated twice.  A rank without a cube layer (more ranks than
+    layers) holds no slab (None) and contributes nothing, but still enters the collective."""
+    from . import dist as nd
+    rank, world = nd.world()
+    n0, n1, n2 = nums
+    lo, hi, below, above, p_lo, p_hi = nd.slab_layers(n0, rank, world)
+    if slab is None or hi == lo:
+        own = torch.empty(0, n1, n2, dtype=torch.float32, device=device)
+    else:
+        top = hi + (1 if hi == n0 - 1 else 0)
+        own = slab.view(p_hi - p_lo, n1, n2)[lo - p_lo:top - p_lo]
+    return nd.all_gather_ragged(own.contiguous()).view(n0, n1, n2)
+
+
 def extract_geometry_with_super_sampling(model, device, args):
     raise NotImplementedError   # dead code in the reference as well (mesh_nerf.py:95-96)
 
@@ -171,8 +188,8 @@ def export_marching_cubes(model, args, cfg, device):
         print("Generating mesh geometry...")
         vertices, triangles, normals, density = extract_geometry(model, device, args)
         if cache_new or args.override_cache_mesh:
-            if nd.world()[1] > 1 and density.shape[0] != _nums(args.res)[0]:
-                density = extract_density(model, args, device, args.res)     # the cache holds the whole grid
+            if nd.world()[1] > 1 and getattr(args, "gather", "triangles") == "triangles":
+                density = _assemble_grid_from_slabs(density, _nums(args.res), device)   # the cache holds the whole grid
             if nd.world()[0] == 0:
                 torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(), density.cpu().numpy()), cache_path)
                 print(f"Cached mesh geometry saved to {cache_path}")

@@ -81,6 +81,12 @@ class TreeSampling:
         weights, restart the integration counter."""
         if self.memm is not None:
             tree = self.config.tree
+            from .. import dist as nd
+            if nd.world()[1] > 1:
+                # data-parallel training: every rank integrated its own rays; the refinement decision must be ONE
+                # decision (the replicas' voxel sets may not drift apart), taken on the mean of the ranks' running means
+                nd.all_reduce(self.memm)
+                self.memm /= nd.world()[1]
             memm = self.memm.detach().cpu()
             print(f"Min memm {memm.min()}\nMax memm {memm.max()}\nMean memm {memm.mean()}\nMedian memm {memm.median()}")
             print(f"Threshold {tree.eps}")
@@ -129,9 +135,25 @@ class TreeSampling:
             u_pos = torch.rand(shape, dtype=torch.float32, device=dev)
             return hip_ops.buff_intersect_random(self.voxels, origins, dirs, float(near), float(far), u_pick, u_pos)
         order = getattr(self, "tie_order", "auto")
-        if order == "auto":
+        auto = order == "auto"
+        if auto:
             order = "reference" if getattr(self, "training", False) else "stable"
+        if auto and order == "reference" and self.voxels.shape[0] > hip_ops.BUFF_REFERENCE_MAX_VOXELS:
+            order = self._fall_back_to_stable(f"{self.voxels.shape[0]} voxels > {hip_ops.BUFF_REFERENCE_MAX_VOXELS}")
         return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count), ids=order)
+
+    def _fall_back_to_stable(self, why):
+        """`tie_order = "auto"` beyond the reference-order kernel's limit of 8192 voxels (its per-ray LDS holds the sort
+        keys of every voxel; shipped configs: `tree.max_voxel_count` 1536): the stable order from here on, said once --
+        "auto" never turns that limit into a failure in the middle of a training run; an explicit
+        `tree.tie_order = "reference"` still raises.  (512 crossed voxels per ray is a limit of BOTH orders.)"""
+        if not getattr(self, "_warned_tie_fallback", False):
+            import warnings
+            warnings.warn(f"tree.tie_order=auto: the reference tie order is not available ({why}); using the stable order "
+                          "(the voxel ids then differ from the reference's, see DESIGN.md 3.4)")
+            self._warned_tie_fallback = True
+        self.tie_order = "stable"
+        return "stable"
 
     def serialize(self):
         return {"root": self.root, "voxels": self.voxels, "memm": self.memm, "counter": self.counter}

@@ -183,3 +183,85 @@ def test_init_from_env_gloo(monkeypatch):
     finally:
         nd.shutdown()
     assert not dist.is_initialized()
+
+
+# ---- all-gatherv: exact-size ragged gather, empty shards included ------------------------------
+def _ragged_job(rank, world):
+    counts = [5, 0, 2][:world] if world == 3 else [0, 4]
+    rows = torch.arange(counts[rank] * 3, dtype=torch.float32).reshape(counts[rank], 3) + 100.0 * rank
+    ids = torch.arange(counts[rank], dtype=torch.int32) + 1000 * rank
+    return nd.all_gather_rows(rows, counts).numpy(), nd.all_gather_ragged(ids).numpy()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_gather_v_places_ragged_and_empty_shards_exactly(world):
+    counts = [5, 0, 2] if world == 3 else [0, 4]
+    want_rows = np.concatenate([np.arange(c * 3, dtype=np.float32).reshape(c, 3) + 100.0 * r for r, c in enumerate(counts)])
+    want_ids = np.concatenate([np.arange(c, dtype=np.int32) + 1000 * r for r, c in enumerate(counts)])
+    for rows, ids in _run(_ragged_job, world=world):
+        assert rows.shape == (sum(counts), 3), "exact size: no padding to the largest shard"
+        assert np.array_equal(rows, want_rows) and np.array_equal(ids, want_ids)
+
+
+# ---- the Trainer stand-in under a launcher: identical replicas, distinct ray streams, one version dir ----
+def _fit_worker(rank, world, port, tmp, deterministic, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    from nerfmeshes_amd import lightning_compat as LC
+    nd.init_from_env(backend="gloo")
+    try:
+        if deterministic:
+            LC.seed_everything(42)          # train_nerf.py --deterministic: every rank seeds alike
+
+        class Toy(LC.LightningModule):
+            def __init__(self):
+                super().__init__()
+                self.hparams = {"toy": 1}
+                self.net = torch.nn.Linear(4, 3)          # unseeded unless --deterministic: differs per rank
+                self.register_buffer("stat", torch.rand(2))
+                self.seen = []
+
+            def setup(self, stage):
+                self.trainer.max_steps = 6
+
+            def configure_optimizers(self):
+                return torch.optim.SGD(self.parameters(), lr=0.1)
+
+            def train_dataloader(self):
+                return [torch.zeros(1) for _ in range(6)]
+
+            def training_step(self, batch, batch_idx):
+                x = torch.rand(8, 4)                      # the "random rays" of this rank
+                self.seen.append(x.clone())
+                return {"loss": self.net(x).pow(2).mean(), "log": {}}
+
+        logger = LC.TensorBoardLogger(tmp, "run")
+        os.makedirs(os.path.join(logger.log_dir, "checkpoints"), exist_ok=True)      # what PathParser.parse does next
+        model = Toy()
+        first = [p.detach().clone() for p in model.parameters()]
+        LC.Trainer(logger=logger, max_epochs=1).fit(model)
+        out[rank] = {"version": logger.version, "first": [p.numpy() for p in first], "stat": model.stat.numpy(),
+                     "params": [p.detach().numpy() for p in model.parameters()], "rays": torch.stack(model.seen).numpy()}
+    finally:
+        nd.shutdown()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_trainer_fit_keeps_two_replicas_identical_on_different_rays(tmp_path, deterministic):
+    """`train_nerf` under `torch.distributed.run`: rank 0's initial weights and buffers reach every rank (DDP's broadcast),
+    so gradient averaging keeps the replicas equal step after step; the ranks draw DIFFERENT rays even when
+    `--deterministic` seeded them alike; and all ranks log into the version directory rank 0 picked."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path), deterministic, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["version"] == b["version"] == 0
+    assert sorted(os.listdir(tmp_path / "run")) == ["version_0"]
+    if not deterministic:
+        assert any(not np.array_equal(x, y) for x, y in zip(a["first"], b["first"])), "the test needs replicas that start apart"
+    for x, y in zip(a["params"], b["params"]):
+        assert np.array_equal(x, y), "replicas diverged"
+    assert np.array_equal(a["stat"], b["stat"])
+    assert any(not np.array_equal(x, y) for x, y in zip(a["params"], a["first"])), "no training happened"
+    assert not np.array_equal(a["rays"], b["rays"]), "both ranks drew the same rays: data parallelism would be a no-op"

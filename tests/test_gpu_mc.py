@@ -81,7 +81,6 @@ def test_mc_slabs_concatenate_to_the_whole_mesh(ops, shape, parts, kind):
     """Per-slab marching cubes (nm_mc_count_slab / nm_mc_emit_slab): the cube layers of a volume are cut into `parts` slabs,
     every slab is meshed on its own from its planes plus one ghost plane on either side, and the slabs' arrays concatenated
     in order ARE the mesh of the whole volume -- vertices, faces with their vertex numbering, normals, values, bitwise."""
-    from nerfmeshes_amd import dist as nd
     rng = np.random.default_rng(hash((shape, kind, parts)) % (2 ** 32))
     if kind == "noise":
         vol, iso = rng.standard_normal(shape).astype(np.float32), 0.1
@@ -92,10 +91,20 @@ def test_mc_slabs_concatenate_to_the_whole_mesh(ops, shape, parts, kind):
         vol, iso = (np.sin(3 * g[..., 0]) * np.cos(2 * g[..., 1]) + g[..., 2] ** 2 - 0.3).astype(np.float32), float(np.float32(0.05))
     full = torch.from_numpy(vol).cuda()
     try:
-        want = ops.marching_cubes(full, iso)
+        want = mc_oracle.marching_cubes(vol, iso)                      # the C oracle, not the HIP whole-grid path
     except (RuntimeError, ValueError):
         pytest.skip("no surface in this volume")
-    layers = shape[0] - 1
+    got = _slab_mesh(ops, full, iso, parts)
+    for name, a, b in zip(("vertices", "faces", "normals", "values"), got, want):
+        assert _same(a, b), f"{shape} {kind} x{parts}: {name} differ from the C oracle's whole-grid mesh"
+    whole = ops.marching_cubes(full, iso)                              # and the whole-grid HIP call agrees with both
+    for name, a, b in zip(("vertices", "faces", "normals", "values"), got, whole):
+        assert a.shape == b.shape and torch.equal(a, b), f"{shape} {kind} x{parts}: {name} differ from nm_mc_emit"
+
+
+def _slab_mesh(ops, full, iso, parts):
+    from nerfmeshes_amd import dist as nd
+    layers = full.shape[0] - 1
     pieces, base = [], 0
     for r in range(parts):
         lo, hi = nd.split_range(layers, r, parts)
@@ -106,9 +115,29 @@ def test_mc_slabs_concatenate_to_the_whole_mesh(ops, shape, parts, kind):
         slab = ops.marching_cubes_slab(sub, iso, lo - below, below, above)
         pieces.append(slab.emit(base - slab.ghost_vertices))
         base += slab.vertices
-    got = [torch.cat([p[i] for p in pieces], 0) for i in range(4)]
+    return [torch.cat([p[i] for p in pieces], 0) for i in range(4)]
+
+
+@pytest.mark.parametrize("tip", [3.2, 3.5, 3.9, 4.0, 4.3])
+def test_mc_slab_whose_only_vertices_lie_in_the_ghost_layer(ops, tip):
+    """the surface's topmost tip ends inside the last cube layer of the LOWER slab.  The upper slab then counts
+    vertices in its ghost layer only -- it owns none, its output arrays have no elements (null pointers) -- and must
+    return an empty piece instead of failing with 'bad argument' (which would leave the other ranks waiting in the
+    triangle all-gather)."""
+    n0, n1, n2 = 9, 8, 8
+    z, y, x = np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2), indexing="ij")
+    vol = (tip - z - 0.15 * np.hypot(y - 3.4, x - 3.6)).astype(np.float32)       # a cone whose apex sits at height `tip`
+    want = mc_oracle.marching_cubes(vol, 0.0)
+    full = torch.from_numpy(vol).cuda()
+    lo, hi = 4, 8                                                       # upper slab: cube layers 4..7, ghost layer 3 below
+    upper = ops.marching_cubes_slab(full[lo - 1:hi + 1].contiguous(), 0.0, lo - 1, 1, 0)
+    if tip < 4.0:
+        assert upper.ghost_vertices > 0 and upper.vertices == 0 and upper.faces == 0
+    v, f, nrm, val = upper.emit(123)
+    assert v.shape == (upper.vertices, 3) and f.shape == (upper.faces, 3)
+    got = _slab_mesh(ops, full, 0.0, 2)
     for name, a, b in zip(("vertices", "faces", "normals", "values"), got, want):
-        assert a.shape == b.shape and torch.equal(a, b), f"{shape} {kind} x{parts}: {name} differ"
+        assert _same(a, b), f"tip {tip}: {name} differ"
 
 
 def test_mc_errors(ops):
