@@ -309,6 +309,26 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
     scale = float(ref[:, 3].abs().max()) + 1.0
     out["grid_query"]["parity"] = {"max_abs_dsigma_over_scale": float((got[:, 3] - ref[:, 3]).abs().max()) / scale,
                                    "max_abs_drgb": float((got[:, :3] - ref[:, :3]).abs().max()), "points": int(pts.shape[0])}
+    # ---- end-to-end topology against the CPU path (mesh_nerf.py:73-79) at a size the oracle's grid takes seconds for:
+    # HIP grid -> GPU iso level -> nm_mc_* vs oracle grid -> numpy iso level -> C marching cubes
+    from oracle import parity
+    tres = 128
+    tax = torch.linspace(-limit, limit, tres).to(dev)
+    tgrid = fine.grid_query(tax, tax, tax, density_only=True).view(tres, tres, tres)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tiso = float(extract_iso_level(tgrid, _A))
+    tmesh = [t.cpu().numpy() for t in hip_ops.marching_cubes(tgrid, tiso)]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        rgrid = O.extract_radiance(weights, spec, limit, tres)[..., 3]
+        dt = time.perf_counter() - t0
+    riso = float(O.iso_level(rgrid, iso_request))
+    topo = parity.mesh_topology(tgrid.cpu().numpy(), rgrid, tiso, riso, tmesh, mc_oracle.marching_cubes(np.ascontiguousarray(rgrid), riso))
+    topo["cpu_grid_s"] = dt
+    out["parity"] = {"topology": topo,
+                     "note": f"end to end at {tres}^3: the HIP density grid meshed by nm_mc_* vs the oracle's CPU grid meshed by the C oracle, "
+                             "each at its own adaptive iso level; on an identical grid the two marching cubes agree bitwise (marching_cubes."
+                             "bitwise_identical_to_oracle)"}
     return out
 
 
@@ -402,6 +422,86 @@ def buff_probe(dev, cpu_rays=2048, rank=0, world=1, use_dist=False, cpu_legs=Tru
                            "kind": "port", "sample": f"{dc.shape[0]} strided rays of the view, chunks of 1024, {dt:.1f} s"}
     out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     out["parity"] = parity.psnr_parity(got, ref, chunk=1024)
+    return out
+
+
+def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=2, cpu_size=80, cpu_legs=True):
+    """BASELINE config 3 at N = 1 (`eval_nerf.py` over a test set, /root/reference/src/eval_nerf.py:50-105): `views` orbit
+    views of 800x800 through the eval_nerf mirror (`eval_views`: per-view loss = sum of per-2048-ray-chunk MSEs divided by
+    the FLOAT batch count 312.5, dataset loss = mean over views, PSNR of that), every view scored against a seeded noisy
+    photograph of itself (~34 dB, the regime a trained NeRF is scored in).  Parity leg: `cpu_views` small views rendered by
+    the oracle on the host, scored by the oracle's bookkeeping, against the same views through the mirror."""
+    import contextlib, io
+    from nerfmeshes_amd import eval_nerf as E, models
+    from nerfmeshes_amd.nerf import CfgNode
+    from nerfmeshes_amd.models.model_helpers import nest_dict
+    hp = S.hparams()
+    model = models.NeRFModel(hp)
+    sd = model.state_dict()
+    for k, v in weights.items():
+        sd["model_coarse." + k] = torch.from_numpy(v)
+        sd["model_fine." + k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model = model.eval().to(dev)
+    cfg = CfgNode(nest_dict(hp, sep="."))
+    gen = torch.Generator(device=dev)
+
+    def photograph(view_nr, rgb):       # the view's own render + seeded noise, clamped: PSNR ~ 34 dB by construction
+        gen.manual_seed(1000 + view_nr)
+        return (rgb + 0.02 * torch.randn(rgb.shape, generator=gen, device=dev)).clamp_(0.0, 1.0)
+
+    def run(n):
+        vs = [(pose, H, W, S.LEGO_FOCAL_800, photograph) for pose in S.orbit_poses(n)]
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            return E.eval_views(model, vs, cfg, dev, render_chunk=render_chunk)
+
+    run(1)
+    torch.cuda.synchronize()
+    hip_ops.mlp_profile_enable(True)
+    hip_ops.mlp_profile_read()
+    t0 = time.perf_counter()
+    losses, total, psnr, _ = run(views)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    launches, kernel_ms, kernel_flops = hip_ops.mlp_profile_read()
+    hip_ops.mlp_profile_enable(False)
+    achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    out = {"workload": f"config 3 at N = 1: {views} orbit views of 800x800 through the eval_nerf mirror (eval_views), 8x256 coarse+fine, 64+128, "
+                       f"rays generated in the kernels, rendered in calls of {render_chunk} rays, loss bookkeeping per 2048 rays / float batch_count 312.5",
+           "value": views * H * W / wall, "unit": "rays/s", "views": views, "ms_per_view": wall / views * 1e3,
+           "dataset_loss_mse": float(total), "dataset_psnr_db": float(psnr),
+           "per_view_psnr_db_min_max": [float(min(-10.0 * torch.log10(l) for l in losses)), float(max(-10.0 * torch.log10(l) for l in losses))],
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "launches": launches,
+                        "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / wall}}
+    if not cpu_legs:
+        return out
+    from oracle import nerf_oracle as O, parity
+    spec, rs = O.MLPSpec(**MLP_KW), O.RenderSpec(num_coarse=NUM_COARSE, num_fine=NUM_FINE)
+    focal = S.LEGO_FOCAL_800 * cpu_size / 800.0
+    small, ref_losses = [], []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i, pose in enumerate(S.orbit_poses(views)[:: max(1, views // cpu_views)][:cpu_views]):
+            o, d = O.get_ray_bundle(cpu_size, cpu_size, focal, torch.from_numpy(pose))
+            d = d.reshape(-1, 3)
+            ref = torch.cat([O.render(weights, weights, spec, spec, rs, o[None], d[s0:s0 + 2048], NEAR, FAR)[1]["rgb_map"]
+                             for s0 in range(0, d.shape[0], 2048)])
+            tgt = parity.noisy_targets(ref, seed=parity.TARGET_SEED + i)
+            ref_losses.append(O.view_loss(ref, tgt, 2048))
+            small.append((pose, cpu_size, cpu_size, focal, tgt))
+    dt = time.perf_counter() - t0
+    ref_total = O.dataset_loss(ref_losses)
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        got_losses, got_total, got_psnr, _ = E.eval_views(model, small, cfg, dev)
+    rays = cpu_views * cpu_size * cpu_size
+    out["cpu_baseline"] = {"value": rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
+                           "sample": f"{cpu_views} views of {cpu_size}x{cpu_size} ({rays} rays; batch_count {cpu_size * cpu_size / 2048}), chunks of 2048, {dt:.1f} s"}
+    out["parity"] = {"views": cpu_views, "rays_per_view": cpu_size * cpu_size, "float_batch_count": cpu_size * cpu_size / 2048,
+                     "dataset_psnr_ref_db": float(O.mse2psnr(ref_total)), "dataset_psnr_hip_db": float(got_psnr),
+                     "abs_dpsnr_db": abs(float(O.mse2psnr(ref_total)) - float(got_psnr)),
+                     "per_view_abs_dpsnr_db": [abs(float(O.mse2psnr(a)) - float(O.mse2psnr(b.cpu()))) for a, b in zip(ref_losses, got_losses)],
+                     "targets": "oracle render + N(0,0.02) PCG64, per view; HIP and oracle scored against the same targets by their own bookkeeping"}
     return out
 
 
@@ -516,11 +616,13 @@ def main():
     ap.add_argument("--no-buff-probe", action="store_true")
     ap.add_argument("--no-b3-probe", action="store_true")
     ap.add_argument("--no-tiny-probe", action="store_true")
+    ap.add_argument("--no-eval-probe", action="store_true")
+    ap.add_argument("--eval-views", type=int, default=20)
     ap.add_argument("--headline-only", action="store_true", help="skip every secondary object and the CPU legs")
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline = args.no_train_probe = args.no_mesh_probe = args.no_buff_probe = args.no_b3_probe = True
-        args.no_tiny_probe = True
+        args.no_tiny_probe = args.no_eval_probe = True
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback exists for the hot path)")
@@ -717,7 +819,8 @@ def main():
         if rank == 0:
             out[name] = res
     # ... and single-GPU objects
-    for name, skip, fn in (("tiny", args.no_tiny_probe, lambda: tiny_probe(dev, cpu_legs)),
+    for name, skip, fn in (("eval", args.no_eval_probe, lambda: eval_probe(dev, weights, views=args.eval_views, cpu_legs=cpu_legs)),
+                           ("tiny", args.no_tiny_probe, lambda: tiny_probe(dev, cpu_legs)),
                            ("train", args.no_train_probe, lambda: train_probe(dev, views[0][1], views[0][0])),
                            ("bf16x3", args.no_b3_probe,
                             lambda: b3_probe(dev, weights, views, near, far, u_c, u_f, args.chunk, ref_idx, ref_rgb))):

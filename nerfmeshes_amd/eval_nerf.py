@@ -126,10 +126,13 @@ def eval_nerf(model, config_args, cfg, device):
     return total_loss
 
 
-def eval_views(model, views, cfg, device="cuda", chunksize=None):
+def eval_views(model, views, cfg, device="cuda", chunksize=None, render_chunk=None):
     """The same bookkeeping over an iterable of `(c2w pose, height, width, focal, targets | None)` -- e.g.
     `synthetic_views()` -- with ray directions generated on the GPU.  Returns (per-view losses, dataset loss, dataset
-    PSNR, last rgb map)."""
+    PSNR, last rgb map).  `targets` may be a callable `(view_nr, rgb) -> (rays, 3) targets` (bench.py photographs the
+    render itself).  `render_chunk` renders in larger calls than the bookkeeping's `chunksize` -- the pixels do not depend
+    on the chunking (tests/test_gpu_parity.py::test_full_size_view_properties), the loss is still summed per `chunksize`
+    rays and divided by the float batch count."""
     chunksize = chunksize or cfg.nerf.validation.chunksize
     bounds = torch.tensor([cfg.dataset.near, cfg.dataset.far], dtype=torch.float32)
     from . import dist as nd
@@ -144,7 +147,9 @@ def eval_views(model, views, cfg, device="cuda", chunksize=None):
             scored[owner] += 1
         if owner != rank:
             continue
-        rgb, _ = render_view(model, pose, h, w, focal, bounds, chunksize, device)
+        rgb, _ = render_view(model, pose, h, w, focal, bounds, render_chunk or chunksize, device)
+        if callable(targets):
+            targets = targets(view_nr, rgb)
         if targets is not None:
             targets = targets.to(device)
             batch_count = rgb.shape[0] / chunksize              # float: 640000 / 2048 = 312.5 (eval_nerf.py:57)

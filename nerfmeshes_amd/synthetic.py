@@ -139,6 +139,27 @@ def make_scene_weights(seed=SCENE_SEED, **mlp_kwargs):
     return w
 
 
+# The same construction for the narrower shipped shapes (round 4: strict-bar PSNR fixtures for them): shape -> (network
+# arguments, raw fc_alpha mean / std of the band-limited draw along orbit rays -- tests/golden/calibrate_scene.py --, gain).
+SMOOTH_SCENES = {
+    "fern_8x128": (dict(num_layers=8, hidden_size=128, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4),
+                   0.117229, 0.008811, 6.0e4),          # config/nerf-colmap-fern.yml:115,152
+    "tiny_4x64": (dict(num_layers=4, hidden_size=64, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
+                  0.011192, 0.008393, 6.4e4),           # BASELINE configs[0]: 4-layer x 64
+}
+
+
+def make_smooth_scene_weights(name, seed=SCENE_SEED):
+    """(weights, network arguments) of the smooth scene for one of SMOOTH_SCENES' shapes: the seeded draw, band-limited,
+    fc_alpha rescaled so that sigma = gain * (raw - mean - std) + SCENE_BIAS (positive on roughly a sixth of the volume)."""
+    kw, raw_mean, raw_std, gain = SMOOTH_SCENES[name]
+    w = band_limit(make_mlp_weights(seed, **kw), SCENE_DECAY, **kw)
+    g = np.float32(gain)
+    w["fc_alpha.weight"] = w["fc_alpha.weight"] * g
+    w["fc_alpha.bias"] = ((w["fc_alpha.bias"] - np.float32(raw_mean + raw_std)) * g + np.float32(SCENE_BIAS)).astype(np.float32)
+    return w, dict(kw)
+
+
 def hparams(model="NeRFModel", hidden_size=256, num_layers=8, skip_step=4, num_encoding_fn_xyz=10,
             num_encoding_fn_dir=4, num_coarse=64, num_fine=128, use_fine=True, near=2.0, far=6.0,
             white_background=False, lindisp=False, chunksize=2048, dataset_type="blender", use_ndc=False,

@@ -101,3 +101,42 @@ def explain_outliers(err, ref_coarse, ref_fine, t_got, rgb_on_ref_depths, tol=1e
             out["unexplained"] += 1
             out["unexplained_rays"].append(int(r))
     return out
+
+
+def mesh_topology(grid_hip, grid_ref, iso_hip, iso_ref, mesh_hip, mesh_ref):
+    """End-to-end mesh parity of `mesh_nerf` (/root/reference/src/mesh_nerf.py:73-79): the density grid computed by the
+    path under test vs the grid the CPU reference computes, each meshed at its OWN adaptive iso level by its own marching
+    cubes.  On an identical grid the two marching cubes agree bitwise (tests/test_gpu_mc.py); what remains is the grid:
+    a voxel whose fp32 density lies within round-off of the iso level may fall on the other side, and every such sign
+    flip changes the tiling of the <= 8 cubes around it.  Reports the flips, the cubes whose 8-bit corner pattern differs
+    (= the cubes whose tiling can differ), |dV|, |dF|, and checks the stated budget: isolated cubes only.
+    grids: (n0,n1,n2) fp32 arrays; meshes: (vertices, faces, ...) array tuples."""
+    a, b = np.asarray(grid_hip, dtype=np.float32), np.asarray(grid_ref, dtype=np.float32)
+    assert a.shape == b.shape and a.ndim == 3
+    inside_a, inside_b = a > np.float32(iso_hip), b > np.float32(iso_ref)        # skimage's test: value > level
+    flips = inside_a != inside_b
+
+    def patterns(m):
+        m = m.astype(np.uint8)
+        p = np.zeros(tuple(s - 1 for s in m.shape), dtype=np.uint8)
+        for bit, (dz, dy, dx) in enumerate(((0, 0, 0), (0, 0, 1), (0, 1, 1), (0, 1, 0), (1, 0, 0), (1, 0, 1), (1, 1, 1), (1, 1, 0))):
+            p |= m[dz:m.shape[0] - 1 + dz, dy:m.shape[1] - 1 + dy, dx:m.shape[2] - 1 + dx] << bit
+        return p
+
+    pa, pb = patterns(inside_a), patterns(inside_b)
+    cut = int(((pb != 0) & (pb != 255)).sum())
+    differ = int((pa != pb).sum())
+    scale = float(np.abs(b).max()) + 1.0
+    nv_a, nf_a, nv_b, nf_b = mesh_hip[0].shape[0], mesh_hip[1].shape[0], mesh_ref[0].shape[0], mesh_ref[1].shape[0]
+    out = {
+        "grid": list(a.shape), "iso_hip": float(iso_hip), "iso_ref": float(iso_ref), "iso_equal": bool(np.float32(iso_hip) == np.float32(iso_ref)),
+        "max_abs_dsigma_over_scale": float(np.abs(a - b).max()) / scale,
+        "sign_flips_at_iso": int(flips.sum()), "voxels": int(a.size),
+        "cubes_cut_by_the_surface": cut, "cubes_whose_corner_pattern_differs": differ,
+        "vertices_hip": int(nv_a), "vertices_ref": int(nv_b), "abs_dV": abs(int(nv_a) - int(nv_b)),
+        "faces_hip": int(nf_a), "faces_ref": int(nf_b), "abs_dF": abs(int(nf_a) - int(nf_b)),
+        "budget": "sign flips <= 1e-5 of the voxels; differing cubes <= 8 per flip and <= 1e-3 of the cut cubes; |dV| <= 1e-3 V; |dF| <= 1e-3 F",
+    }
+    out["within_budget"] = bool(out["sign_flips_at_iso"] <= max(1, 1e-5 * a.size) and differ <= 8 * out["sign_flips_at_iso"]
+                                and differ <= max(8, 1e-3 * cut) and out["abs_dV"] <= max(8, 1e-3 * nv_b) and out["abs_dF"] <= max(16, 1e-3 * nf_b))
+    return out

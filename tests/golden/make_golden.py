@@ -113,6 +113,35 @@ def case_view(name, hp, n_rays, view=0, chunk=2048):
     print(name, "rays", n_rays)
 
 
+def case_view_narrow(name, scene, hp, n_rays, view=0, chunk=2048):
+    """`case_view` for the narrower shipped shapes (synthetic.SMOOTH_SCENES): 8192 strided rays of a bench view through the
+    reference's NeRFModel.forward, final rgb maps only -- the strict 1e-4 dB fixtures of the 8x128 (fern) and 4x64 (tiny)
+    networks."""
+    nerf, models = ref_import.load()
+    m = models.NeRFModel(hp).eval()
+    w, kw = S.make_smooth_scene_weights(scene)
+    assert kw == mlp_kwargs(hp, "coarse")
+    load_weights(m, "model_coarse.", w)
+    if hp["models.use_fine"]:
+        load_weights(m, "model_fine.", w)
+    o, d, idx = lego_rays(n_rays, view=view)
+    bounds = torch.tensor([2.0, 6.0], dtype=torch.float32)
+    rgb_c, rgb_f, acc = [], [], []
+    with torch.no_grad():
+        for s in range(0, n_rays, chunk):
+            coarse, fine = m.forward((o, d[s:s + chunk], bounds))
+            rgb_c.append(coarse.rgb_map)
+            acc.append((fine or coarse).acc_map)
+            if fine is not None:
+                rgb_f.append(fine.rgb_map)
+    out = {"coarse.rgb_map": torch.cat(rgb_c).numpy()}
+    if rgb_f:
+        out["fine.rgb_map"] = torch.cat(rgb_f).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), pose=S.orbit_poses(4)[view], ray_index=idx.numpy(),
+                        bounds=bounds.numpy(), seed=S.SCENE_SEED, scene=scene, **out)
+    print(name, "rays", n_rays, "acc", float(torch.cat(acc).mean()))
+
+
 def case_mlp(name, hp, seed, gain, bias, n):
     """R3/R7: sample_points(points, dirs) on scattered points, incl. large coordinates."""
     nerf, models = ref_import.load()
@@ -609,6 +638,10 @@ if __name__ == "__main__":
         case_ref_cache("ref_cache")
     elif "--buff-sampled-tree" in sys.argv:
         case_buff_sampled_tree("buff_sampled_tree")
+    elif "--view8k-narrow" in sys.argv:
+        case_view_narrow("render_fern_view_8k", "fern_8x128", S.hparams(hidden_size=128), 8192)
+        case_view_narrow("render_tiny_view_8k", "tiny_4x64",
+                         S.hparams(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6, num_coarse=32, num_fine=0, use_fine=False), 8192)
     elif "--view8k" in sys.argv:
         case_view("render_lego_view_8k", S.hparams(), 8192)
     elif "--val-steps" in sys.argv:

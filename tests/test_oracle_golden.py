@@ -56,6 +56,33 @@ def test_view8k_parity_fixture_matches_reference():
     assert p["abs_dpsnr_db"] <= 1e-4, p
 
 
+NARROW_8K = {"render_fern_view_8k": ("fern_8x128", O.RenderSpec()),
+             "render_tiny_view_8k": ("tiny_4x64", O.RenderSpec(num_coarse=32, num_fine=0))}
+
+
+@pytest.mark.parametrize("name", sorted(NARROW_8K))
+def test_narrow_view8k_parity_fixtures_match_reference(name):
+    """Round 4: the strict-bar PSNR fixtures of the 8x128 (config/nerf-colmap-fern.yml:115,152) and 4x64 (BASELINE
+    configs[0]) networks -- 8192 strided rays of a bench view through the unmodified reference: the oracle reproduces a
+    slice of each, and the parity helper reads <= 1e-4 dB."""
+    from oracle import parity
+    scene, rs = NARROW_8K[name]
+    g = load_golden(name)
+    w, kw = S.make_smooth_scene_weights(scene)
+    o, d = O.get_ray_bundle(800, 800, S.LEGO_FOCAL_800, g["pose"])
+    o, d = o[None].contiguous(), d.reshape(-1, 3)[torch.from_numpy(g["ray_index"])].contiguous()
+    spec = O.MLPSpec(**kw)
+    sl = slice(4096, 4096 + 1024)
+    with torch.no_grad():
+        c, f = O.render(w, w if rs.num_fine else None, spec, spec, rs, o, d[sl], 2.0, 6.0)
+    np.testing.assert_allclose(c["rgb_map"].numpy(), g["coarse.rgb_map"][sl], **TOL)
+    pre, final = ("fine.", f) if f is not None else ("coarse.", c)
+    np.testing.assert_allclose(final["rgb_map"].numpy(), g[pre + "rgb_map"][sl], rtol=2e-5, atol=2e-5)
+    p = parity.psnr_parity(final["rgb_map"].numpy(), g[pre + "rgb_map"][sl], chunk=2048)
+    assert p["abs_dpsnr_db"] <= 1e-4, p
+    assert 0.1 < float(final["acc_map"].mean()) < 0.95, "the scene must be neither empty nor opaque"
+
+
 def test_mlp_points_match_reference():
     g = load_golden("mlp_8x256_points")
     w = gen_weights(g["seed"], g["gain"], g["bias"])

@@ -46,3 +46,28 @@ def test_float_batch_count_quirk_is_kept():
     mse = torch.nn.functional.mse_loss
     manual = (mse(r[:100], tgt[:100]) + mse(r[100:200], tgt[100:200]) + mse(r[200:], tgt[200:])) / (250 / 100)
     assert abs(p["psnr_ref_db"] - float(O.mse2psnr(manual))) < 1e-5
+
+
+def test_mesh_topology_report_counts_flips_and_enforces_the_budget():
+    """oracle/parity.py::mesh_topology (the end-to-end mesh figure of tests/test_gpu_parity.py and bench.py's
+    `mesh.parity.topology`): identical grids -> nothing differs; one voxel pushed across the iso level -> one flip, at
+    most 8 differing cubes, within budget; a grid that differs everywhere -> out of budget.  The check can fail."""
+    import numpy as np
+    from oracle import mc_oracle, parity
+    n = 40
+    ax = np.linspace(-1, 1, n, dtype=np.float32)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    ref = (0.7 - np.sqrt(x * x + y * y + z * z)).astype(np.float32)
+    mesh = mc_oracle.marching_cubes(ref, 0.0)
+    same = parity.mesh_topology(ref, ref, 0.0, 0.0, mesh, mesh)
+    assert same["sign_flips_at_iso"] == 0 and same["cubes_whose_corner_pattern_differs"] == 0 and same["within_budget"]
+    assert same["cubes_cut_by_the_surface"] > 100
+    one = ref.copy()
+    i = np.unravel_index(np.argmin(np.where(ref > 0, ref, np.inf)), ref.shape)          # the inside voxel closest to the level
+    one[i] = -1e-6
+    rep = parity.mesh_topology(one, ref, 0.0, 0.0, mc_oracle.marching_cubes(one, 0.0), mesh)
+    assert rep["sign_flips_at_iso"] == 1 and 1 <= rep["cubes_whose_corner_pattern_differs"] <= 8 and rep["within_budget"], rep
+    rng = np.random.default_rng(0)
+    noisy = (ref + 0.05 * rng.standard_normal(ref.shape)).astype(np.float32)
+    bad = parity.mesh_topology(noisy, ref, 0.0, 0.0, mc_oracle.marching_cubes(noisy, 0.0), mesh)
+    assert bad["sign_flips_at_iso"] > 100 and not bad["within_budget"]
