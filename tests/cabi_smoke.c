@@ -2,8 +2,12 @@
  * Builds a 4x64 FlexibleNeRFModel from weights read from a raw fp32 file, evaluates n points with
  * nm_mlp_sample_points and writes the (n,4) result to a raw fp32 file; then runs the training entry points
  * (nm_mlp_forward_train + nm_mlp_backward with dL/d(radiance) = 1) on the same points as one-sample rays and appends
- * the radiance again, delta at layer1's output (n,H) and the head deltas (n,4).  The pytest driver
- * (tests/test_gpu_cabi_c.py) generates the inputs and checks everything against the CPU oracle.
+ * the radiance again, delta at layer1's output (n,H) and the head deltas (n,4).  Then the two entry points INTEGRATION.md B
+ * tells a maintainer to bind first: the one-call renderer nm_render_rays (R = 256 rays from the given points / directions,
+ * 16 coarse + 24 fine samples, the same network as coarse and fine) -> fine rgb_map (R,3) and acc_map (R,), and mesh
+ * extraction -- nm_mlp_grid_query (density only, 24^3) -> nm_mc_count -> nm_mc_emit at iso = the grid's mean -> the grid,
+ * iso, V, F, vertices, faces, normals, values.  The pytest driver (tests/test_gpu_cabi_c.py) generates the inputs and
+ * checks everything against the CPU oracle.
  *
  *   gcc -D__HIP_PLATFORM_AMD__ tests/cabi_smoke.c -Iinclude -I/opt/rocm/include -Lnerfmeshes_amd/csrc -lnerfmeshes_hip \
  *       -L/opt/rocm/lib -lamdhip64 -o cabi_smoke
@@ -90,6 +94,77 @@ int main(int argc, char** argv) {
     fwrite(buf, sizeof(float), (size_t)n * H, f);
     if (hipMemcpy(out, dl.d_last, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return 9;
     fwrite(out, sizeof(float), (size_t)n * 4, f);
+
+    /* ---- nm_render_rays: NeRFModel.forward in one call (src/models/model_nerf.py:37-78) */
+    {
+        enum { R = 256, NC = 16, NF = 24 };
+        if (n < R) { fprintf(stderr, "need at least %d points\n", R); return 10; }
+        float u_c[NC], u_f[NF], bounds[2] = {0.5f, 3.0f};
+        for (int i = 0; i < NC; ++i) u_c[i] = (float)i / (float)(NC - 1);
+        for (int i = 0; i < NF; ++i) u_f[i] = (float)i / (float)(NF - 1);
+        float *d_uc, *d_uf, *d_bounds, *d_rgb, *d_depth, *d_w, *d_mw, *d_acc, *d_disp;
+        void* d_ws;
+        hipMalloc((void**)&d_uc, sizeof u_c); hipMalloc((void**)&d_uf, sizeof u_f); hipMalloc((void**)&d_bounds, sizeof bounds);
+        hipMemcpy(d_uc, u_c, sizeof u_c, hipMemcpyHostToDevice); hipMemcpy(d_uf, u_f, sizeof u_f, hipMemcpyHostToDevice);
+        hipMemcpy(d_bounds, bounds, sizeof bounds, hipMemcpyHostToDevice);
+        hipMalloc(&d_ws, (size_t)nm_render_workspace_bytes(R, NC, NF));
+        hipMalloc((void**)&d_rgb, R * 12); hipMalloc((void**)&d_depth, R * 4); hipMalloc((void**)&d_acc, R * 4); hipMalloc((void**)&d_disp, R * 4);
+        hipMalloc((void**)&d_w, (size_t)R * (NC + NF) * 4); hipMalloc((void**)&d_mw, (size_t)R * (NC + NF) * 4);
+        nm_render_cfg cfg = {NC, NF, 0, 0, 0, 1e-5f};
+        nm_bundle_out fine_out = {d_rgb, d_depth, d_w, d_mw, d_acc, d_disp};
+        nm_bundle_out coarse_out;                 /* the coarse bundle is mandatory: its own (R,.) arrays */
+        hipMalloc((void**)&coarse_out.d_rgb_map, R * 12); hipMalloc((void**)&coarse_out.d_depth_map, R * 4);
+        hipMalloc((void**)&coarse_out.d_acc_map, R * 4); hipMalloc((void**)&coarse_out.d_disp_map, R * 4);
+        hipMalloc((void**)&coarse_out.d_weights, (size_t)R * NC * 4); hipMalloc((void**)&coarse_out.d_mask_weights, (size_t)R * NC * 4);
+        if (nm_render_rays(mlp, mlp, &cfg, d_pts, 1, d_dirs, d_bounds, d_bounds + 1, 0, d_uc, d_uf, R, d_ws, &coarse_out, &fine_out, NULL)) {
+            fprintf(stderr, "render_rays: %s\n", nm_last_error()); return 10;
+        }
+        float img[R * 4];
+        if (hipMemcpy(img, d_rgb, R * 12, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+        if (hipMemcpy(img + 3 * R, d_acc, R * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+        fwrite(img, sizeof(float), R * 4, f);
+    }
+
+    /* ---- mesh extraction: nm_mlp_grid_query -> nm_mc_count -> nm_mc_emit (src/mesh_nerf.py:27-53, 73-79) */
+    {
+        enum { G = 24 };
+        float ax[G];
+        for (int i = 0; i < G; ++i) ax[i] = -1.2f + 2.4f * (float)i / (float)(G - 1);
+        float *d_ax, *d_grid;
+        hipMalloc((void**)&d_ax, sizeof ax); hipMalloc((void**)&d_grid, (size_t)G * G * G * 4);
+        hipMemcpy(d_ax, ax, sizeof ax, hipMemcpyHostToDevice);
+        if (nm_mlp_grid_query(mlp, d_ax, d_ax, d_ax, G, G, G, 0, (int64_t)G * G * G, 1, d_grid, NULL)) { fprintf(stderr, "grid_query: %s\n", nm_last_error()); return 11; }
+        float* grid = (float*)malloc((size_t)G * G * G * 4);
+        if (hipMemcpy(grid, d_grid, (size_t)G * G * G * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+        double sum = 0;
+        for (long i = 0; i < (long)G * G * G; ++i) sum += grid[i];
+        const float iso = (float)(sum / ((double)G * G * G));
+        void *d_mcws, *d_scratch;
+        hipMalloc(&d_mcws, (size_t)nm_mc_workspace_bytes(G, G, G));
+        int64_t nv = 0, nf = 0;
+        if (nm_mc_count(d_grid, G, G, G, (double)iso, d_mcws, &nv, &nf, NULL)) { fprintf(stderr, "mc_count: %s\n", nm_last_error()); return 12; }
+        float head[3] = {iso, (float)nv, (float)nf};
+        fwrite(grid, sizeof(float), (size_t)G * G * G, f);
+        fwrite(head, sizeof(float), 3, f);
+        if (nv > 0) {
+            float *d_v, *d_nrm, *d_val;
+            int32_t* d_f;
+            hipMalloc(&d_scratch, (size_t)nm_mc_vertex_scratch_bytes(nv, nf) + 256);
+            hipMalloc((void**)&d_v, (size_t)nv * 12); hipMalloc((void**)&d_nrm, (size_t)nv * 12); hipMalloc((void**)&d_val, (size_t)nv * 4);
+            hipMalloc((void**)&d_f, (size_t)nf * 12);
+            if (nm_mc_emit(d_grid, G, G, G, (double)iso, d_mcws, d_scratch, nv, nf, d_v, d_f, d_nrm, d_val, NULL)) { fprintf(stderr, "mc_emit: %s\n", nm_last_error()); return 13; }
+            const size_t big = (size_t)(nv > nf ? nv : nf) * 12;
+            void* host = malloc(big);
+            if (hipMemcpy(host, d_v, (size_t)nv * 12, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+            fwrite(host, 4, (size_t)nv * 3, f);
+            if (hipMemcpy(host, d_f, (size_t)nf * 12, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+            fwrite(host, 4, (size_t)nf * 3, f);
+            if (hipMemcpy(host, d_nrm, (size_t)nv * 12, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+            fwrite(host, 4, (size_t)nv * 3, f);
+            if (hipMemcpy(host, d_val, (size_t)nv * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+            fwrite(host, 4, (size_t)nv, f);
+        }
+    }
     fclose(f);
     printf("abi %d flops/sample %lld ok\n", nm_abi_version(), (long long)nm_mlp_flops_per_sample(mlp, 0));
     nm_mlp_destroy(mlp);

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from nerfmeshes_amd import synthetic as S
-from oracle import nerf_oracle as O
+from oracle import mc_oracle, nerf_oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +43,9 @@ def test_c_program_through_the_c_abi(tmp_path):
     assert res.returncode == 0, res.stderr
     assert "abi 2" in res.stdout
     blob = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
-    assert blob.size == n * (4 + 4 + 64 + 4)
+    mlp_part = n * (4 + 4 + 64 + 4)
+    rest = blob[mlp_part:]
+    blob = blob[:mlp_part]
     got, taped, d_h0, d_last = np.split(blob, [4 * n, 8 * n, 8 * n + 64 * n])
     got, taped, d_h0, d_last = got.reshape(n, 4), taped.reshape(n, 4), d_h0.reshape(n, 64), d_last.reshape(n, 4)
     assert np.array_equal(got, taped), "nm_mlp_forward_train must reproduce nm_mlp_sample_points"
@@ -57,3 +59,25 @@ def test_c_program_through_the_c_abi(tmp_path):
                        ("fc_alpha.bias", d_last[:, 3:].astype(np.float64).sum(0))):
         ref_g = w64[name].grad.numpy()
         assert np.abs(ours - ref_g).max() <= 2e-4 * np.abs(ref_g).max(), name
+
+    # ---- nm_render_rays from C: 256 rays, 16 + 24 samples, one network as coarse and fine
+    R, G = 256, 24
+    img, rest = rest[:4 * R], rest[4 * R:]
+    rgb, acc = img[:3 * R].reshape(R, 3), img[3 * R:]
+    _, fb = O.render(w, w, O.MLPSpec(**kw), O.MLPSpec(**kw), O.RenderSpec(num_coarse=16, num_fine=24),
+                     torch.from_numpy(pts[:R]), torch.from_numpy(dirs[:R]), 0.5, 3.0)
+    ok = np.abs(rgb - fb["rgb_map"].numpy()).max(-1) <= 1e-4
+    assert ok.mean() >= 0.98 and np.abs(rgb - fb["rgb_map"].numpy()).max() < 5e-2, (ok.mean(), np.abs(rgb - fb["rgb_map"].numpy()).max())
+    assert np.abs(acc - fb["acc_map"].numpy())[ok].max() <= 1e-4 and 0.02 < acc.mean() < 0.98
+    # ---- nm_mlp_grid_query -> nm_mc_count / nm_mc_emit from C: the grid vs the oracle's, the mesh vs the C oracle on THAT grid
+    grid, rest = rest[:G ** 3].reshape(G, G, G), rest[G ** 3:]
+    iso, nv, nf = float(rest[0]), int(rest[1]), int(rest[2])
+    rest = rest[3:]
+    ref_grid = O.extract_radiance(w, O.MLPSpec(**kw), 1.2, G)[..., 3]
+    assert np.abs(grid - ref_grid).max() <= 2e-5 * (np.abs(ref_grid).max() + 1)
+    assert rest.size == nv * 3 + nf * 3 + nv * 3 + nv and nv > 50 and nf > 50
+    v, f, nrm, val = np.split(rest, [3 * nv, 3 * nv + 3 * nf, 6 * nv + 3 * nf])
+    rv, rf, rn, rval = mc_oracle.marching_cubes(np.ascontiguousarray(grid), iso)
+    assert rv.shape == (nv, 3) and rf.shape == (nf, 3)
+    assert v.tobytes() == rv.tobytes() and f.view(np.int32).tobytes() == rf.astype(np.int32).tobytes()
+    assert nrm.tobytes() == rn.tobytes() and val.tobytes() == rval.tobytes()

@@ -3,8 +3,16 @@ against `nerfmeshes_amd.compat.install()` in a fresh interpreter (tests/test_ref
 shim's module names `models` / `nerf` / `data` must not leak into the pytest process, where other tests import the real
 reference under the same names).
 
-There is no GPU in the build container and no reference tree on the GPU box, so here the arithmetic behind the shim's
-model classes is replaced by the CPU ORACLE (test double `OracleNeRFModel`, registered as `models.OracleNeRFModel`):
+Two backends (`NM_REF_BACKEND`):
+
+* `hip` -- the REAL `models.NeRFModel` over the HIP kernels on cuda:0: one process in which the unmodified
+  `/root/reference/src/eval_nerf.py:62-65 -> models.NeRFModel.query -> nm_render_rays` (and `mesh_nerf.py:73-79 ->
+  sample_points -> nm_mlp_sample_points`, `skimage.measure.marching_cubes -> nm_mc_count / nm_mc_emit`, `train_nerf.py ->
+  training_step -> nm_mlp_forward_train / nm_mlp_backward`) actually executes.  Needs a GPU AND a reference checkout
+  (`NERFMESHES_REFERENCE=<dir>`); the expectations still come from the oracle, on the CPU.
+* `oracle` (default) -- there is no GPU in the build container and no reference tree on the driver's GPU box, so here the
+  arithmetic behind the shim's model classes is replaced by the CPU ORACLE (test double `OracleNeRFModel`, registered as
+  `models.OracleNeRFModel`):
 what is under test is everything between the reference's script and the kernels -- module aliases, third-party
 stand-ins, PathParser, dataset classes, DataLoader collation, DataBundle, batchify, the cast_* / export_obj helpers,
 BaseModel.setup / dataloaders, the Trainer stand-in, LoggerCallback, checkpoint layout.  The GPU tests
@@ -35,7 +43,13 @@ models, nerf = compat.install()
 from nerfmeshes_amd.data import CachedRayDataset, DataBundle, DatasetType  # noqa: E402
 from nerfmeshes_amd.nerf.modules import OutputBundle                        # noqa: E402
 
+BACKEND = os.environ.get("NM_REF_BACKEND", "oracle")
+HIP = BACKEND == "hip"
+if HIP and not torch.cuda.is_available():
+    raise SystemExit("NM_REF_BACKEND=hip needs a MI355X")
+DEVICE = "cuda" if HIP else "cpu"
 MLP = dict(num_layers=4, hidden_size=32, skip_step=2, num_encoding_fn_xyz=4, num_encoding_fn_dir=2)
+MODEL_NAME = "NeRFModel" if HIP else "OracleNeRFModel"      # the class the checkpoints name, i.e. what the scripts instantiate
 H, W, FOCAL = 10, 14, 16.0
 
 
@@ -79,7 +93,7 @@ models.OracleNeRFModel = OracleNeRFModel
 
 
 def hparams(work, **over):
-    hp = S.hparams(model="OracleNeRFModel", num_coarse=8, num_fine=8, chunksize=48, **MLP)
+    hp = S.hparams(model=MODEL_NAME, num_coarse=8, num_fine=8, chunksize=48, **MLP)
     hp.update({"experiment.logdir": os.path.join(work, "logs"), "dataset.caching.use_caching": True,
                "dataset.caching.cache_dir": os.path.join(work, "cache"), "nerf.train.num_random_rays": 64,
                "nerf.train.chunksize": 48, "experiment.train_iters": 6, "experiment.validate_every": 3,
@@ -166,20 +180,24 @@ def scenario_eval(work):
         # the package's mirror of the script, same model object, same files
         from nerfmeshes_amd import eval_nerf as mirror
         args = mirror.build_parser().parse_args(["--log-checkpoint", vdir, "--save-dir", save_ours, "--save-images", "--save-disparity"])
+        run_model = model
+        if HIP:     # the mirror over the real kernels too: script and mirror must agree bit for bit, the oracle within tolerance
+            run_model = models.NeRFModel.load_from_checkpoint(os.path.join(vdir, "checkpoints", "model_last.ckpt")).eval().to(DEVICE)
         with contextlib.redirect_stdout(io.StringIO()) as mtext:
-            total = mirror.eval_nerf(model, args, cfg, "cpu")
+            total = mirror.eval_nerf(run_model, args, cfg, DEVICE)
     files = sorted(os.path.relpath(os.path.join(d, f), save_ref) for d, _, fs in os.walk(save_ref) for f in fs)
     same = all(np.array_equal(png(os.path.join(save_ref, f)), png(os.path.join(save_ours, f))) for f in files)
     img0 = png(os.path.join(save_ref, hp["experiment.id"], "images", "0000.png"))
     want0 = (rgbs[0].view(H, W, 3).clamp(0, 1) * 255).to(torch.uint8).numpy()
-    return {"stdout": text, "expected_losses": losses, "expected_total": float(O.dataset_loss(losses)),
+    return {"backend": BACKEND, "stdout": text, "expected_losses": losses, "expected_total": float(O.dataset_loss(losses)),
             "mirror_total": float(total), "mirror_stdout": mtext.getvalue(), "files": files,
             "mirror_files_identical": bool(same), "image0_matches_render": bool(np.array_equal(img0, want0))}
 
 
 def scenario_mesh(work):
     import skimage.measure
-    skimage.measure.marching_cubes = lambda vol, level: mc_oracle.marching_cubes(np.ascontiguousarray(vol), float(level))
+    if not HIP:      # hip: whatever `skimage.measure.marching_cubes` resolves to -- the package, or compat's nm_mc_* stand-in
+        skimage.measure.marching_cubes = lambda vol, level: mc_oracle.marching_cubes(np.ascontiguousarray(vol), float(level))
     hp = hparams(work)
     vdir, model = write_checkpoint(hp)
     res = 20
@@ -199,6 +217,8 @@ def scenario_mesh(work):
     iso = min(max(5.0, sigma.min() + sigma.std()), sigma.max() - sigma.std())
     v, f, n, _ = mc_oracle.marching_cubes(sigma, float(iso))
     out["expected"] = {"v": int(v.shape[0]), "f": int(f.shape[0]), "iso": float(iso)}
+    out["backend"] = BACKEND
+    out["marching_cubes_is_stand_in"] = bool(getattr(skimage.measure, "__nerfmeshes_amd_stand_in__", False))
     return out
 
 
@@ -221,7 +241,7 @@ def scenario_train(work):
     text2 = run_reference("train_nerf.py", ["--log-checkpoint", vdir])
     state2 = torch.load(ck, weights_only=False)
     reloaded = OracleNeRFModel.load_from_checkpoint(ck)
-    return {"stdout": text, "resume_stdout": text2, "checkpoint_keys": sorted(state.keys()),
+    return {"backend": BACKEND, "stdout": text, "resume_stdout": text2, "checkpoint_keys": sorted(state.keys()),
             "checkpoints": sorted(os.listdir(os.path.join(vdir, "checkpoints"))),
             "global_step": int(state["global_step"]), "resumed_global_step": int(state2["global_step"]),
             "hparams_yaml": os.path.exists(os.path.join(vdir, "hparams.yaml")),
@@ -234,4 +254,8 @@ if __name__ == "__main__":
     name, work = sys.argv[1], sys.argv[2]
     os.makedirs(work, exist_ok=True)
     result = {"imports": scenario_imports, "eval": scenario_eval, "mesh": scenario_mesh, "train": scenario_train}[name](work)
+    if HIP:
+        # evidence that the kernels ran in THIS process: the library is mapped and its MLP launch counter moved
+        from nerfmeshes_amd import _lib
+        result["native_library"] = os.path.basename(_lib.load()._name)
     print(json.dumps(result))
