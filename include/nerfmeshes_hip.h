@@ -69,7 +69,12 @@ typedef struct nm_mlp_weights {
 typedef struct nm_mlp nm_mlp;
 
 /* Packs the weights into the MFMA operand stream and uploads them to `device`.
- * Unsupported (hidden_size, num_encoding_fn_*) combinations fail with a message. */
+ * Every shape FlexibleNeRFModel's constructor accepts (models.py:5-58) is served: the shipped configs' shapes (hidden_size
+ * 64 / 128 / 256, 6 or 10 xyz and 4 direction functions) by kernels tuned for exactly them, every other one -- any hidden_size
+ * up to 512, 0..15 encoding functions per input (16 without the input itself), include_input_* on or off -- by the
+ * generic-shape kernel family (padded to the next width class; nm_mlp_kernel_variant reports 1000 + class).  Only a
+ * hidden_size above 512 or an encoding beyond those limits fails, with a message.  Training entry points and
+ * NM_PREC_BF16X3 exist for the tuned shapes only. */
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
 
 /* Arithmetic of the GEMMs.  NM_PREC_F32 (default, what nm_mlp_create builds): fp32 MFMA, the reference's fp32 arithmetic
@@ -78,6 +83,9 @@ int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int 
  * a product) at ~2.3x the throughput, but not bit-comparable with the fp32 path; inference entry points only
  * (nm_mlp_forward_train / nm_mlp_backward refuse such a handle). */
 enum { NM_PREC_F32 = 0, NM_PREC_BF16X3 = 1 };
+/* OR into `precision` (with NM_PREC_F32): bind the handle to the generic-shape kernel family even where a tuned kernel exists
+ * for the shape.  A cross-check, not a mode: the results are the tuned kernel's bit for bit. */
+enum { NM_KERNEL_GENERIC = 0x100 };
 int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* host_weights, int device, int precision, nm_mlp** out);
 int nm_mlp_precision(const nm_mlp* mlp);
 void nm_mlp_destroy(nm_mlp* mlp);

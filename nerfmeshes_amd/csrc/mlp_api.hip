@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "nm_internal.h"
+#include "mlp_device_g.h"
 
 namespace nm {
 
@@ -12,6 +13,7 @@ static thread_local std::string g_error;
 void set_error(const std::string& msg) { g_error = msg; }
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD);
+const MlpPlan* find_generic_plan(int H);
 bool has_b3_kernel(int H, int FX, int FD);
 int mlp_plan_info(const MlpPlan* p, int* nw);
 int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream);
@@ -61,6 +63,141 @@ static void pack_gemm(std::vector<int32_t>& out, int tensor, int ld, int rows, i
                     const int64_t off = transposed ? (int64_t)k * ld + n : (int64_t)n * ld + k;
                     out.push_back((n < rows && k >= 0) ? (int32_t)((tensor << 24) | (int32_t)off) : -1);
                 }
+}
+
+static bool is_skip(const nm_mlp_desc& d, int i);
+static void pack_range(std::vector<int32_t>& out, int tensor, int count);
+static void pad_to(std::vector<int32_t>& v, size_t multiple);
+
+// ---- generic-shape family (mlp_device_g.h) -------------------------------------------------------------------------
+// hidden activation of the PADDED width 16 * nt, real width `width`: columns beyond it are zero weights
+static void hidden_steps_g(std::vector<StepCols>& out, int nt, int width, int col_offset) {
+    for (int s = 0; s < 4 * nt; ++s) {
+        StepCols c;
+        for (int g = 0; g < 4; ++g) {
+            const int k = 16 * (s >> 2) + 4 * g + (s & 3);
+            c[g] = k < width ? col_offset + k : -1;
+        }
+        out.push_back(c);
+    }
+}
+
+// an encoding's own stage: (3 F + 1) / 2 argument k-steps, the identity step only when the input is included, zero k-steps
+// up to a whole number of chunks; returns the chunk count
+static int encoding_stage_g(std::vector<StepCols>& out, int F, bool include_input, int col_offset, int kch) {
+    const int base = col_offset + (include_input ? 3 : 0);
+    int n = 0;
+    for (int s = 0; s < (3 * F + 1) / 2; ++s, ++n) {
+        StepCols c;
+        for (int g = 0; g < 4; ++g) {
+            const int a = 2 * s + (g >> 1);
+            c[g] = a < 3 * F ? base + ((g & 1) ? 3 * F : 0) + a : -1;
+        }
+        out.push_back(c);
+    }
+    if (include_input) {
+        StepCols id;
+        for (int g = 0; g < 4; ++g) id[g] = g < 3 ? col_offset + g : -1;
+        out.push_back(id);
+        ++n;
+    }
+    for (; n % kch; ++n) out.push_back(StepCols{-1, -1, -1, -1});
+    return n / kch;
+}
+
+// A-operand stream of one generic stage: per k-step ceil(ntiles / 4) blocks of 4 tiles (1 KiB each; tiles beyond ntiles and rows
+// beyond `rows` are zeros)
+static void pack_gemm_g(std::vector<int32_t>& out, int tensor, int ld, int rows, int ntiles, const std::vector<StepCols>& steps) {
+    const int nb = (ntiles + 3) / 4;
+    for (const StepCols& c : steps)
+        for (int b = 0; b < nb; ++b)
+            for (int l = 0; l < 64; ++l)
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 16 * (4 * b + q) + (l & 15);
+                    const int k = c[l >> 4];
+                    out.push_back((4 * b + q < ntiles && n < rows && k >= 0) ? (int32_t)((tensor << 24) | (int32_t)((int64_t)n * ld + k)) : -1);
+                }
+}
+
+static void pack_range_padded(std::vector<int32_t>& out, int tensor, int count, int padded) {
+    for (int i = 0; i < padded; ++i) out.push_back(i < count ? ((tensor << 24) | i) : -1);
+}
+
+// GEMV operand of a head row over a D-layout activation of padded width 16 * nt (fc_alpha's layout): [4 lane groups][4 nt]
+static void pack_head_row_g(std::vector<int32_t>& out, int tensor, int row_offset, int nt, int width) {
+    for (int g = 0; g < 4; ++g)
+        for (int s = 0; s < 4 * nt; ++s) {
+            const int k = 16 * (s >> 2) + 4 * g + (s & 3);
+            out.push_back(k < width ? ((tensor << 24) | (row_offset + k)) : -1);
+        }
+}
+
+struct BlobLayout { size_t off_bias, off_wa, off_wr, off_bwd; uint32_t skip_mask; int chx, chd; };
+
+// The whole blob of a generic plan as an index map (layout: mlp_device_g.h's kernel): forward stream | biases | fc_alpha |
+// fc_rgb (or fc_out's colour rows).  No backward stream: the training kernels are instantiated for the tuned shapes only.
+static BlobLayout build_index_generic(std::vector<int32_t>& index, const nm_mlp_desc& d, const MlpPlan& plan) {
+    const int H = d.hidden_size, L = d.num_layers, FX = d.num_encoding_fn_xyz, FD = d.num_encoding_fn_dir;
+    const bool no_view = d.use_viewdirs == 0;
+    const int dx = 6 * FX + (d.include_input_xyz ? 3 : 0), dd = 6 * FD + (d.include_input_dir ? 3 : 0);
+    const int NT = plan.generic_nt, NTD = (NT + 1) / 2, HP = 16 * NT, HPD = 16 * NTD, kch = plan.KCH;
+    BlobLayout lay{};
+    std::vector<StepCols> enc_x, hid, skip_enc, dir_enc;
+    lay.chx = encoding_stage_g(enc_x, FX, d.include_input_xyz != 0, 0, kch);
+    hidden_steps_g(hid, NT, H, 0);
+    encoding_stage_g(skip_enc, FX, d.include_input_xyz != 0, H, kch);         // cat(hidden, xyz): models.py:65
+    lay.chd = no_view ? 0 : encoding_stage_g(dir_enc, FD, d.include_input_dir != 0, H, kch);   // cat(feat, view): models.py:72
+    pack_gemm_g(index, T_L1W, dx, H, NT, enc_x);
+    for (int i = 0; i < L - 1; ++i) {
+        const bool skip = is_skip(d, i);
+        const int ld = H + (skip ? dx : 0);
+        pack_gemm_g(index, T_XYZ0 + 2 * i, ld, H, NT, hid);
+        if (skip) {
+            pack_gemm_g(index, T_XYZ0 + 2 * i, ld, H, NT, skip_enc);
+            lay.skip_mask |= 1u << i;
+        }
+    }
+    if (!no_view) {
+        pack_gemm_g(index, T_FEATW, H, H, NT, hid);
+        pack_gemm_g(index, T_DIRW, H + dd, H / 2, NTD, hid);
+        pack_gemm_g(index, T_DIRW, H + dd, H / 2, NTD, dir_enc);
+    }
+    index.resize(index.size() + 8192, -1);   // DMA granularity padding: a tail fetch may run one chunk (32 KiB) past the stream
+    pad_to(index, 64);
+    lay.off_bias = index.size();
+    pack_range_padded(index, T_L1B, H, HP);
+    for (int i = 0; i < L - 1; ++i) pack_range_padded(index, T_XYZ0 + 2 * i + 1, H, HP);
+    if (no_view) index.resize(index.size() + HP + HPD, -1);
+    else {
+        pack_range_padded(index, T_FEATB, H, HP);
+        pack_range_padded(index, T_DIRB, H / 2, HPD);
+    }
+    pack_range(index, T_ALPHAB, 1);
+    pack_range(index, T_RGBB, 3);
+    pad_to(index, 64);
+    lay.off_wa = index.size();
+    pack_head_row_g(index, T_ALPHAW, 0, NT, H);
+    pad_to(index, 64);
+    lay.off_wr = index.size();
+    for (int c = 0; c < 3; ++c) {
+        if (no_view) pack_head_row_g(index, T_RGBW, c * H, NT, H);              // rows 0..2 of fc_out over the trunk output
+        else pack_head_row_g(index, T_RGBW, c * (H / 2), NTD, H / 2);
+    }
+    pad_to(index, 64);
+    lay.off_bwd = index.size();
+    index.resize(index.size() + 1024, -1);
+    pad_to(index, 64);
+    return lay;
+}
+
+// the per-argument table of one encoding (GEncArg: band, coordinate)
+static void fill_enc_table(float* tab /* [G_ENC_ARGS][2] */, int F, const float* bands) {
+    for (int a = 0; a < 48; ++a) {
+        const bool real = F > 0 && a < 3 * F;
+        const int32_t coord = real ? a / F : 0;
+        tab[2 * a] = real ? bands[a % F] : 0.0f;
+        memcpy(&tab[2 * a + 1], &coord, 4);
+    }
 }
 
 // ---- bf16x3 stream (mlp_device_b3.h): per (k-block m, tile nt) unit the fp32 image [lane][j = 0..7] =
@@ -252,15 +389,19 @@ int nm_mlp_precision(const nm_mlp* m) { return m ? m->precision : -1; }
 
 int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int device, int precision, nm_mlp** out) {
     NM_REQUIRE(desc && w && out, "null argument");
+    const bool force_generic = (precision & NM_KERNEL_GENERIC) != 0;
+    precision &= ~NM_KERNEL_GENERIC;
     NM_REQUIRE(precision == NM_PREC_F32 || precision == NM_PREC_BF16X3, "unknown precision");
+    NM_REQUIRE(!force_generic || precision == NM_PREC_F32, "NM_KERNEL_GENERIC goes with NM_PREC_F32");
     const nm_mlp_desc& d = *desc;
     NM_REQUIRE(d.use_viewdirs == 0 || d.use_viewdirs == 1, "use_viewdirs is 0 or 1");
     const bool no_view = d.use_viewdirs == 0;      // models.py:77-79: trunk -> fc_out (4 rows), no view branch
     NM_REQUIRE(!no_view || precision == NM_PREC_F32, "use_viewdirs=0 networks run in fp32 only");
     NM_REQUIRE(d.num_layers >= 2 && d.num_layers <= 32, "num_layers out of range");
     NM_REQUIRE(d.skip_step >= 1, "skip_step must be >= 1");
-    NM_REQUIRE(d.num_encoding_fn_xyz <= MAX_FREQ_XYZ && d.num_encoding_fn_dir <= MAX_FREQ_DIR, "too many encoding fns");
-    // a network without view directions has no direction encoding: any instantiated kernel of that width / xyz encoding runs it
+    NM_REQUIRE(d.hidden_size >= 1 && d.num_encoding_fn_xyz >= 0 && d.num_encoding_fn_dir >= 0, "negative network dimension");
+    NM_REQUIRE(d.num_encoding_fn_xyz > 0 || d.include_input_xyz,
+               "the xyz encoding is empty (num_encoding_fn_xyz = 0 without include_input_xyz): layer1 would have no input");
     // every tensor the packer will read, checked before anything dereferences one
     NM_REQUIRE(w->layer1_w && w->layer1_b && w->fc_alpha_w && w->fc_alpha_b && w->fc_rgb_w && w->fc_rgb_b, "missing weight tensor");
     NM_REQUIRE(no_view || (w->fc_feat_w && w->fc_feat_b && w->layers_dir0_w && w->layers_dir0_b), "missing view-branch weight tensor");
@@ -269,18 +410,37 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         NM_REQUIRE(w->layers_xyz_w[i] && w->layers_xyz_b[i], "missing layers_xyz weight tensor");
     NM_REQUIRE(d.num_encoding_fn_xyz == 0 || w->freq_xyz, "missing xyz frequency bands");
     NM_REQUIRE(no_view || d.num_encoding_fn_dir == 0 || w->freq_dir, "missing direction frequency bands");
-    const MlpPlan* plan = find_mlp_plan(d.hidden_size, d.num_encoding_fn_xyz, no_view ? 4 : d.num_encoding_fn_dir);
-    if (!plan) {
-        set_error("no gfx950 kernel instantiated for hidden_size=" + std::to_string(d.hidden_size) +
-                  " num_encoding_fn_xyz=" + std::to_string(d.num_encoding_fn_xyz) +
-                  " num_encoding_fn_dir=" + std::to_string(d.num_encoding_fn_dir) +
-                  " (add a make_plan<> line in nerf_mlp.hip)");
-        return 3;
-    }
     const int H = d.hidden_size, L = d.num_layers, FX = d.num_encoding_fn_xyz, FD = d.num_encoding_fn_dir;
     const int dx = 6 * FX + (d.include_input_xyz ? 3 : 0), dd = 6 * FD + (d.include_input_dir ? 3 : 0);
+    // A tuned plan for exactly this shape, else the generic family (mlp_device_g.h): every shape FlexibleNeRFModel's
+    // constructor accepts up to hidden_size 512 and 24 k-steps per encoding.  (A network without view directions has no
+    // direction encoding: any tuned kernel of that width / xyz encoding runs it.)
+    const MlpPlan* plan = (!force_generic && FX <= MAX_FREQ_XYZ && (no_view || FD <= MAX_FREQ_DIR)) ? find_mlp_plan(H, FX, no_view ? 4 : FD) : nullptr;
+    if (!plan) {
+        plan = find_generic_plan(H);
+        if (!plan) {
+            set_error("hidden_size=" + std::to_string(H) + " exceeds the widest instantiated kernel class (512): the activations of a "
+                      "wider layer do not fit the register file of one wavefront");
+            return 3;
+        }
+        const int steps_x = (3 * FX + 1) / 2 + (d.include_input_xyz ? 1 : 0), steps_d = (3 * FD + 1) / 2 + (d.include_input_dir ? 1 : 0);
+        if (steps_x > G_ENC_STEPS || (!no_view && steps_d > G_ENC_STEPS)) {
+            set_error("an encoding of " + std::to_string(FX) + " / " + std::to_string(FD) + " functions spans more than " +
+                      std::to_string(G_ENC_STEPS) + " MFMA k-steps (limit: 15 functions, or 16 without the input itself)");
+            return 3;
+        }
+        if (precision != NM_PREC_F32) {
+            set_error("precision bf16x3 is instantiated for hidden_size 256 with 6 or 10 xyz / 4 direction frequencies only");
+            return 3;
+        }
+    }
     const int NT = H / 16, NTD = H / 32;
 
+    std::vector<int32_t> index;
+    BlobLayout lay{};
+    if (plan->generic_nt) {
+        lay = build_index_generic(index, d, *plan);
+    } else {
     std::vector<StepCols> enc_x, hid, hid_half, hid_skip_enc, dir_steps;
     encoding_steps(enc_x, FX, d.include_input_xyz != 0, 0);
     hidden_steps(hid, H, 0);
@@ -290,7 +450,6 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     encoding_steps(dir_steps, FD, d.include_input_dir != 0, H);     // cat(feat, view): models.py:72
 
     // ---- the blob as an index map: forward stream | biases | fc_alpha | fc_rgb | backward stream
-    std::vector<int32_t> index;
     uint32_t skip_mask = 0;
     pack_gemm(index, T_L1W, dx, H, NT, enc_x);
     for (int i = 0; i < L - 1; ++i) {
@@ -345,6 +504,8 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     }
     index.resize(index.size() + 1024, -1);
     pad_to(index, 64);
+    lay = BlobLayout{off_bias, off_wa, off_wr, off_bwd, skip_mask, 0, 0};
+    }
 
     // opt-in bf16x3 stream: the same stages as units of (k-block, tile)
     std::vector<int32_t> index_b3;
@@ -398,13 +559,23 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     const float* base = static_cast<const float*>(m->d_blob);
     MlpArgs& a = m->base;
     a.wstream = reinterpret_cast<const char*>(base);
-    a.bias = base + off_bias;
-    a.walpha = base + off_wa;
-    a.wrgb = base + off_wr;
-    for (int f = 0; f < FX; ++f) a.bands_xyz[f] = w->freq_xyz[f];
-    for (int f = 0; f < FD; ++f) a.bands_dir[f] = w->freq_dir[f];
-    a.skip_mask = skip_mask;
-    m->bwd.wstream = reinterpret_cast<const char*>(base + off_bwd);
+    a.bias = base + lay.off_bias;
+    a.walpha = base + lay.off_wa;
+    a.wrgb = base + lay.off_wr;
+    for (int f = 0; f < FX && f < MAX_FREQ_XYZ; ++f) a.bands_xyz[f] = w->freq_xyz[f];
+    for (int f = 0; f < FD && f < MAX_FREQ_DIR && !no_view; ++f) a.bands_dir[f] = w->freq_dir[f];
+    a.skip_mask = lay.skip_mask;
+    if (plan->generic_nt) {      // the encodings' run-time description (mlp_device_g.h)
+        float tab[2 * 2 * G_ENC_ARGS];
+        fill_enc_table(tab, FX, w->freq_xyz);
+        fill_enc_table(tab + 2 * G_ENC_ARGS, no_view ? 0 : FD, w->freq_dir);
+        NM_HIP_CHECK(hipMalloc(&m->d_enc_tab, sizeof(tab)));
+        NM_HIP_CHECK(hipMemcpy(m->d_enc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        a.g_tab = m->d_enc_tab;
+        a.g_nsx = (3 * FX + 1) / 2; a.g_idx = d.include_input_xyz ? 1 : 0; a.g_chx = lay.chx;
+        a.g_nsd = no_view ? 0 : (3 * FD + 1) / 2; a.g_idd = (!no_view && d.include_input_dir) ? 1 : 0; a.g_chd = lay.chd;
+    }
+    m->bwd.wstream = reinterpret_cast<const char*>(base + lay.off_bwd);
     m->bwd.walpha = a.walpha;
     m->bwd.wrgb = a.wrgb;
     m->flops_full = 2 * mlp_macs(d, false);
@@ -463,6 +634,7 @@ void nm_mlp_destroy(nm_mlp* m) {
     if (m->d_index_b3) (void)hipFree(m->d_index_b3);
     if (m->d_tmp_b3) (void)hipFree(m->d_tmp_b3);
     if (m->d_stream_b3) (void)hipFree(m->d_stream_b3);
+    if (m->d_enc_tab) (void)hipFree(m->d_enc_tab);
     delete m;
 }
 

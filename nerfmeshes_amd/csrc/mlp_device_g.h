@@ -1,0 +1,247 @@
+// Generic-shape instantiation family of the fused MLP (round 4): every FlexibleNeRFModel the reference's constructor accepts
+// (/root/reference/src/nerf/models.py:5-58 -- any hidden_size up to 512, 0..15 encoding functions per input, include_input_*
+// on or off, with or without view directions) runs on the same register-resident dataflow as the tuned plans of
+// nerf_mlp.hip; what is a template parameter there and a RUNTIME value here:
+//
+//   * hidden_size -> a width class NT (16-row MFMA tiles, 16 * NT >= hidden_size; classes in nerf_mlp_generic*.hip).  The packer
+//     pads rows / columns / biases beyond the real width with zeros: relu(0 * x + 0) = 0 feeds zero columns, so the padded
+//     network computes exactly the real one.  The view layer (hidden_size // 2 rows) is padded to NTD = ceil(NT / 2) tiles.
+//     A-operand blocks are 4 tiles (one ds_read_b128 per lane); a trailing block of NT % 4 tiles skips its unused MFMAs.
+//   * num_encoding_fn_* / include_input_* -> encodings live in G_ENC_STEPS = 24 registers per lane; how many k-steps are
+//     real, which argument (coordinate, frequency band) each lane encodes and whether an identity step follows come from a
+//     host-built table (LDS-resident).  An encoding's GEMM columns are their own stage of a runtime number of whole
+//     KCH-k-step chunks (zero-padded), accumulated into the same tiles as the hidden columns -- as the tuned kernels do for
+//     the skip layer; here also for layers_dir[0] (cat(feat, view): two stages).
+//   * use_viewdirs = 0 is the runtime `density_only == 2` branch (flat_head), not a separate instantiation.
+//
+// The values are the tuned kernels': the same sincosf on the same products, fp32 MFMA chains over the same column order
+// (the padded k-steps add exact zeros at the end of a chain), so on a menu shape this kernel reproduces the tuned one bit
+// for bit (tests/test_gpu_generic.py).  Dataflow = round 1's (2-slot ring, one barrier per chunk, scalar-addressed DMA) with
+// round 2's block-granular operand prefetch inside a chunk; wide classes (NT > 16: 2 * 4 * NT activation + accumulator
+// registers per lane exceed 256) run 4-wave workgroups, one wave per SIMD, on the 512-register budget.
+#pragma once
+#include "mlp_device.h"
+
+namespace nm {
+
+constexpr int G_ENC_STEPS = 24;     // k-steps one encoding may span: (3 F + 1) / 2 + include_input <= 24  (F <= 15; F = 16 without input)
+constexpr int G_ENC_ARGS = 2 * G_ENC_STEPS;
+
+// one encoding argument a < 3 F: coordinate a / F times frequency band a % F (modules.py:30-33, coordinate-major);
+// a >= 3 F (the odd tail): band 0 -> sin 0 / cos 1 against zero weights
+struct GEncArg { float band; int32_t coord; };
+
+// One GEMM stage of the generic kernel: acc[NT tiles] += W_stage * b, chunk by chunk through the 2-slot ring.
+// On entry the stage's first chunk is resident in slot `par`; on exit the chunk (tail_src, tail_bytes) -- the first chunk of
+// whatever runs next -- is resident in slot `par`.  RUNTIME: `nchunks` (>= 1) whole chunks of KCH k-steps are present
+// (an encoding stage); otherwise the stage spans exactly KS k-steps (last chunk partial).
+template <int NT, int KS, int NW, int KCH, bool RUNTIME>
+__device__ __forceinline__ void gemm_stage_g(f32x4 (&acc)[NT], const float (&b)[KS], int nchunks, const char* gw,
+                                             const char* tail_src, int tail_bytes, char* lds, int slot_bytes, int& par,
+                                             int wave, int lane) {
+    constexpr int NB = (NT + 3) / 4;
+    constexpr int STEP_BYTES = NB * 1024;
+    constexpr int NCH = (KS + KCH - 1) / KCH;
+    static_assert(!RUNTIME || KS % KCH == 0, "an encoding stage is a whole number of chunks");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if constexpr (RUNTIME) {
+            if (c >= nchunks) break;      // uniform
+        }
+        const int steps = (KS - c * KCH) < KCH ? (KS - c * KCH) : KCH;
+        const int steps_next = (KS - (c + 1) * KCH) < KCH ? (KS - (c + 1) * KCH) : KCH;
+        const bool last = RUNTIME ? (c + 1 >= nchunks) : (c + 1 == NCH);
+        const char* next_src = last ? tail_src : gw + (c + 1) * KCH * STEP_BYTES;
+        const int next_bytes = last ? tail_bytes : steps_next * STEP_BYTES;
+        stream_to_lds<NW>(next_src, lds + (par ^ 1) * slot_bytes, next_bytes, wave, lane);
+        const char* buf = lds + par * slot_bytes + lane * 16;
+        const int nblk = steps * NB;      // blocks of this chunk: block j = (k-step j / NB, tiles 4 (j % NB) ..), 1 KiB apart
+        f32x4 ab[3];
+        ab[0] = *reinterpret_cast<const f32x4*>(buf);
+        if (nblk > 1) ab[1] = *reinterpret_cast<const f32x4*>(buf + 1024);
+#pragma unroll
+        for (int j = 0; j < nblk; ++j) {
+            if (j + 2 < nblk) ab[(j + 2) % 3] = *reinterpret_cast<const f32x4*>(buf + (j + 2) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ks = j / NB, blk = j % NB;
+            const float bv = b[c * KCH + ks];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (blk * 4 + q < NT)
+                    acc[blk * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j % 3][q], bv, acc[blk * 4 + q], 0, 0, 0);
+        }
+        __syncthreads();   // this wave's DMA pieces have landed (vmcnt(0)); slot `par` is free for the next fill
+        par ^= 1;
+    }
+}
+
+// Positional encoding as MFMA B operands with the number of frequencies at run time (layout of mlp_device.h's encode: k-step
+// s < ns carries arguments 2 s, 2 s + 1 -- lane groups sin(a0) cos(a0) sin(a1) cos(a1) --, then the identity step (x, y, z, 0)
+// when the input itself is included, then zeros).  Same sincosf-halving exchange between a sin group and its cos group.
+__device__ __forceinline__ void encode_g(float (&enc)[G_ENC_STEPS], const float (&x)[3], const GEncArg* tab, int ns,
+                                         int ident, int g) {
+    const int hi = g >> 1;
+    const bool want_cos = (g & 1) != 0;
+    auto argument = [&](int a) -> float {         // a: per-lane argument index
+        const GEncArg e = tab[a];
+        const float xv = e.coord == 0 ? x[0] : (e.coord == 1 ? x[1] : x[2]);
+        return xv * e.band;
+    };
+    auto rest = [&](int t) -> float {             // the identity step, or padding
+        return (ident && t == ns) ? (g == 0 ? x[0] : (g == 1 ? x[1] : (g == 2 ? x[2] : 0.0f))) : 0.0f;
+    };
+#pragma unroll
+    for (int s = 0; s < G_ENC_STEPS; s += 2) {
+        if (s + 1 < ns) {          // uniform: both k-steps carry arguments
+            const float mine = argument(2 * (s + (want_cos ? 1 : 0)) + hi);
+            float sv, cv;
+            sincosf(mine, &sv, &cv);
+            const float give = want_cos ? sv : cv;
+            const float got = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(give), 0x401f));   // lane ^ 16
+            enc[s] = want_cos ? got : sv;
+            enc[s + 1] = want_cos ? cv : got;
+        } else if (s < ns) {       // the odd last argument step
+            float sv, cv;
+            sincosf(argument(2 * s + hi), &sv, &cv);
+            enc[s] = want_cos ? cv : sv;
+            enc[s + 1] = rest(s + 1);
+        } else {
+            enc[s] = rest(s);
+            enc[s + 1] = rest(s + 1);
+        }
+    }
+}
+
+template <int NT, int NW, int KCH>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const MlpArgs args, const int num_layers,
+                                                                       const int density_only) {
+    constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
+    constexpr int KH = 4 * NT, KD = 4 * NTD;
+    constexpr int NB = (NT + 3) / 4, NBD = (NTD + 3) / 4;
+    constexpr int STEP = NB * 1024, STEPD = NBD * 1024;
+    constexpr int SLOT = KCH * STEP;
+    constexpr int FIRST_H = (KH < KCH ? KH : KCH) * STEP;       // first chunk of a hidden-input stage (trunk tiles)
+    constexpr int FIRST_HD = (KH < KCH ? KH : KCH) * STEPD;     // ... of layers_dir[0]'s hidden columns
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_bias = reinterpret_cast<float*>(lds + 2 * SLOT);
+    const int nbias = HP * (1 + num_layers) + HPD + 4;          // layer1 | layers_xyz.* | fc_feat | layers_dir.0 | fc_alpha.b | fc_rgb.b[3]
+    float* lds_walpha = lds_bias + nbias;                       // [4][HP / 4]
+    float* lds_wrgb = lds_walpha + HP;                          // [3][4][HPD / 4], or [3][4][HP / 4] for a use_viewdirs = 0 network
+    const bool flat = density_only == 2;
+    const int nrgb = flat ? 3 * HP : 3 * HPD;
+    GEncArg* lds_tab = reinterpret_cast<GEncArg*>(lds_wrgb + (3 * HP > 3 * HPD ? 3 * HP : 3 * HPD));   // [2][G_ENC_ARGS]
+    for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
+    for (int i = threadIdx.x; i < HP; i += NW * 64) lds_walpha[i] = args.walpha[i];
+    for (int i = threadIdx.x; i < nrgb; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    for (int i = threadIdx.x; i < 2 * G_ENC_ARGS; i += NW * 64) lds_tab[i] = static_cast<const GEncArg*>(args.g_tab)[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const float* tail_bias = lds_bias + nbias - 4;
+    const int chx = args.g_chx, chd = args.g_chd;               // whole chunks of the xyz / direction encoding stages
+    const int enc_x_bytes = chx * KCH * STEP;                   // an xyz encoding stage in the stream (trunk tiles)
+
+    const int64_t wg_iters = (args.n + NW * 16 - 1) / (NW * 16);
+    int par = 0;
+    if ((int64_t)blockIdx.x < wg_iters) stream_to_lds<NW>(args.wstream, lds, KCH * STEP, wave, lane);
+    __syncthreads();   // tables, biases and layer1's first chunk are resident (later tiles: the previous tile's last stage fetched it)
+
+    for (int64_t it = blockIdx.x; it < wg_iters; it += gridDim.x) {
+        const bool has_next = it + gridDim.x < wg_iters;
+        const int wrap_bytes = has_next ? KCH * STEP : 0;        // the next tile's first chunk: layer1's encoding columns
+        const int64_t sample = (it * NW + wave) * 16 + col;
+        const bool valid = sample < args.n;
+        const int64_t sidx = valid ? sample : args.n - 1;
+        const SamplePD smp = fetch_sample(args, sidx);
+        const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
+        float encx[G_ENC_STEPS];
+        encode_g(encx, p, lds_tab, args.g_nsx, args.g_idx, g);
+
+        f32x4 acc[NT];
+        float in[KH];
+        const char* gw = args.wstream;
+        // ---- layer1: xyz_enc -> H, no activation (models.py:62)
+        load_bias<NT>(acc, lds_bias, g);
+        gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
+        gw += enc_x_bytes;
+        acc_to_operand<NT, false>(acc, in);
+
+        // ---- layers_xyz[0 .. L-2], then (full evaluation only) fc_feat as iteration L-1 (models.py:63-70)
+        float sigma = 0.0f;
+        const int trunk_iters = density_only ? num_layers - 1 : num_layers;
+#pragma unroll 1
+        for (int i = 0; i < trunk_iters; ++i) {
+            const bool is_feat = i == num_layers - 1;
+            if (is_feat) sigma = alpha_gemv<HP>(in, lds_walpha, g) + tail_bias[0];   // on the pre-feature activation
+            const bool skip = !is_feat && ((args.skip_mask >> i) & 1u);
+            const bool last_density = density_only && i == num_layers - 2;
+            load_bias<NT>(acc, lds_bias + HP * (1 + i), g);
+            {
+                const char* after = gw + KH * STEP;
+                const char* tsrc = after;
+                int tbytes = FIRST_H;
+                if (skip) tbytes = KCH * STEP;                    // the skip layer's encoding columns follow
+                else if (is_feat) tbytes = FIRST_HD;              // layers_dir[0]'s hidden columns follow
+                else if (last_density) { tsrc = args.wstream; tbytes = wrap_bytes; }
+                gemm_stage_g<NT, KH, NW, KCH, false>(acc, in, 0, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                gw = after;
+            }
+            if (skip) {   // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
+                const char* after = gw + enc_x_bytes;
+                const char* tsrc = after;
+                int tbytes = FIRST_H;
+                if (last_density) { tsrc = args.wstream; tbytes = wrap_bytes; }
+                gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                gw = after;
+            }
+            acc_to_operand<NT, true>(acc, in);
+        }
+
+        if (density_only) {
+            sigma = alpha_gemv<HP>(in, lds_walpha, g) + tail_bias[0];
+            if (flat) flat_head<HP>(args, in, lds_wrgb, tail_bias, sigma, sample, valid, g);   // use_viewdirs = 0 (models.py:77-79)
+            else if (valid && g == 0) args.out[sample] = sigma;
+            continue;
+        }
+
+        // ---- layers_dir[0]: cat(feat, dir_enc) -> H/2, relu (models.py:72-74): hidden columns, then the encoding columns
+        f32x4 accd[NTD];
+        float v[KD];
+        load_bias<NTD>(accd, lds_bias + HP * (1 + num_layers), g);
+        {
+            const char* after = gw + KH * STEPD;
+            const bool has_enc = chd > 0;
+            gemm_stage_g<NTD, KH, NW, KCH, false>(accd, in, 0, gw, has_enc ? after : args.wstream,
+                                                  has_enc ? KCH * STEPD : wrap_bytes, lds, SLOT, par, wave, lane);
+            gw = after;
+            if (has_enc) {
+                float encd[G_ENC_STEPS];
+                encode_g(encd, d, lds_tab + G_ENC_ARGS, args.g_nsd, args.g_idd, g);
+                gemm_stage_g<NTD, G_ENC_STEPS, NW, KCH, true>(accd, encd, chd, gw, args.wstream, wrap_bytes, lds, SLOT, par, wave, lane);
+            }
+        }
+        acc_to_operand<NTD, true>(accd, v);
+
+        // ---- fc_rgb + sigmoid (models.py:75), 3-row GEMV on the VALU
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float part = 0.0f;
+            const float* wr = lds_wrgb + (ch * 4 + g) * KD;
+#pragma unroll
+            for (int s = 0; s < KD; s += 4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part = fmaf(v[s + q], w4[q], part);
+            }
+            const float x = group_sum(part) + tail_bias[1 + ch];
+            rgb[ch] = 1.0f / (1.0f + expf(-x));
+        }
+        if (valid && g == 0) {
+            f32x4 o4 = {rgb[0], rgb[1], rgb[2], sigma};
+            *reinterpret_cast<f32x4*>(args.out + 4 * sample) = o4;
+        }
+    }
+}
+
+}  // namespace nm

@@ -28,45 +28,38 @@
 // kernel issues 9 280 MFMAs (1 024 MAC each) per 16-sample tile = 99.9 % useful work.
 #include <stdlib.h>
 
+#include <iterator>
 #include <mutex>
+#include <vector>
 
 #include "nm_internal.h"
 #include "mlp_device.h"
 #include "mlp_device_r3.h"
 #include "mlp_device_b3.h"
+#include "mlp_device_g.h"
 
 namespace nm {
 
 
 // ---- host side: plan table + launcher ------------------------------------------------------
-struct MlpPlan {
-    int H, FX, FD, NW, KCH, variant;
-    int ring_bytes;
-    bool lds_bias;
-    void (*kernel)(const MlpArgs, const int, const int);
-    int wg_samples;      // samples one workgroup evaluates per iteration
-    int wg_per_cu;       // workgroups co-resident on a CU
-    void (*kernel_flat)(const MlpArgs, const int, const int);   // the FLAT instantiation (use_viewdirs = 0 networks), or null
-};
-
 template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD = false, int ABL = 0>
 static MlpPlan make_plan(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
                    &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>, NW * 16, 8 / NW,
-                   (ABL == 0 && LBIAS) ? &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false, true> : nullptr};
+                   (ABL == 0 && LBIAS) ? &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false, true> : nullptr, 0};
 }
 
 template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0>
 static MlpPlan make_plan3(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 3 * Net<H, FX, FD, KCH>::LDSBUF, true, &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL>,
-                   NW * 16, 8 / NW, ABL == 0 ? &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL, true> : nullptr};
+                   NW * 16, 8 / NW, ABL == 0 ? &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL, true> : nullptr, 0};
 }
 
 // variant 0 is the production choice and the ONLY one in libnerfmeshes_hip.so.  The others exist for within-process
 // A/B runs (scripts/bench_mlp.py) and are compiled only with -DNM_ABLATIONS into a separate library
 // (libnerfmeshes_hip_ablations.so, `python -m nerfmeshes_amd.build --ablations`), where NM_MLP_VARIANT=<n> selects
 // them; the product library never reads that variable, so an inherited environment cannot change its results.
-static const MlpPlan g_plans[] = {
+static const MlpPlan g_tuned_plans[] = {
     // production: the round-2 kernel (3-slot ring, operand stream across boundaries, staggered scalar-addressed DMA)
     // for the 256- and 128-wide networks; 64-wide networks (2-tile view layer) keep the round-1 dataflow
     make_plan3<256, 10, 4, 8, 8, 1>(0),
@@ -100,6 +93,21 @@ static const MlpPlan g_plans[] = {
 #endif
 };
 
+// the generic-shape family (mlp_device_g.h), instantiated in nerf_mlp_generic_{a,b,c,d}.hip, in ascending width
+void generic_plans_a(std::vector<MlpPlan>&);
+void generic_plans_b(std::vector<MlpPlan>&);
+void generic_plans_c(std::vector<MlpPlan>&);
+void generic_plans_d(std::vector<MlpPlan>&);
+
+static const std::vector<MlpPlan>& all_plans() {
+    static const std::vector<MlpPlan> plans = [] {
+        std::vector<MlpPlan> v(std::begin(g_tuned_plans), std::end(g_tuned_plans));
+        generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v);
+        return v;
+    }();
+    return plans;
+}
+
 // opt-in bf16x3 precision (mlp_device_b3.h)
 struct B3Plan {
     int H, FX, FD;
@@ -116,23 +124,32 @@ static const B3Plan* find_b3_plan(int H, int FX, int FD) {
 }
 bool has_b3_kernel(int H, int FX, int FD) { return find_b3_plan(H, FX, FD) != nullptr; }
 
+// A tuned plan when one is instantiated for exactly this shape (and the input itself is part of both encodings, which the
+// tuned kernels' identity k-step assumes is laid out -- its weights may still be zero); otherwise the narrowest class of
+// the generic family that holds the network; null only beyond the family's limits (mlp_api.hip says which).
 const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
     int want = 0;
 #ifdef NM_ABLATIONS
     if (const char* v = getenv("NM_MLP_VARIANT")) want = atoi(v);
 #endif
     const MlpPlan* fallback = nullptr;
-    for (const MlpPlan& p : g_plans)
-        if (p.H == H && p.FX == FX && p.FD == FD) {
+    for (const MlpPlan& p : all_plans())
+        if (!p.generic_nt && p.H == H && p.FX == FX && p.FD == FD) {
             if (p.variant == want) return &p;
             if (p.variant == 0) fallback = &p;
         }
     return fallback;
 }
 
+const MlpPlan* find_generic_plan(int H) {
+    for (const MlpPlan& p : all_plans())
+        if (p.generic_nt && p.H >= H) return &p;
+    return nullptr;
+}
+
 int mlp_plan_info(const MlpPlan* p, int* nw) {
     *nw = p->NW;
-    return p->variant;
+    return p->generic_nt ? 1000 + p->generic_nt : p->variant;     // generic family: 1000 + width class
 }
 
 // The handle's device must be current for the launch (the stream belongs to it): a model on cuda:1 used from a process
@@ -174,18 +191,23 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     // bias cache + fc_alpha + fc_rgb rows; a use_viewdirs = 0 network (mode 2) keeps three H-wide fc_out rows where fc_rgb's
     // three H/2-wide ones go
     const int rgb_floats = density_only == 2 ? 3 * H : 3 * H / 2;
-    const int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + rgb_floats) * 4 + 255) & ~255) : 0);
+    int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + rgb_floats) * 4 + 255) & ~255) : 0);
+    if (p->generic_nt) {    // padded widths, both head layouts, the two argument tables (mlp_device_g.h)
+        const int HP = 16 * p->generic_nt, HPD = 16 * ((p->generic_nt + 1) / 2);
+        lds_bytes = p->ring_bytes + (HP * (1 + L) + HPD + 4 + HP + 3 * HP) * 4 + 2 * G_ENC_ARGS * (int)sizeof(GEncArg);
+    }
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     // the dynamic-LDS attribute is per device: tracked per (device, plan)
     // (two host threads creating / launching models race on it otherwise: the table is read and written under a lock)
-    static int attr_bytes[64][2 * sizeof(g_plans) / sizeof(g_plans[0])] = {};
+    static std::vector<int> attr_bytes(64 * 2 * all_plans().size(), 0);
     static std::mutex attr_lock;
-    const int idx = 2 * (int)(p - g_plans) + (density_only == 2 ? 1 : 0), dev = (m->device >= 0 && m->device < 64) ? m->device : 0;
+    const int idx = 2 * (int)(p - all_plans().data()) + (density_only == 2 ? 1 : 0), dev = (m->device >= 0 && m->device < 64) ? m->device : 0;
     {
         std::lock_guard<std::mutex> hold(attr_lock);
-        if (attr_bytes[dev][idx] < lds_bytes) {
+        int& have = attr_bytes[(size_t)dev * 2 * all_plans().size() + idx];
+        if (have < lds_bytes) {
             NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            attr_bytes[dev][idx] = lds_bytes;
+            have = lds_bytes;
         }
     }
     const int64_t wg_iters = (args.n + p->wg_samples - 1) / p->wg_samples;

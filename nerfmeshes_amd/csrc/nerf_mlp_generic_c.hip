@@ -1,0 +1,25 @@
+// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part c: width classes NT = 14, 16, 20 (hidden_size <= 16 NT).
+// One translation unit per group of classes so that the build compiles them side by side (nerfmeshes_amd/build.py).
+#include <vector>
+
+#include "nm_internal.h"
+#include "mlp_device_g.h"
+
+namespace nm {
+
+template <int NT>
+static MlpPlan generic_plan() {
+    constexpr int NW = NT <= 16 ? 8 : 4;      // wide classes: one wave per SIMD on the 512-register budget
+    constexpr int KCH = NT <= 16 ? 8 : 4;     // 32 KiB ring slots either way
+    constexpr int SLOT = KCH * ((NT + 3) / 4) * 1024;
+    return MlpPlan{16 * NT, -1, -1, NW, KCH, 0, 2 * SLOT, true, &mlp_kernel_g<NT, NW, KCH>, NW * 16, 1,
+                   &mlp_kernel_g<NT, NW, KCH>, NT};
+}
+
+void generic_plans_c(std::vector<MlpPlan>& out) {
+    out.push_back(generic_plan<14>());
+    out.push_back(generic_plan<16>());
+    out.push_back(generic_plan<20>());
+}
+
+}  // namespace nm

@@ -117,6 +117,10 @@ struct MlpArgs {
     uint64_t* mask_v;        // (tiles, 64)
     int64_t tiles;           // ceil(n / 16)
     RayGen gen;              // VIEW: rays generated from the pose (c = t as in RAYS; a, b unused)
+    // generic-shape kernels only (mlp_device_g.h): the encodings' run-time description
+    const void* g_tab;       // device: GEncArg[2][48] (xyz, dir): coordinate and frequency band of every encoding argument
+    int32_t g_nsx, g_idx, g_chx;   // xyz: k-steps that carry arguments, 1 = an identity step follows, whole chunks in the stream
+    int32_t g_nsd, g_idd, g_chd;   // direction encoding likewise (g_chd = 0: no encoded direction columns at all)
 };
 
 // Kernel arguments of the backward (delta propagation) kernel.
@@ -142,7 +146,17 @@ enum TensorId : int {
 };
 struct WeightPtrs { const float* p[T_COUNT]; };
 
-struct MlpPlan;  // host-side description of one template instantiation
+// host-side description of one template instantiation of the fused forward kernel
+struct MlpPlan {
+    int H, FX, FD, NW, KCH, variant;
+    int ring_bytes;
+    bool lds_bias;
+    void (*kernel)(const MlpArgs, const int, const int);
+    int wg_samples;      // samples one workgroup evaluates per iteration
+    int wg_per_cu;       // workgroups co-resident on a CU
+    void (*kernel_flat)(const MlpArgs, const int, const int);   // the FLAT instantiation (use_viewdirs = 0 networks), or null
+    int generic_nt;      // 0: a tuned plan for exactly (H, FX, FD) | NT: the generic family's width class (mlp_device_g.h), H = 16 NT
+};
 
 // fused MLP over rays generated from a camera pose (mlp_api.hip; used by the render path in ray_ops.hip)
 int nm_mlp_eval_view_internal(nm_mlp* m, const RayGen* gen, const float* d_t, int64_t rays, int32_t samples,
@@ -169,4 +183,5 @@ struct nm_mlp {
     float* d_tmp_b3;         // gathered fp32 image [unit][lane][8] the planes are split from
     int32_t* d_index_b3;
     size_t b3_units;
+    void* d_enc_tab;         // generic plans: GEncArg[2][48]
 };

@@ -40,12 +40,13 @@ PRECISIONS = {"f32": 0, "bf16x3": 1}
 class HipMLP:
     """Device-resident packed copy of one FlexibleNeRFModel (handle of nm_mlp_create_ex)."""
 
-    def __init__(self, state, desc, device, precision="f32"):
+    def __init__(self, state, desc, device, precision="f32", force_generic=False):
         """state: dict name -> array-like in torch.nn.Linear layout, keyed like
         FlexibleNeRFModel.state_dict(); desc: dict of constructor hyper-parameters.
         precision: "f32" (default: fp32 MFMA, the reference's arithmetic) or the opt-in "bf16x3" (every product emulated
         by six bf16 MFMA products of three-way operand splits, fp32 accumulation: fp32-class error, ~2x the throughput,
-        inference only, 256-wide networks)."""
+        inference only, 256-wide networks).  force_generic: bind to the generic-shape kernel family even where a tuned
+        kernel exists for the shape (NM_KERNEL_GENERIC: a cross-check, same results bit for bit)."""
         lib = _lib.load()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
@@ -92,7 +93,8 @@ class HipMLP:
                            arr("encode_xyz.frequency_bands"), arr("encode_dir.frequency_bands"))
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        check(lib.nm_mlp_create_ex(C.byref(d), C.byref(w), idx, PRECISIONS[precision], C.byref(self._h)), "nm_mlp_create_ex")
+        check(lib.nm_mlp_create_ex(C.byref(d), C.byref(w), idx, PRECISIONS[precision] | (0x100 if force_generic else 0),
+                                   C.byref(self._h)), "nm_mlp_create_ex")
         self._lib = lib
         self.desc = dict(desc)
 

@@ -141,9 +141,13 @@ def make_scene_weights(seed=SCENE_SEED, **mlp_kwargs):
 
 # The same construction for the narrower shipped shapes (round 4: strict-bar PSNR fixtures for them): shape -> (network
 # arguments, raw fc_alpha mean / std of the band-limited draw along orbit rays -- tests/golden/calibrate_scene.py --, gain).
+# The gain is the largest of 6e4 / 2e4 / 6e3 at which the REFERENCE'S OWN self-noise on the fixture's 8192 rays -- the same
+# network with its hidden units permuted, a different order of the same fp32 sums -- stays below 1e-5 dB (same script): a
+# scene on which the reference differs from itself by more than the bar cannot carry a 1e-4 dB comparison (at gain 6e4 the
+# 8x128 scene has one ray that moves by 0.05 under a permutation: 5e-3 dB on 8192 rays).
 SMOOTH_SCENES = {
     "fern_8x128": (dict(num_layers=8, hidden_size=128, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4),
-                   0.117229, 0.008811, 6.0e4),          # config/nerf-colmap-fern.yml:115,152
+                   0.117229, 0.008811, 2.0e4),          # config/nerf-colmap-fern.yml:115,152
     "tiny_4x64": (dict(num_layers=4, hidden_size=64, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
                   0.011192, 0.008393, 6.4e4),           # BASELINE configs[0]: 4-layer x 64
 }

@@ -27,7 +27,7 @@ def test_c_program_through_the_c_abi(tmp_path):
                     "-L", libdir, "-lnerfmeshes_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", str(exe)], check=True)
     kw = dict(num_layers=4, hidden_size=64, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
-    w = S.make_mlp_weights(31, density_gain=50.0, density_bias=1.0, **kw)
+    w = S.make_mlp_weights(31, density_gain=50.0, density_bias=6.5, **kw)    # bias: the rays of the render leg see a half-empty scene
     order = ["layer1"] + [f"layers_xyz.{i}" for i in range(3)] + ["layers_dir.0", "fc_alpha", "fc_rgb", "fc_feat"]
     flat = [np.concatenate([w[n + ".weight"].ravel(), w[n + ".bias"].ravel()]) for n in order]
     flat += [(2.0 ** np.arange(6)).astype(np.float32), (2.0 ** np.arange(4)).astype(np.float32)]

@@ -1,0 +1,167 @@
+"""GPU: the generic-shape kernel family (nerfmeshes_amd/csrc/mlp_device_g.h) -- every FlexibleNeRFModel shape the reference's
+constructor accepts (/root/reference/src/nerf/models.py:5-58) is served, not only the shipped configs' shapes.  Off-menu
+shapes against the CPU oracle at the tuned kernels' tolerance (2e-5), through every entry point; on a menu shape the family
+reproduces the tuned kernel bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from nerfmeshes_amd import synthetic as S
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X")
+    from nerfmeshes_amd import hip_ops
+    return hip_ops
+
+
+def _desc(kw):
+    spec = O.MLPSpec(**kw)
+    return spec, {k: getattr(spec, k) for k in ("num_layers", "hidden_size", "skip_step", "num_encoding_fn_xyz", "num_encoding_fn_dir",
+                                                "include_input_xyz", "include_input_dir", "log_sampling_xyz", "log_sampling_dir", "use_viewdirs")}
+
+
+def _close(got, ref, atol, what):
+    got, ref = got.detach().cpu().numpy(), ref.detach().cpu().numpy()
+    err = np.abs(got - ref)
+    assert got.shape == ref.shape and np.all(err <= atol), f"{what}: max err {err.max():.3e} > {atol:.3e}"
+
+
+# off-menu shapes: what a user's config may say that no shipped config does
+OFF_MENU = [
+    dict(hidden_size=512),                                                            # "a user's 8x512 ..."
+    dict(num_encoding_fn_xyz=8),                                                      # "... or F_xyz = 8 checkpoint"
+    dict(hidden_size=32, num_layers=4, skip_step=2, num_encoding_fn_xyz=4, num_encoding_fn_dir=2),   # the reference-script runner's network
+    dict(hidden_size=48, num_layers=3, num_encoding_fn_xyz=5, num_encoding_fn_dir=3),                # odd tile count, odd argument counts
+    dict(hidden_size=96, num_layers=5, skip_step=2),
+    dict(hidden_size=100, num_layers=4, num_encoding_fn_xyz=7, num_encoding_fn_dir=1),               # not a multiple of 16; 50-row view layer
+    dict(hidden_size=160, num_encoding_fn_xyz=12, num_encoding_fn_dir=6),
+    dict(hidden_size=192, num_layers=6, skip_step=3, include_input_xyz=False),
+    dict(hidden_size=256, include_input_dir=False, include_input_xyz=False),                          # no inputs in the encodings (a tuned plan serves it: zero weights on its identity step)
+    dict(hidden_size=256, num_encoding_fn_xyz=15, num_encoding_fn_dir=15),                            # the longest encodings: 24 k-steps each
+    dict(hidden_size=272, num_layers=4),                                                              # 17 tiles -> class 20 (4 waves, 512 registers)
+    dict(hidden_size=320, num_layers=5, num_encoding_fn_xyz=6),
+    dict(hidden_size=384, num_layers=4, num_encoding_fn_dir=0),                                       # direction = the raw vector only
+    dict(hidden_size=448, num_layers=3, num_encoding_fn_xyz=0),                                       # xyz = the raw point only
+    dict(hidden_size=128, num_encoding_fn_dir=0, include_input_dir=False),                            # no direction columns at all
+    dict(hidden_size=64, num_layers=2, num_encoding_fn_xyz=3, log_sampling_xyz=False, log_sampling_dir=False),
+    dict(hidden_size=16, num_layers=2, num_encoding_fn_xyz=2, num_encoding_fn_dir=1),                 # one tile
+    dict(hidden_size=224, num_layers=10, skip_step=1),                                                # a skip at every layer
+    dict(hidden_size=144, use_viewdirs=False, num_encoding_fn_xyz=9),
+    dict(hidden_size=400, num_layers=4, use_viewdirs=False),
+]
+
+
+@pytest.mark.parametrize("kw", OFF_MENU, ids=lambda kw: "-".join(f"{k.replace('num_encoding_fn_', 'F').replace('hidden_size', 'H')}{v}" for k, v in kw.items()))
+def test_off_menu_shapes_vs_oracle(ops, kw):
+    spec, desc = _desc(kw)
+    w = S.make_mlp_weights(29, density_gain=40.0, density_bias=1.0, **desc)
+    mlp = ops.HipMLP(w, desc, "cuda")
+    variant, waves = mlp.kernel_variant()
+    on_menu = spec.hidden_size in (64, 128, 256) and spec.num_encoding_fn_xyz in (6, 10) and spec.num_encoding_fn_dir == 4
+    assert variant == 0 if on_menu else (variant >= 1000 and 16 * (variant - 1000) >= spec.hidden_size), "an off-menu shape runs on the generic family"
+    g = torch.Generator().manual_seed(5)
+    n = 3000
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * 4.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    ref = O.mlp_forward(w, spec, pts, dirs)
+    scale = float(ref[:, 3].abs().max()) + 1.0
+    got = mlp.sample_points(pts.cuda(), dirs.cuda())
+    _close(got[:, :3], ref[:, :3], 2e-5, "rgb")
+    _close(got[:, 3], ref[:, 3], 2e-5 * scale, "sigma")
+    for m in (1, 16, 17, 129):                                 # ragged tails: fewer samples than a wave / a workgroup
+        part = mlp.sample_points(pts[:m].cuda(), dirs[:m].cuda())
+        assert torch.equal(part, got[:m]), f"n = {m}: a sample's value may not depend on the batch it is in"
+    # rays (o + d t in the prologue) and the grid entry point, density-only == the full evaluation's sigma bit for bit
+    rays, samples = 300, 9
+    o = (torch.rand(rays, 3, generator=g) - 0.5) * 2.0
+    d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1)
+    t = torch.sort(torch.rand(rays, samples, generator=g) * 3.0, dim=-1).values
+    ray_pts = o[:, None, :] + d[:, None, :] * t[..., None]
+    ref_r = O.mlp_forward(w, spec, ray_pts.reshape(-1, 3), d[:, None, :].expand(rays, samples, 3).reshape(-1, 3))
+    got_r = mlp.eval_rays(o.cuda(), d.cuda(), t.cuda()).reshape(-1, 4)
+    _close(got_r[:, :3], ref_r[:, :3], 2e-5, "rgb (rays)")
+    _close(got_r[:, 3], ref_r[:, 3], 2e-5 * (float(ref_r[:, 3].abs().max()) + 1.0), "sigma (rays)")
+    ax = torch.linspace(-1.2, 1.2, 11)
+    full, dens = mlp.grid_query(ax, ax, ax, density_only=False), mlp.grid_query(ax, ax, ax, density_only=True)
+    assert torch.equal(full[:, 3], dens)
+    grid = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3)
+    ref_g = O.mlp_forward(w, spec, grid, grid)
+    _close(full[:, :3], ref_g[:, :3], 2e-5, "rgb (grid)")
+    _close(dens, ref_g[:, 3], 2e-5 * (float(ref_g[:, 3].abs().max()) + 1.0), "sigma (grid)")
+    assert mlp.flops_per_sample() == 2 * sum(a * b for _, a, b in S.mlp_layer_shapes(**desc)), "useful FLOP only: padding is not counted"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hidden_size=128), dict(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6),
+                                dict(hidden_size=128, num_layers=6, skip_step=2, num_encoding_fn_xyz=6), dict(use_viewdirs=False)])
+def test_generic_family_reproduces_the_tuned_kernels_bit_for_bit(ops, kw):
+    """NM_KERNEL_GENERIC on a menu shape: same sincosf on the same products, the same fp32 MFMA chains over the same column
+    order (padded k-steps add exact zeros at the end of a chain) -> identical radiance, all four input modes."""
+    spec, desc = _desc(kw)
+    w = S.make_mlp_weights(3, density_gain=60.0, density_bias=2.0, **desc)
+    tuned, generic = ops.HipMLP(w, desc, "cuda"), ops.HipMLP(w, desc, "cuda", force_generic=True)
+    assert tuned.kernel_variant()[0] == 0 and generic.kernel_variant()[0] == 1000 + spec.hidden_size // 16
+    g = torch.Generator().manual_seed(1)
+    pts = ((torch.rand(4099, 3, generator=g) * 2 - 1) * 5.0).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(4099, 3, generator=g), dim=-1).cuda()
+    assert torch.equal(tuned.sample_points(pts, dirs), generic.sample_points(pts, dirs))
+    t = torch.sort(torch.rand(500, 12, generator=g) * 4.0 + 2.0, dim=-1).values.cuda()
+    assert torch.equal(tuned.eval_rays(pts[:1], dirs[:500], t), generic.eval_rays(pts[:1], dirs[:500], t))
+    ax = torch.linspace(-1.2, 1.2, 17)
+    for density_only in (True, False):
+        assert torch.equal(tuned.grid_query(ax, ax, ax, density_only=density_only), generic.grid_query(ax, ax, ax, density_only=density_only))
+    if spec.use_viewdirs:
+        view = ops.make_view(S.orbit_poses(4)[1], 40, 50, 60.0)
+        near, far, u = torch.tensor([2.0]), torch.tensor([6.0]), torch.linspace(0, 1, 16)
+        a = ops.render_view(tuned, tuned, view, near, far, u, torch.linspace(0, 1, 24))
+        b = ops.render_view(generic, generic, view, near, far, u, torch.linspace(0, 1, 24))
+        assert all(torch.equal(a[1][k], b[1][k]) for k in ("rgb_map", "depth_map", "acc_map", "weights"))
+
+
+def test_render_and_module_surface_on_an_off_menu_shape(ops):
+    """The whole render path (nm_render_rays) and the module surface (nerf.FlexibleNeRFModel, parameter refresh after an
+    in-place update) on a shape outside the menu; training such a network says so instead of running something else."""
+    from nerfmeshes_amd.nerf import FlexibleNeRFModel
+    kw = dict(num_layers=5, hidden_size=80, skip_step=2, num_encoding_fn_xyz=7, num_encoding_fn_dir=3)
+    spec, desc = _desc(kw)
+    w = S.make_mlp_weights(8, density_gain=3000.0, density_bias=100.0, **desc)
+    mlp = ops.HipMLP(w, desc, "cuda")
+    o, d = ops.ray_bundle(S.orbit_poses(4)[1], 800, 800, S.LEGO_FOCAL_800)
+    d = d[torch.arange(0, 640000, 2500, device="cuda")].contiguous()
+    cb, fb = ops.render_rays(mlp, mlp, o[None], d, torch.tensor([2.0]), torch.tensor([6.0]), torch.linspace(0, 1, 32), torch.linspace(0, 1, 48))
+    rc, rf = O.render(w, w, spec, spec, O.RenderSpec(num_coarse=32, num_fine=48), o[None].cpu(), d.cpu(), 2.0, 6.0)
+    _close(cb["rgb_map"], rc["rgb_map"], 1e-4, "coarse rgb_map")
+    err = (fb["rgb_map"].cpu() - rf["rgb_map"]).abs().max(-1).values
+    assert float((err <= 1e-4).float().mean()) >= 0.97 and float(err.max()) < 5e-2, (float(err.max()), int((err > 1e-4).sum()))
+    net = FlexibleNeRFModel(**kw).cuda().eval()
+    pts, dirs = torch.rand(200, 3).cuda(), torch.rand(200, 3).cuda()
+    with torch.no_grad():
+        a = net(pts, dirs)
+        net.layer1.weight.mul_(1.5)
+        b = net(pts, dirs)
+        ref = O.mlp_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, spec, pts.cpu(), dirs.cpu())
+    assert not torch.equal(a, b)
+    _close(b[:, :3], ref[:, :3], 2e-5, "module rgb after an in-place update")
+    with pytest.raises(Exception, match="training kernel|shape"):
+        net.train()
+        net(pts, dirs).sum().backward()
+
+
+def test_limits_of_the_family_are_errors_with_a_reason(ops):
+    from nerfmeshes_amd import _lib
+    for kw, why in ((dict(hidden_size=528, num_layers=2), "512"), (dict(num_encoding_fn_xyz=16), "k-steps"),
+                    (dict(num_encoding_fn_xyz=0, include_input_xyz=False), "empty")):
+        spec, desc = _desc(kw)
+        with pytest.raises(_lib.HipLibraryError, match=why):
+            ops.HipMLP(S.make_mlp_weights(1, **desc), desc, "cuda")
+    spec, desc = _desc(dict(num_encoding_fn_xyz=16, include_input_xyz=False, hidden_size=64, num_layers=2))    # 24 k-steps exactly
+    w = S.make_mlp_weights(2, **desc)
+    pts = torch.rand(64, 3)
+    got = ops.HipMLP(w, desc, "cuda").sample_points(pts.cuda(), pts.cuda()).cpu()
+    ref = O.mlp_forward(w, spec, pts, pts)
+    assert float((got[:, :3] - ref[:, :3]).abs().max()) < 1e-3      # 2^15 x: the argument itself carries 2^-9 of absolute error

@@ -531,7 +531,8 @@ def test_mesh_topology_end_to_end_vs_cpu_grid(ops, res):
     print("mesh topology end to end:", rep)
     assert rep["cubes_cut_by_the_surface"] > 1000 and rep["faces_ref"] > 2000, "the scene must have a surface in the cube"
     assert rep["max_abs_dsigma_over_scale"] <= 2e-5
-    assert abs(iso_hip - iso_ref) <= 1e-5 * max(1.0, abs(iso_ref))
+    # the adaptive level is max - std here: it inherits the grid's own round-off at the largest voxel (sigma scale ~ 6e2)
+    assert abs(iso_hip - iso_ref) <= 2e-5 * (float(np.abs(ref).max()) + 1.0)
     assert rep["within_budget"], rep
 
 
