@@ -93,16 +93,17 @@ static const MlpPlan g_tuned_plans[] = {
 #endif
 };
 
-// the generic-shape family (mlp_device_g.h), instantiated in nerf_mlp_generic_{a,b,c,d}.hip, in ascending width
+// the generic-shape family (mlp_device_g.h), instantiated in nerf_mlp_generic_{a..e}.hip, in ascending width
 void generic_plans_a(std::vector<MlpPlan>&);
 void generic_plans_b(std::vector<MlpPlan>&);
 void generic_plans_c(std::vector<MlpPlan>&);
 void generic_plans_d(std::vector<MlpPlan>&);
+void generic_plans_e(std::vector<MlpPlan>&);
 
 static const std::vector<MlpPlan>& all_plans() {
     static const std::vector<MlpPlan> plans = [] {
         std::vector<MlpPlan> v(std::begin(g_tuned_plans), std::end(g_tuned_plans));
-        generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v);
+        generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_e(v);
         return v;
     }();
     return plans;

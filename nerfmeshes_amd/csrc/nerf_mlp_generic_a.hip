@@ -1,4 +1,4 @@
-// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part a: width classes NT = 1, 2, 3, 4, 5, 6 (hidden_size <= 16 NT).
+// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part a: width classes NT = 1, 2, 3, 4, 5, 6, 7 (hidden_size <= 16 NT).
 // One translation unit per group of classes so that the build compiles them side by side (nerfmeshes_amd/build.py).
 #include <vector>
 
@@ -23,6 +23,7 @@ void generic_plans_a(std::vector<MlpPlan>& out) {
     out.push_back(generic_plan<4>());
     out.push_back(generic_plan<5>());
     out.push_back(generic_plan<6>());
+    out.push_back(generic_plan<7>());
 }
 
 }  // namespace nm

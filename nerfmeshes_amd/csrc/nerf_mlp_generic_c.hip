@@ -1,4 +1,4 @@
-// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part c: width classes NT = 14, 16, 20 (hidden_size <= 16 NT).
+// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part c: width classes NT = 14, 15, 16, 18, 20 (hidden_size <= 16 NT).
 // One translation unit per group of classes so that the build compiles them side by side (nerfmeshes_amd/build.py).
 #include <vector>
 
@@ -18,7 +18,9 @@ static MlpPlan generic_plan() {
 
 void generic_plans_c(std::vector<MlpPlan>& out) {
     out.push_back(generic_plan<14>());
+    out.push_back(generic_plan<15>());
     out.push_back(generic_plan<16>());
+    out.push_back(generic_plan<18>());
     out.push_back(generic_plan<20>());
 }
 

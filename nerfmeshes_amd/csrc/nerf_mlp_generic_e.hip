@@ -1,4 +1,4 @@
-// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part b: width classes NT = 8, 9, 10, 11, 12, 13 (hidden_size <= 16 NT).
+// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part e: width classes NT = 28, 30, 32 (hidden_size <= 16 NT).
 // One translation unit per group of classes so that the build compiles them side by side (nerfmeshes_amd/build.py).
 #include <vector>
 
@@ -16,13 +16,10 @@ static MlpPlan generic_plan() {
                    &mlp_kernel_g<NT, NW, KCH>, NT};
 }
 
-void generic_plans_b(std::vector<MlpPlan>& out) {
-    out.push_back(generic_plan<8>());
-    out.push_back(generic_plan<9>());
-    out.push_back(generic_plan<10>());
-    out.push_back(generic_plan<11>());
-    out.push_back(generic_plan<12>());
-    out.push_back(generic_plan<13>());
+void generic_plans_e(std::vector<MlpPlan>& out) {
+    out.push_back(generic_plan<28>());
+    out.push_back(generic_plan<30>());
+    out.push_back(generic_plan<32>());
 }
 
 }  // namespace nm

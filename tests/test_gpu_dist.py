@@ -47,14 +47,16 @@ def test_rccl_sharded_render_grid_mesh(world):
     assert f"DIST_OK world={world} backend=nccl" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_sharing_one_gpu_over_gloo(world):
     """N > 1 with the REAL kernels on a one-GPU box: `world` processes on cuda:0 over gloo (RCCL refuses duplicate
     devices).  Sharded pixels, slab-sharded grid -> marching cubes, vertex-sharded appearance re-query + OBJ, ragged
-    eval-loss gather, gradient all-reduce of a real training step -- each equal to the 1-rank result bit for bit."""
+    eval-loss gather, gradient all-reduce of a real training step, and the 480-plane / 5-plane per-slab marching-cubes
+    rehearsal (ragged and empty triangle shards, ranks without a cube layer) -- each equal to the 1-rank result bit for
+    bit.  world = 8 is the node size the driver's scaling run uses: every 8-rank code path has run before it does."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a MI355X")
-    r = _torchrun(world, os.path.join("tests", "tools", "dist_worker.py"), timeout=900,
+    r = _torchrun(world, os.path.join("tests", "tools", "dist_worker.py"), timeout=1500,
                   env={"NERFMESHES_RANKS_PER_GPU": str(world), "NM_EXPECT_BACKEND": "gloo"})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert f"DIST_OK world={world} backend=gloo device=cuda:0" in r.stdout, r.stdout[-2000:]
@@ -109,6 +111,28 @@ def test_bench_two_ranks_on_one_gpu_carries_the_sharded_objects(mode):
     assert mesh["marching_cubes"]["bitwise_identical_to_oracle"] is True and mesh["marching_cubes"]["iso_equals_numpy_fp32"] is True
     assert buff["rays_per_rank"] == [95256, 95256] and len(buff["roofline"]["frac_per_rank"]) == 2 and buff["value"] > 1e4
     assert "cpu_baseline" not in line and "train" not in line            # N = 1 only
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """`python bench.py --gpus 1 --ranks-per-gpu 8 --mesh-res 120`: the exact launch shape of the driver's 8-GPU scaling run
+    (8 ranks, views dealt to the ranks, 8-way slab split of the mesh grid, ray-sharded BuFF view) rehearsed on one GPU over
+    gloo -- a functional run: its rates say nothing about scaling, its objects must all be there and consistent."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--ranks-per-gpu", "8", "--steps", "1", "--warmup", "1",
+                        "--mesh-res", "120", "--no-cpu-baseline"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    printed = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, printed
+    line = json.loads(printed[0])
+    assert line["n_gpus"] == 1 and line["ranks_per_gpu"] == 8 and line["scaling"] == "weak" and "FUNCTIONAL" in line["note"]
+    assert line["rccl"]["ranks_in_all_gather"] == 8 and line["rccl"]["slots_match_rank_checksums"] is True
+    assert line["rccl"]["gathered_bytes_per_step"] == 8 * 640000 * 3 * 4 and len(line["rccl"]["roofline_frac_per_rank"]) == 8
+    mesh = line["mesh"]
+    assert mesh["grid_query"]["planes_per_rank"] == [15] * 8
+    for strategy in ("grid", "triangles"):
+        assert mesh["sharded"]["strategies"][strategy]["faces_and_normals_equal_single_grid_mesh"] is True
+    assert mesh["marching_cubes"]["bitwise_identical_to_oracle"] is True
+    assert len(line["buff"]["rays_per_rank"]) == 8 and sum(line["buff"]["rays_per_rank"]) == 504 * 378
 
 
 def test_bench_self_launches_two_ranks():

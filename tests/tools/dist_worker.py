@@ -101,6 +101,36 @@ def model_level_checks(rank, world, dev):
     return int(out["N"][0].shape[0])
 
 
+def slab_rehearsal(rank, world, dev, mlp):
+    """Per-slab marching cubes the way an 8-GPU node will run it: the 480 axis-0 planes of config 4 at
+    reduced n1 / n2, cube layers dealt to the ranks (`dist.marching_cubes_sharded`), ONLY the triangles gathered
+    (all-gatherv: exact sizes).  The surface lives in part of the slabs, so the ranks' shards are ragged and some are empty;
+    a second, 5-plane grid has fewer cube layers than an 8-rank group has ranks (ranks without any layer still enter every
+    collective).  Both must equal the 1-rank mesh bit for bit, vertex numbering included.  Returns the ranks' face counts."""
+    out = []
+    for n0, n1, n2 in ((480, 24, 20), (5, 24, 20)):
+        ax0 = torch.linspace(-1.2, 1.2, n0).to(dev)
+        ax1, ax2 = torch.linspace(-0.30, 0.30, n1).to(dev), torch.linspace(-0.25, 0.25, n2).to(dev)
+        plane = n1 * n2
+        whole = mlp.grid_query(ax0, ax1, ax2, density_only=True).view(n0, n1, n2)
+        iso = float(whole.float().mean() + 0.5 * whole.float().std())
+        want = hip_ops.marching_cubes(whole, iso)
+        query = lambda p_lo, p_hi: mlp.grid_query(ax0, ax1, ax2, first=p_lo * plane, count=(p_hi - p_lo) * plane, density_only=True)   # noqa: E731
+        v, f, nrm, val, slab = nd.marching_cubes_sharded(query, n0, n1, n2, lambda slab, p_lo, own_lo, own_hi: iso)
+        for name, a, b in zip(("vertices", "faces", "normals", "values"), (v, f, nrm, val), want):
+            assert a.shape == b.shape and torch.equal(a, b), f"{n0} planes on {world} ranks: {name} differ from the 1-rank mesh"
+        # this rank's own share of the faces: those whose first vertex it owns is not defined -- count by layer instead
+        lo, hi, below, above, p_lo, p_hi = nd.slab_layers(n0, rank, world)
+        mine = 0
+        if hi > lo:
+            piece = hip_ops.marching_cubes_slab(slab, iso, p_lo, below, above)
+            mine = piece.faces
+        counts = nd.all_gather_rows(torch.tensor([[mine]], dtype=torch.int64, device=dev), [1] * world).reshape(-1).tolist()
+        assert sum(counts) == f.shape[0], (counts, f.shape)
+        out.append(counts)
+    return out
+
+
 def main():
     rank, world, dev = nd.init_from_env()
     import torch.distributed as dist
@@ -146,6 +176,11 @@ def main():
     gathered = nd.all_gather_rows(local[None].contiguous(), [1] * world)
     assert torch.allclose(lin.weight.grad, gathered.mean(0), rtol=1e-6, atol=1e-7)
 
+    shards = slab_rehearsal(rank, world, dev, mlp)
+    if world > 1:
+        assert len(set(shards[0])) > 1, f"the 480-plane rehearsal is meant to produce ragged triangle shards: {shards[0]}"
+    if world >= 8:
+        assert 0 in shards[0] and shards[1].count(0) >= world - 4, f"empty shards / ranks without a cube layer expected: {shards}"
     mesh_vertices = model_level_checks(rank, world, dev)
 
     # barrier + max-over-ranks reduction as bench.py uses them
@@ -156,7 +191,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"DIST_OK world={world} backend={dist.get_backend()} device={dev} rays={hh * ww} planes={n} "
-              f"vertices={int(v1[0].shape[0])} mesh_vertices={mesh_vertices}", flush=True)
+              f"vertices={int(v1[0].shape[0])} mesh_vertices={mesh_vertices} faces_per_rank_480={shards[0]} faces_per_rank_5={shards[1]}", flush=True)
     nd.shutdown()
 
 
