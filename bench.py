@@ -110,9 +110,13 @@ def _timed(fn, reps):
     return min(ms), sum(ms) / len(ms), out
 
 
-def train_probe(dev, dirs, origin, rays=2048, iters=10):
+def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=True):
     """Secondary figure: one optimizer iteration of the same 8x256 coarse+fine model on a
-    2048-ray batch -- forward in train mode (perturb + noise), MSE(coarse)+MSE(fine), HIP backward, Adam."""
+    2048-ray batch -- forward in train mode (perturb + noise), MSE(coarse)+MSE(fine), HIP backward, Adam.  Roofline: the
+    iteration's algorithmic fp32 matrix work -- forward, delta propagation (hidden columns of the transposed layers) and
+    weight gradients, 524 288 samples x (1.187 + 1.114 + 1.187) MFLOP -- over the WHOLE iteration's wall time against the
+    fp32 MFMA peak (so everything that is not a matrix kernel counts against it).  CPU leg: the same iteration through torch
+    autograd over the oracle on a bounded ray batch."""
     from nerfmeshes_amd import models
     from nerfmeshes_amd.nerf import CfgNode
     torch.manual_seed(0)
@@ -141,8 +145,55 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10):
         iteration()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return {"value": rays / ms * 1e3, "unit": "rays/s", "ms_per_iteration": ms, "rays_per_iteration": rays,
-            "workload": "training step: 8x256 coarse+fine, 64+128 samples, perturb + noise, Adam (forward + HIP backward + step)"}
+    kw = MLP_KW
+    Hh, dx, dd = kw["hidden_size"], 6 * kw["num_encoding_fn_xyz"] + 3, 6 * kw["num_encoding_fn_dir"] + 3
+    fwd = model.model_fine.hip().flops_per_sample()
+    nskip = sum(1 for i in range(kw["num_layers"] - 1) if i % kw["skip_step"] == 0 and i > 0 and i != kw["num_layers"] - 1)
+    delta = fwd - 2 * (dx * Hh * (1 + nskip) + dd * (Hh // 2) + Hh + 3 * (Hh // 2))      # no encoding columns, heads on the VALU
+    samples = rays * (NUM_COARSE + NUM_COARSE + NUM_FINE)
+    flops = samples * (fwd + delta + fwd)
+    achieved = flops / (ms * 1e-3) / 1e12
+    out = {"value": rays / ms * 1e3, "unit": "rays/s", "ms_per_iteration": ms, "rays_per_iteration": rays,
+           "workload": "training step: 8x256 coarse+fine, 64+128 samples, perturb + noise, Adam (forward + HIP backward + step)",
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "samples_per_iteration": samples,
+                        "algorithmic_flops_per_sample": {"forward": fwd, "delta": delta, "weight_gradients": fwd},
+                        "floor_ms_at_peak": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
+                        "note": "whole-iteration wall time (taping forward, delta kernel, dW kernels, encodings, compositing, Adam) "
+                                "against the fp32 MFMA peak"}}
+    if not cpu_legs:
+        return out
+    # ---- the same iteration through torch autograd over the CPU oracle, bounded
+    from oracle import nerf_oracle as O
+    spec, rs = O.MLPSpec(**MLP_KW), O.RenderSpec(training=True)
+    oc, dc, tgt = origin.reshape(1, 3).cpu(), batch[1][:cpu_rays].cpu(), target[:cpu_rays].cpu()
+    wc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.model_coarse.named_parameters()}
+    wf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.model_fine.named_parameters()}
+
+    def cpu_iter():
+        t_c = O.perturb_intervals(O.coarse_intervals(NEAR, FAR, NUM_COARSE, cpu_rays), torch.rand(cpu_rays, NUM_COARSE))
+        loss, tt = 0.0, t_c
+        for w_, first in ((wc, True), (wf, False)):
+            pts = O.ray_points(tt, dc, oc).reshape(-1, 3)
+            dirs_ = dc[:, None, :].expand(-1, tt.shape[1], -1).reshape(-1, 3)
+            rad = O.mlp_forward(w_, spec, pts, dirs_, keep_graph=True).reshape(cpu_rays, -1, 4)
+            b = O.composite(rad, tt, dc, rs, noise=0.2 * torch.randn(cpu_rays, tt.shape[1]))
+            loss = loss + torch.nn.functional.mse_loss(b["rgb_map"], tgt)
+            if first:
+                tt = O.sample_pdf_intervals(t_c, b["weights"].detach(), NUM_FINE, u=torch.rand(cpu_rays, NUM_FINE))
+        loss.backward()
+
+    threads = _pick_threads(cpu_iter, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        cpu_iter()
+    dt = (time.perf_counter() - t0) / reps
+    out["cpu_baseline"] = {"value": cpu_rays / dt, "unit": "rays/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+                           "sample": f"forward + loss.backward() of the oracle (torch autograd, fp32) on {cpu_rays} rays, {reps} iterations, "
+                                     f"{dt:.2f} s each (no optimizer step)"}
+    out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 def _wall_max(fn, dev, use_dist):
@@ -821,7 +872,7 @@ def main():
     # ... and single-GPU objects
     for name, skip, fn in (("eval", args.no_eval_probe, lambda: eval_probe(dev, weights, views=args.eval_views, cpu_legs=cpu_legs)),
                            ("tiny", args.no_tiny_probe, lambda: tiny_probe(dev, cpu_legs)),
-                           ("train", args.no_train_probe, lambda: train_probe(dev, views[0][1], views[0][0])),
+                           ("train", args.no_train_probe, lambda: train_probe(dev, views[0][1], views[0][0], cpu_legs=cpu_legs)),
                            ("bf16x3", args.no_b3_probe,
                             lambda: b3_probe(dev, weights, views, near, far, u_c, u_f, args.chunk, ref_idx, ref_rgb))):
         if solo and not skip:

@@ -497,11 +497,11 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     pad_to(index, 64);
     // backward (delta propagation): the same layers transposed, in reverse order, hidden columns only
     const size_t off_bwd = index.size();
-    if (!no_view) {    // (training a use_viewdirs = 0 network is not implemented: nm_mlp_forward_train rejects the handle)
+    if (!no_view) {
         pack_gemm(index, T_DIRW, H + dd, H, NT, hid_half, true);
         pack_gemm(index, T_FEATW, H, H, NT, hid, true);
-        for (int i = L - 2; i >= 0; --i) pack_gemm(index, T_XYZ0 + 2 * i, H + (is_skip(d, i) ? dx : 0), H, NT, hid, true);
     }
+    for (int i = L - 2; i >= 0; --i) pack_gemm(index, T_XYZ0 + 2 * i, H + (is_skip(d, i) ? dx : 0), H, NT, hid, true);
     index.resize(index.size() + 1024, -1);
     pad_to(index, 64);
     lay = BlobLayout{off_bias, off_wa, off_wr, off_bwd, skip_mask, 0, 0};

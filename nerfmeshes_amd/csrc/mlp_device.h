@@ -425,8 +425,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, con
 
         if (density_only) {
             sigma = alpha_gemv<H>(in, walpha_src, g) + tail_bias[0];
-            if (FLAT && density_only == 2) flat_head<H>(args, in, wrgb_src, tail_bias, sigma, sample, valid, g);   // use_viewdirs = 0
-            else if (valid && g == 0) args.out[sample] = sigma;
+            if (FLAT && density_only == 2) {   // use_viewdirs = 0
+                flat_head<H>(args, in, wrgb_src, tail_bias, sigma, sample, valid, g);
+                // TAPE: the trunk's last activation has no stage behind it that would write it while consuming it
+                if constexpr (TAPE) store_rows<N::NT>(args.tape_h + (int64_t)(num_layers - 1) * args.n * H, H, sample, valid, in, g);
+            } else if (valid && g == 0) args.out[sample] = sigma;
             gw = args.wstream;
             continue;
         }

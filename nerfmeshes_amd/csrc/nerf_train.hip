@@ -24,19 +24,22 @@ __device__ __forceinline__ void masked_operand(const f32x4 (&acc)[NT], uint64_t 
         for (int r = 0; r < 4; ++r) op[4 * nt + r] = ((mask >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
 }
 
-template <int H, int NW, int KCH>
+// FLAT: a network without view directions (models.py:77-79: the trunk ends in fc_out, 4 rows): no layers_dir / fc_feat stages;
+// the delta at the trunk's output is fc_out^T applied to the four head deltas on the VALU.
+template <int H, int NW, int KCH, bool FLAT = false>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_backward_kernel(const MlpBwdArgs args, const int num_layers) {
     using N = Net<H, 10, 4, KCH>;   // only the hidden-width constants are used here
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_walpha = reinterpret_cast<float*>(lds + 2 * N::LDSBUF);   // [4][H/4]
     float* lds_wrgb = lds_walpha + H;                                    // [3][4][H/8]
     for (int i = threadIdx.x; i < H; i += NW * 64) lds_walpha[i] = args.walpha[i];
-    for (int i = threadIdx.x; i < 3 * H / 2; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    for (int i = threadIdx.x; i < (FLAT ? 3 * H : 3 * H / 2); i += NW * 64) lds_wrgb[i] = args.wrgb[i];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int L = num_layers;
-    constexpr int FIRST = (N::KD < KCH ? N::KD : KCH) * N::STEP;   // first chunk of the layers_dir.0^T stage
+    // first chunk of the first stage: layers_dir.0^T, or (FLAT) layers_xyz[L-2]^T
+    constexpr int FIRST = FLAT ? N::LDSBUF : (N::KD < KCH ? N::KD : KCH) * N::STEP;
 
     const int64_t wg_iters = (args.n + NW * 16 - 1) / (NW * 16);
     int par = 0;
@@ -66,6 +69,30 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_backward_kernel(const MlpBwdAr
             const f32x4 o4 = {drgb[0], drgb[1], drgb[2], dsigma};
             *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = o4;
         }
+        // every delta is written while the NEXT stage consumes it (gemm_stage STORE; measured: the 16-instruction
+        // bursts cost 10 % -- 3.49 ms with them, 3.15 ms with the stores ablated)
+        float* const d_row = valid ? args.d_h + sample * H + 4 * g : nullptr;
+
+        f32x4 acc[N::NT];
+        float in[N::KH];
+        if constexpr (FLAT) {
+            // ---- fc_out^T: delta at the output of layers_xyz[L-2] = sum over the four rows of fc_out (fc_alpha's operand layout)
+            const float* wa = lds_walpha + g * (H / 4);
+#pragma unroll
+            for (int nt = 0; nt < N::NT; ++nt) {
+                f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
+                f32x4 a = {w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    w4 = *reinterpret_cast<const f32x4*>(lds_wrgb + ch * H + g * (H / 4) + 4 * nt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = fmaf(w4[r], drgb[ch], a[r]);
+                }
+                acc[nt] = a;
+            }
+            const uint64_t m = tile_ok ? mrow[(int64_t)(L - 2) * mstride] : 0;
+            masked_operand<N::NT>(acc, m, in);
+        } else {
         const uint64_t mv = tile_ok ? args.mask_v[tile * 64 + lane] : 0;
         float dv[N::KD];
 #pragma unroll
@@ -75,12 +102,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_backward_kernel(const MlpBwdAr
             a = fmaf(lds_wrgb[(2 * 4 + g) * N::KD + s], drgb[2], a);
             dv[s] = ((mv >> s) & 1u) ? a : 0.0f;
         }
-        // every delta is written while the NEXT stage consumes it (gemm_stage STORE; measured: the 16-instruction
-        // bursts cost 10 % -- 3.49 ms with them, 3.15 ms with the stores ablated)
-        float* const d_row = valid ? args.d_h + sample * H + 4 * g : nullptr;
-
-        f32x4 acc[N::NT];
-        float in[N::KH];
         // ---- layers_dir.0^T (hidden columns): delta at relu(fc_feat) -> masked -> delta at fc_feat's output
         {
 #pragma unroll
@@ -106,6 +127,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_backward_kernel(const MlpBwdAr
                 valid ? args.d_feat + sample * H + 4 * g : nullptr);
             gw += N::KH * N::STEP;
             masked_operand<N::NT>(acc, m, in);
+        }
         }
         // ---- layers_xyz[i]^T, i = L-2 .. 0: delta at the input of layers_xyz[i] (x[i-1] post-ReLU, or layer1's output)
 #pragma unroll 1
@@ -206,10 +228,12 @@ __global__ __launch_bounds__(256) void encode_samples64_kernel(const EncodeArgs 
 struct TrainPlan {
     int H, FX, FD;
     void (*forward)(const MlpArgs, const int, const int);
+    void (*forward_flat)(const MlpArgs, const int, const int);     // the taping kernel that also serves use_viewdirs = 0 networks
 };
 template <int H, int FX, int FD>
 static TrainPlan make_train_plan() {
-    return TrainPlan{H, FX, FD, &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true>};
+    return TrainPlan{H, FX, FD, &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true>,
+                     &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true, true>};
 }
 static const TrainPlan g_train_plans[] = {
     make_train_plan<256, 10, 4>(), make_train_plan<128, 10, 4>(), make_train_plan<64, 10, 4>(),
@@ -219,9 +243,12 @@ static const TrainPlan g_train_plans[] = {
 struct BwdPlan {
     int H;
     void (*backward)(const MlpBwdArgs, const int);
+    void (*backward_flat)(const MlpBwdArgs, const int);
 };
 static const BwdPlan g_bwd_plans[] = {
-    {256, &mlp_backward_kernel<256, 8, KC>}, {128, &mlp_backward_kernel<128, 8, KC>}, {64, &mlp_backward_kernel<64, 8, KC>},
+    {256, &mlp_backward_kernel<256, 8, KC>, &mlp_backward_kernel<256, 8, KC, true>},
+    {128, &mlp_backward_kernel<128, 8, KC>, &mlp_backward_kernel<128, 8, KC, true>},
+    {64, &mlp_backward_kernel<64, 8, KC>, &mlp_backward_kernel<64, 8, KC, true>},
 };
 
 static unsigned persistent_grid(int64_t wg_iters, int num_cus) {
@@ -249,13 +276,13 @@ extern "C" {
 int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
                          int64_t rays, int32_t samples, const nm_mlp_tape* tape, float* d_radiance, void* stream) {
     NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
-    NM_REQUIRE(tape->d_h && tape->d_feat && tape->d_v && tape->d_mask_h && tape->d_mask_v, "incomplete tape");
-    NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
-    NM_REQUIRE(m->desc.use_viewdirs == 1, "training a use_viewdirs=0 network is not implemented on the HIP path (inference only)");
     const nm_mlp_desc& d = m->desc;
+    const bool flat = d.use_viewdirs == 0;      // models.py:77-79: the tape is the trunk's (d_h, d_mask_h); d_feat / d_v / d_mask_v are not touched
+    NM_REQUIRE(tape->d_h && tape->d_mask_h && (flat || (tape->d_feat && tape->d_v && tape->d_mask_v)), "incomplete tape");
+    NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
     const TrainPlan* plan = nullptr;
     for (const TrainPlan& p : g_train_plans)
-        if (p.H == d.hidden_size && p.FX == d.num_encoding_fn_xyz && p.FD == d.num_encoding_fn_dir) plan = &p;
+        if (p.H == d.hidden_size && p.FX == d.num_encoding_fn_xyz && p.FD == (flat ? 4 : d.num_encoding_fn_dir)) plan = &p;
     NM_REQUIRE(plan, "no training kernel instantiated for this network shape");
     MlpArgs a = m->base;
     a.mode = MODE_RAYS;
@@ -268,11 +295,12 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     a.tiles = (a.n + 15) / 16;
     const int H = d.hidden_size, L = d.num_layers;
     const int ring = 2 * KC * (H / 16) * 256;
-    const int lds_bytes = ring + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255);
-    if (int rc = set_lds((const void*)plan->forward, lds_bytes)) return rc;
+    const int lds_bytes = ring + (((H * (1 + L) + H / 2 + 4 + H + (flat ? 3 * H : 3 * H / 2)) * 4 + 255) & ~255);
+    const auto kernel = flat ? plan->forward_flat : plan->forward;
+    if (int rc = set_lds((const void*)kernel, lds_bytes)) return rc;
     const int64_t wg_iters = (a.n + 127) / 128;
-    hipLaunchKernelGGL(plan->forward, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(512), lds_bytes,
-                       static_cast<hipStream_t>(stream), a, L, 0);
+    hipLaunchKernelGGL(kernel, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(512), lds_bytes,
+                       static_cast<hipStream_t>(stream), a, L, flat ? 2 : 0);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -280,11 +308,12 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
 int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
                     const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream) {
     NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && deltas && n >= 0, "bad argument");
-    NM_REQUIRE(tape->d_mask_h && tape->d_mask_v, "incomplete tape");
-    NM_REQUIRE(deltas->d_h && deltas->d_feat && deltas->d_v && deltas->d_last, "incomplete delta buffers");
-    if (n == 0) return 0;
-    NM_REQUIRE(m->desc.use_viewdirs == 1, "training a use_viewdirs=0 network is not implemented on the HIP path (inference only)");
     const nm_mlp_desc& d = m->desc;
+    const bool flat = d.use_viewdirs == 0;
+    NM_REQUIRE(tape->d_mask_h && (flat || tape->d_mask_v), "incomplete tape");
+    NM_REQUIRE(deltas->d_h && deltas->d_last && (flat || (deltas->d_feat && deltas->d_v)), "incomplete delta buffers");
+    NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
+    if (n == 0) return 0;
     const BwdPlan* plan = nullptr;
     for (const BwdPlan& p : g_bwd_plans)
         if (p.H == d.hidden_size) plan = &p;
@@ -295,10 +324,11 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
     a.n = n; a.tiles = (n + 15) / 16;
     a.d_h = deltas->d_h; a.d_feat = deltas->d_feat; a.d_v = deltas->d_v; a.d_last = deltas->d_last;
     const int H = d.hidden_size;
-    const int lds_bytes = 2 * KC * (H / 16) * 256 + (((H + 3 * H / 2) * 4 + 255) & ~255);
-    if (int rc = set_lds((const void*)plan->backward, lds_bytes)) return rc;
+    const int lds_bytes = 2 * KC * (H / 16) * 256 + (((H + (flat ? 3 * H : 3 * H / 2)) * 4 + 255) & ~255);
+    const auto kernel = flat ? plan->backward_flat : plan->backward;
+    if (int rc = set_lds((const void*)kernel, lds_bytes)) return rc;
     const int64_t wg_iters = (n + 127) / 128;
-    hipLaunchKernelGGL(plan->backward, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(512), lds_bytes,
+    hipLaunchKernelGGL(kernel, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(512), lds_bytes,
                        static_cast<hipStream_t>(stream), a, (int)d.num_layers);
     NM_HIP_CHECK(hipGetLastError());
     return 0;

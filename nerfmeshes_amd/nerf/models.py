@@ -69,9 +69,6 @@ class FlexibleNeRFModel(torch.nn.Module):
     def forward(self, ray_points, ray_directions=None):
         dirs = ray_directions if ray_directions is not None else ray_points
         if self.needs_grad():
-            if not self.use_viewdirs:
-                raise NotImplementedError("training a use_viewdirs=False network is not implemented on the HIP path; "
-                                          "inference (torch.no_grad() / requires_grad_(False)) is")
             # differentiable path: every point is a one-sample ray (origin = point, t = 0: o + d * 0 == o exactly)
             pts = ray_points.reshape(-1, 3)
             t = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)

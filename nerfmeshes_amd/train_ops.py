@@ -22,10 +22,12 @@ from ._lib import BundleGrads, MlpDeltas, MlpTape, MlpWeights, check
 from .hip_ops import _dev32, _ptr, _stream
 
 
-def param_names(num_layers):
+def param_names(num_layers, use_viewdirs=True):
     names = ["layer1.weight", "layer1.bias"]
     for i in range(num_layers - 1):
         names += [f"layers_xyz.{i}.weight", f"layers_xyz.{i}.bias"]
+    if not use_viewdirs:                       # models.py:52-55: the trunk ends in fc_out (4, H)
+        return names + ["fc_out.weight", "fc_out.bias"]
     return names + ["fc_feat.weight", "fc_feat.bias", "fc_alpha.weight", "fc_alpha.bias", "layers_dir.0.weight",
                     "layers_dir.0.bias", "fc_rgb.weight", "fc_rgb.bias"]
 
@@ -69,19 +71,26 @@ def forward_train(mlp, origins, dirs, t):
     n, H, L = rays * samples, int(mlp.desc["hidden_size"]), int(mlp.desc["num_layers"])
     tiles = (n + 15) // 16
     f32 = dict(dtype=torch.float32, device=mlp.device)
-    tape_bytes = 4 * n * (L * H + H + H // 2)
+    flat = not mlp.desc.get("use_viewdirs", True)      # trunk-only tape: no fc_feat / layers_dir activations
+    tape_bytes = 4 * n * (L * H + (0 if flat else H + H // 2))
     if 2.1 * tape_bytes > torch.cuda.get_device_properties(mlp.device).total_memory:     # tape + deltas of the backward
         raise _lib.HipLibraryError(
             f"the training tape of {rays} rays x {samples} samples needs {tape_bytes / 2**30:.0f} GiB (+ as much for the "
             "deltas): use a smaller ray chunk, or torch.no_grad() if this is inference")
-    tape = dict(h=torch.empty(L, n, H, **f32), feat=torch.empty(n, H, **f32), v=torch.empty(n, H // 2, **f32),
+    tape = dict(h=torch.empty(L, n, H, **f32), feat=None if flat else torch.empty(n, H, **f32),
+                v=None if flat else torch.empty(n, H // 2, **f32),
                 mask_h=torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
-                mask_v=torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
+                mask_v=None if flat else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
     out = torch.empty(rays, samples, 4, **f32)
-    ct = MlpTape(_ptr(tape["h"]), _ptr(tape["feat"]), _ptr(tape["v"]), _ptr(tape["mask_h"]), _ptr(tape["mask_v"]))
+    ct = _tape_struct(tape)
     check(lib.nm_mlp_forward_train(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays, samples,
                                    C.byref(ct), _ptr(out), _stream()), "nm_mlp_forward_train")
     return out, tape
+
+
+def _tape_struct(tape):
+    opt = lambda x: None if x is None else _ptr(x)   # noqa: E731
+    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(tape["v"]), _ptr(tape["mask_h"]), opt(tape["mask_v"]))
 
 
 def encode_samples(mlp, origins, dirs, t):
@@ -164,10 +173,11 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     L, H, skip_step = int(d["num_layers"]), int(d["hidden_size"]), int(d["skip_step"])
     n = radiance.numel() // 4
     f32 = dict(dtype=torch.float32, device=mlp.device)
-    dh, dfeat = torch.empty(L, n, H, **f32), torch.empty(n, H, **f32)
-    dv, dlast = torch.empty(n, H // 2, **f32), torch.empty(n, 4, **f32)
-    ct = MlpTape(_ptr(tape["h"]), _ptr(tape["feat"]), _ptr(tape["v"]), _ptr(tape["mask_h"]), _ptr(tape["mask_v"]))
-    cd = MlpDeltas(_ptr(dh), _ptr(dfeat), _ptr(dv), _ptr(dlast))
+    flat = not d.get("use_viewdirs", True)
+    dh, dlast = torch.empty(L, n, H, **f32), torch.empty(n, 4, **f32)
+    dfeat, dv = (None, None) if flat else (torch.empty(n, H, **f32), torch.empty(n, H // 2, **f32))
+    ct = _tape_struct(tape)
+    cd = MlpDeltas(_ptr(dh), None if flat else _ptr(dfeat), None if flat else _ptr(dv), _ptr(dlast))
     check(lib.nm_mlp_backward(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), _stream()),
           "nm_mlp_backward")
     h, feat, v = tape["h"], tape["feat"], tape["v"]
@@ -194,14 +204,15 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
             else:
                 gw, gb = _weight_grad(mlp, delta, h[i], H)
             g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, gb
-        g["fc_feat.weight"], g["fc_feat.bias"] = _weight_grad(mlp, dfeat, h[L - 1], H)
-        gw = torch.empty(H // 2, H + dd, **f32)
-        _, g["layers_dir.0.bias"] = _weight_grad(mlp, dv, feat, H, out=gw, col0=0)
-        if (H // 2, 64) in _DW_SHAPES:
-            _weight_grad(mlp, dv, enc_d, dd, out=gw, col0=H, bias=False)
-        else:
-            gw[:, H:] = _tn(dv, enc_d[:, :dd].contiguous())
-        g["layers_dir.0.weight"] = gw
+        if not flat:
+            g["fc_feat.weight"], g["fc_feat.bias"] = _weight_grad(mlp, dfeat, h[L - 1], H)
+            gw = torch.empty(H // 2, H + dd, **f32)
+            _, g["layers_dir.0.bias"] = _weight_grad(mlp, dv, feat, H, out=gw, col0=0)
+            if (H // 2, 64) in _DW_SHAPES:
+                _weight_grad(mlp, dv, enc_d, dd, out=gw, col0=H, bias=False)
+            else:
+                gw[:, H:] = _tn(dv, enc_d[:, :dd].contiguous())
+            g["layers_dir.0.weight"] = gw
     else:
         enc_x, enc_d = encode_samples(mlp, origins, dirs, t)
         g.update({"layer1.weight": _tn(dh[0], enc_x), "layer1.bias": dh[0].sum(0)})
@@ -211,11 +222,18 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
             if is_skip(i):
                 gw = torch.cat((gw, _tn(delta, enc_x)), dim=1)
             g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, delta.sum(0)
-        g["fc_feat.weight"], g["fc_feat.bias"] = _tn(dfeat, h[L - 1]), dfeat.sum(0)
-        g["layers_dir.0.weight"] = torch.cat((_tn(dv, feat), _tn(dv, enc_d)), dim=1)   # cat(feat, view): models.py:72
-        g["layers_dir.0.bias"] = dv.sum(0)
+        if not flat:
+            g["fc_feat.weight"], g["fc_feat.bias"] = _tn(dfeat, h[L - 1]), dfeat.sum(0)
+            g["layers_dir.0.weight"] = torch.cat((_tn(dv, feat), _tn(dv, enc_d)), dim=1)   # cat(feat, view): models.py:72
+            g["layers_dir.0.bias"] = dv.sum(0)
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
+    if flat:
+        # fc_out (4, H) over the trunk output: rows 0..2 take the pre-sigmoid colour deltas, row 3 the density delta --
+        # exactly dlast^T @ h[L-1] and dlast's column sums (models.py:77-79)
+        gh, last_sums = _head_grad(mlp, dlast, h[L - 1], bias=True) if H in _HEAD_WIDTHS else (_tn(dlast, h[L - 1]), dlast.sum(0))
+        g["fc_out.weight"], g["fc_out.bias"] = gh, last_sums
+        return g
     if H in _HEAD_WIDTHS and H // 2 in _HEAD_WIDTHS:
         (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, h[L - 1], bias=True), _head_grad(mlp, dlast, v)
     else:
@@ -245,7 +263,7 @@ def mlp_rays(module, origins, dirs, t):
     """Differentiable FlexibleNeRFModel.forward over (R,S) ray samples; `module` is the nn.Module mirror
     (nerfmeshes_amd.nerf.models.FlexibleNeRFModel) whose parameters receive the gradients."""
     mlp = module.hip()          # re-packed on the device if an optimizer step changed the parameters
-    names = param_names(int(mlp.desc["num_layers"]))
+    names = param_names(int(mlp.desc["num_layers"]), bool(mlp.desc.get("use_viewdirs", True)))
     params = dict(module.named_parameters())
     return _MLPRays.apply(mlp, names, origins, dirs, t, *[params[k] for k in names])
 

@@ -178,9 +178,10 @@ def test_mlp_without_view_directions_vs_reference_golden(ops):
         _close(got[:, 3], ref[:, 3], 2e-5 * (float(np.abs(ref[:, 3]).max()) + 1.0), what=f"sigma ({tag})")
 
 
-def test_model_without_view_directions_follows_parameter_updates_and_refuses_training(ops):
+def test_model_without_view_directions_follows_parameter_updates_and_trains(ops):
     """The nn.Module mirror: forward under no_grad runs the HIP path, an in-place parameter edit is picked up by the
-    on-device re-pack (nm_mlp_refresh with fc_out's rows), the differentiable path raises instead of falling back."""
+    on-device re-pack (nm_mlp_refresh with fc_out's rows), and with autograd on the same call is differentiable (round 4:
+    the taping kernel's mode 2 + the FLAT delta kernel; gradients against fp64 autograd in tests/test_gpu_train.py)."""
     from nerfmeshes_amd.nerf import FlexibleNeRFModel
     torch.manual_seed(4)
     kw = dict(num_layers=4, hidden_size=128, skip_step=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4, use_viewdirs=False)
@@ -198,8 +199,11 @@ def test_model_without_view_directions_follows_parameter_updates_and_refuses_tra
         w = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         _close(b, O.mlp_forward(w, spec, pts, pts), 3e-5, what="fc_out network after the update")
         assert not torch.equal(a, b)
-    with pytest.raises(NotImplementedError, match="use_viewdirs=False"):
-        net(pts.cuda())
+    out = net(pts.cuda())
+    assert out.requires_grad and torch.equal(out.detach(), b), "the taping kernel must not change the output"
+    out.square().sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    assert float(net.fc_out.weight.grad.abs().max()) > 0 and float(net.layer1.weight.grad.abs().max()) > 0
 
 
 def test_mlp_points_golden(ops):

@@ -61,6 +61,69 @@ def _oracle_grads(w, spec, o, d, t, grad_out, dtype):
     return out.detach(), {k: v.grad for k, v in wd.items()}
 
 
+FLAT_SHAPES = [
+    dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4, use_viewdirs=False),
+    dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, use_viewdirs=False),
+    dict(num_layers=5, hidden_size=128, skip_step=2, num_encoding_fn_xyz=10, num_encoding_fn_dir=2, use_viewdirs=False),
+]
+
+
+@pytest.mark.parametrize("kw", FLAT_SHAPES, ids=["4x64", "8x256", "5x128"])
+@pytest.mark.parametrize("rays,samples", [(37, 9), (128, 16)])
+def test_training_a_network_without_view_directions_vs_autograd(ops, T, kw, rays, samples):
+    """FlexibleNeRFModel(use_viewdirs=False) (models.py:52-55, 77-79) through the training entry points: the taping kernel's
+    mode 2 reproduces the inference output bit for bit and tapes the trunk (the last activation by an explicit store: no
+    stage follows that would write it), the FLAT delta kernel starts from fc_out^T applied to the four head deltas; all
+    L + 1 weight / bias gradient pairs against fp64 autograd over the oracle, at the view networks' tolerance."""
+    spec = O.MLPSpec(**kw)
+    w = _weights(kw)
+    mlp = ops.HipMLP(w, kw, "cuda")
+    o, d, t = _rays(rays, samples, rays)
+    grad_out = torch.randn(rays, samples, 4, generator=torch.Generator().manual_seed(1))
+    rad, tape = T.forward_train(mlp, o.cuda(), d.cuda(), t.cuda())
+    assert torch.equal(rad, mlp.eval_rays(o.cuda(), d.cuda(), t.cuda())), "the taping kernel must not change the output"
+    assert tape["feat"] is None and tape["v"] is None and tape["mask_v"] is None, "a trunk-only tape"
+    ref32, g32 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float32)
+    ref64, g64 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float64)
+    assert _rel(rad.reshape(-1, 4), ref64) < max(2e-5, 4 * _rel(ref32, ref64))
+    assert float(tape["h"][1:].min()) >= 0.0
+    # the last trunk activation is the operand of fc_out's gradient: check it against the oracle's trunk
+    pts = O.ray_points(t, d, o).reshape(-1, 3)
+    x = O.positional_encoding(pts, kw["num_encoding_fn_xyz"])
+    h = torch.nn.functional.linear(x, w["layer1.weight"], w["layer1.bias"])
+    for i in range(kw["num_layers"] - 1):
+        if spec.is_skip(i):
+            h = torch.cat((h, x), -1)
+        h = torch.relu(torch.nn.functional.linear(h, w[f"layers_xyz.{i}.weight"], w[f"layers_xyz.{i}.bias"]))
+    assert _rel(tape["h"][-1], h) < 2e-5
+    got = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
+    assert set(got) == set(g64) == set(T.param_names(kw["num_layers"], use_viewdirs=False))
+    worst = {k: (_rel(got[k], ref), _rel(g32[k], ref)) for k, ref in g64.items()}
+    bad = {k: v for k, v in worst.items() if v[0] > max(2e-4, 20 * v[1])}
+    assert not bad, f"gradient mismatch (ours, torch-fp32) relative to fp64 autograd: {bad}"
+
+
+def test_adam_trains_a_network_without_view_directions(ops):
+    """End to end through the module surface: NeRF-style training iterations of a use_viewdirs=False FlexibleNeRFModel (the
+    differentiable forward used to raise NotImplementedError): the loss falls, and the eval path follows the new weights."""
+    from nerfmeshes_amd.nerf import FlexibleNeRFModel
+    torch.manual_seed(0)
+    net = FlexibleNeRFModel(num_layers=4, hidden_size=128, skip_step=4, num_encoding_fn_xyz=6, use_viewdirs=False).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3)
+    pts = (torch.rand(4096, 3, device="cuda") - 0.5) * 2.0
+    target = torch.cat((torch.sigmoid(3.0 * pts), pts.norm(dim=-1, keepdim=True)), -1)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(net(pts), target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.5 * losses[0], losses
+    with torch.no_grad():
+        assert abs(float(torch.nn.functional.mse_loss(net(pts), target)) - losses[-1]) < 0.5 * losses[-1]
+
+
 @pytest.mark.parametrize("kw", SHAPES, ids=["4x64", "8x256", "3x128"])
 def test_refresh_equals_create(ops, T, kw):
     """nm_mlp_refresh (device gather from live tensors) == nm_mlp_create from the same values, bit for bit."""
