@@ -299,7 +299,7 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
             @staticmethod
             def get_model():
                 class _N:
-                    hip = staticmethod(lambda: fine)
+                    hip = staticmethod(lambda precision=None: fine)
                 return _N
 
         def run(gather):

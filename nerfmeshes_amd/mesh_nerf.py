@@ -44,7 +44,7 @@ def _axes(args, nums, device):
 def _grid_query(model, args, device, nums, density_only, shard=None):
     """shard = (rank, world): evaluate only this rank's slab of axis-0 planes (see nerfmeshes_amd.dist)."""
     nums = _nums(nums)
-    net = model.get_model().hip()
+    net = model.get_model().hip("f32")
     ax = _axes(args, nums, device)
     first, count = 0, nums[0] * nums[1] * nums[2]
     if shard is not None:
@@ -71,7 +71,7 @@ def extract_density(model, args, device, nums):
         out, nums = _grid_query(model, args, device, nums, density_only=True)
         return out.view(*nums)
     nums = _nums(nums)
-    net = model.get_model().hip()
+    net = model.get_model().hip("f32")
     ax = _axes(args, nums, device)
     plane = nums[1] * nums[2]
     return nd.density_grid_sharded(
@@ -124,7 +124,7 @@ def extract_geometry(model, device, args):
     rank, world = nd.world()
     if world > 1 and getattr(args, "gather", "triangles") == "triangles":
         nums = _nums(args.res)
-        net = model.get_model().hip()
+        net = model.get_model().hip("f32")
         ax = _axes(args, nums, device)
         plane = nums[1] * nums[2]
         stats = {}
@@ -194,6 +194,8 @@ def export_marching_cubes(model, args, cfg, device):
                 torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(), density.cpu().numpy()), cache_path)
                 print(f"Cached mesh geometry saved to {cache_path}")
 
+    if getattr(args, "precision", "f32") != "f32":     # the geometry above is fp32 by contract; only the colours may use the mode
+        model.set_precision(args.precision)
     # Appearance: one query per vertex.  Vertices are independent, so under torch.distributed every rank queries a
     # contiguous range of them and one ragged all-gather assembles the (V,3) colours; rank 0 writes the file.
     rank, world = nd.world()
@@ -216,6 +218,8 @@ def export_marching_cubes(model, args, cfg, device):
             diffuse.append(model.query((o, d, ray_bounds)).rgb_map)
     diffuse = torch.cat(diffuse, dim=0) if diffuse else torch.empty(0, 3, dtype=torch.float32, device=device)
     diffuse = nd.all_gather_rows(diffuse.contiguous(), counts).cpu().numpy()
+    if getattr(args, "precision", "f32") != "f32":
+        model.set_precision("f32")
     if rank == 0:
         export_obj(vertices.cpu(), triangles.cpu(), diffuse, normals.cpu(), os.path.join(args.save_dir, args.mesh_name))
     return vertices, triangles, normals, diffuse
@@ -238,6 +242,9 @@ def build_parser():
     p.add_argument("--use-cached-mesh", action="store_true", default=False)
     p.add_argument("--override-cache-mesh", action="store_true", default=False)
     p.add_argument("--cache-name", type=str, default="mesh_cache.pt")
+    p.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
+                   help="(addition) arithmetic of the per-vertex appearance re-query; the density grid -- hence the mesh topology "
+                        "-- is always computed in fp32")
     p.add_argument("--gather", choices=("triangles", "grid"), default="triangles",
                    help="(addition, multi-GPU) what travels between the ranks: the emitted triangles of per-slab marching "
                         "cubes (default) or the density grid")

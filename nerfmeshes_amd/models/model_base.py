@@ -48,6 +48,19 @@ class BaseModel(_Base):
     def get_model(self):
         raise NotImplementedError
 
+    def set_precision(self, precision):
+        """Arithmetic of the inference kernels of every network of this model: "f32" (default; the reference's fp32) or
+        the opt-in "bf16x3" (hip_ops.HipMLP: fp32 products emulated on the bf16 matrix pipe, fp32-class error, ~1.8x the
+        throughput; 256-wide networks; a network without such a kernel says so when it is first used).  Training and the
+        mesh grid of `mesh_nerf` always run in fp32."""
+        from ..hip_ops import PRECISIONS
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+        for m in self.modules():
+            if hasattr(m, "hip") and hasattr(m, "precision"):
+                m.precision = precision
+        return self
+
     def setup(self, stage):
         """model_base.py:42-59: load both splits, then size the Trainer from the config -- `train_iters` optimizer steps
         (min = max), the matching epoch count, validation every `validate_every` steps expressed in epochs."""

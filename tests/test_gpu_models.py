@@ -221,12 +221,14 @@ def test_buff_sampled_tree_reference_tie_order(pkg):
     assert np.array_equal(m.tree.voxels.cpu().numpy(), g["voxels_after"])
 
 
-def test_buff_model_forward_golden(pkg):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_buff_model_forward_golden(pkg, precision):
     g = load_golden("buff_fern")
     hp = golden_hparams(g)
     m = pkg["models"].BuFFModel(hp)
     _load(m, "model.", gen_weights(g["seed"], g["gain"], g["bias"], **mlp_kwargs(hp, "coarse")))
-    m = m.eval().to("cuda")
+    m = m.eval().to("cuda").set_precision(precision)     # the opt-in mode is held to the fixture's fp32 tolerance
+    assert m.model.hip().precision == precision
     assert np.array_equal(m.tree.voxels.cpu().numpy(), g["voxels"])
     with torch.no_grad():
         b = m.query((torch.from_numpy(g["origins"]).cuda(), torch.from_numpy(g["directions"]).cuda(),

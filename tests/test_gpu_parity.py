@@ -323,13 +323,13 @@ def test_sample_pdf_vs_oracle(ops, coarse, fine):
         assert np.all(on_edge[tight & (wd[:, -1] / wd.sum(-1) < 1e-5)]), f"{name}: u == 1 sample not on bins[-1] / bins[-2]"
 
 
-def _render_case(ops, case):
+def _render_case(ops, case, precision="f32"):
     g = load_golden(case)
     hp = golden_hparams(g)
     sc, sf, rs = specs_from_hparams(hp)
     wc, wf = golden_weights(g, hp)
-    coarse = ops.HipMLP(wc, _desc(sc), "cuda")
-    fine = ops.HipMLP(wf, _desc(sf), "cuda") if wf is not None else None
+    coarse = ops.HipMLP(wc, _desc(sc), "cuda", precision=precision)
+    fine = ops.HipMLP(wf, _desc(sf), "cuda", precision=precision) if wf is not None else None
     near, far = g["bounds"]
     cb, fb = ops.render_rays(coarse, fine, torch.from_numpy(g["origins"]).cuda(), torch.from_numpy(g["directions"]).cuda(),
                              torch.tensor([near]), torch.tensor([far]), torch.linspace(0, 1, rs.num_coarse),
@@ -338,10 +338,17 @@ def _render_case(ops, case):
     return g, hp, (sc, sf, rs), (wc, wf), (coarse, fine), cb, fb
 
 
+# the opt-in bf16x3 precision is held to the SAME tolerances on every fixture whose networks it is instantiated for (256-wide)
+B3_CASES = ("render_lego_scene", "render_lego_default_init", "render_lego_perray_white_lindisp")
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("case", [c for c in RENDER_CASES if c != "render_lego_rough"])
-def test_render_golden(ops, case):
+def test_render_golden(ops, case, precision):
     """End to end through nm_render_rays against the unmodified reference's outputs."""
-    g, hp, _, _, _, cb, fb = _render_case(ops, case)
+    if precision == "bf16x3" and case not in B3_CASES:
+        pytest.skip("bf16x3 kernels exist for the 256-wide networks")
+    g, hp, _, _, _, cb, fb = _render_case(ops, case, precision)
     good = well_conditioned_rays(g)
     assert good.mean() > 0.9
     for prefix, b in (("coarse.", cb), ("fine.", fb)):
@@ -448,13 +455,14 @@ def test_psnr_parity_view8k_narrow_networks(ops, name, scene, coarse_n, fine_n):
         assert why["unexplained"] == 0, why
 
 
-def test_render_rough_scene_at_the_reference_noise_floor(ops):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_render_rough_scene_at_the_reference_noise_floor(ops, precision):
     """The rough scene (thresholded high-frequency noise density): the reference differs from itself by
     up to ~3e-2 on individual rays when its fp32 sums are re-ordered (test_reference_self_noise), because
     resampled depths in nearly empty bins are ill-conditioned.  Required here: (a) coarse pass tight,
     (b) the fine pass tight on >= 90 % of the rays and inside the noise floor on the rest,
     (c) given the reference's OWN fine depths, MLP + compositing agree to round-off on every ray."""
-    g, hp, (sc, sf, rs), (wc, wf), (coarse, fine), cb, fb = _render_case(ops, "render_lego_rough")
+    g, hp, (sc, sf, rs), (wc, wf), (coarse, fine), cb, fb = _render_case(ops, "render_lego_rough", precision)
     _close(cb["rgb_map"], g["coarse.rgb_map"], 2e-5, what="coarse rgb")
     _close(cb["weights"], g["coarse.weights"], 2e-5, what="coarse weights")
     err = (fb["rgb_map"].cpu() - torch.from_numpy(g["fine.rgb_map"])).abs().max(-1).values
@@ -621,12 +629,13 @@ def test_positional_encoding_module(ops, nf, include):
 
 
 @pytest.mark.parametrize("rays", [1, 17, 2049])
-@pytest.mark.parametrize("nc,nf,kw", [
-    (8, 8, dict(hidden_size=128, num_layers=4, num_encoding_fn_xyz=6)),     # tiny.yaml's literal sizes (4x128, 8+8)
-    (16, 0, dict(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6)),      # coarse only
-    (64, 128, dict()),                                                        # lego
+@pytest.mark.parametrize("nc,nf,kw,precision", [
+    (8, 8, dict(hidden_size=128, num_layers=4, num_encoding_fn_xyz=6), "f32"),     # tiny.yaml's literal sizes (4x128, 8+8)
+    (16, 0, dict(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6), "f32"),      # coarse only
+    (64, 128, dict(), "f32"),                                                        # lego
+    (64, 128, dict(), "bf16x3"),                                                     # ... in the opt-in precision, same bars
 ])
-def test_render_sweep_vs_oracle(ops, rays, nc, nf, kw):
+def test_render_sweep_vs_oracle(ops, rays, nc, nf, kw, precision):
     """Ragged ray counts (1 ray, not a multiple of the 128-sample workgroup tile, one more than the reference's
     2048-ray chunk) x sample counts, per-ray origins and bounds given as (R,) tensors."""
     spec = O.MLPSpec(**kw)
@@ -634,7 +643,7 @@ def test_render_sweep_vs_oracle(ops, rays, nc, nf, kw):
                 num_encoding_fn_xyz=spec.num_encoding_fn_xyz, num_encoding_fn_dir=spec.num_encoding_fn_dir)
     w = (S.make_scene_weights(**full) if not kw else
          S.make_mlp_weights(23, density_gain=60.0, density_bias=0.5, **full))
-    mlp = ops.HipMLP(w, full, "cuda")
+    mlp = ops.HipMLP(w, full, "cuda", precision=precision)
     g = torch.Generator().manual_seed(rays * 7 + nc)
     o = torch.tensor([[0.3, -0.2, 4.0]]) + 0.05 * torch.randn(rays, 3, generator=g)
     d = torch.nn.functional.normalize(torch.tensor([[0.0, 0.05, -1.0]]) + 0.2 * torch.randn(rays, 3, generator=g), dim=-1)
