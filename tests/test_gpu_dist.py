@@ -33,7 +33,14 @@ def _env():
 def _torchrun(nproc, script, *args, timeout=600, env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
-    return subprocess.run(cmd, cwd=ROOT, env=dict(_env(), **(env or {})), capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(_env(), **(env or {})), capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:      # the launcher's summary hides the workers' own tracebacks: put the first one in front
+        lines = r.stderr.splitlines()
+        first = next((i for i, ln in enumerate(lines) if ln.startswith("Traceback")), None)
+        if first is not None:
+            r.stderr = "\n".join(lines[first:first + 40]) + "\n...\n" + r.stderr
+            r.stdout = ""
+    return r
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -58,7 +65,7 @@ def test_ranks_sharing_one_gpu_over_gloo(world):
         pytest.fail("GPU tests need a MI355X")
     r = _torchrun(world, os.path.join("tests", "tools", "dist_worker.py"), timeout=1500,
                   env={"NERFMESHES_RANKS_PER_GPU": str(world), "NM_EXPECT_BACKEND": "gloo"})
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[:6000]
     assert f"DIST_OK world={world} backend=gloo device=cuda:0" in r.stdout, r.stdout[-2000:]
 
 

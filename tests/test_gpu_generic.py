@@ -157,8 +157,10 @@ def test_limits_of_the_family_are_errors_with_a_reason(ops):
     for kw, why in ((dict(hidden_size=528, num_layers=2), "512"), (dict(num_encoding_fn_xyz=16), "k-steps"),
                     (dict(num_encoding_fn_xyz=0, include_input_xyz=False), "empty")):
         spec, desc = _desc(kw)
+        w = {f"{name}.{part}": np.zeros((n_out, n_in) if part == "weight" else (n_out,), dtype=np.float32)
+             for name, n_out, n_in in S.mlp_layer_shapes(**desc) for part in ("weight", "bias")}
         with pytest.raises(_lib.HipLibraryError, match=why):
-            ops.HipMLP(S.make_mlp_weights(1, **desc), desc, "cuda")
+            ops.HipMLP(w, desc, "cuda")
     spec, desc = _desc(dict(num_encoding_fn_xyz=16, include_input_xyz=False, hidden_size=64, num_layers=2))    # 24 k-steps exactly
     w = S.make_mlp_weights(2, **desc)
     pts = torch.rand(64, 3)

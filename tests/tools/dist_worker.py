@@ -90,9 +90,11 @@ def model_level_checks(rank, world, dev):
     got = torch.cat([p.grad.reshape(-1) for p in params])
     every = nd.all_gather_rows(own[None].contiguous(), [1] * world)
     mean = every.sum(0) / world
-    # two addends commute exactly; with more ranks the reduction order is the backend's
-    assert torch.equal(got, mean) if world <= 2 else torch.allclose(got, mean, rtol=1e-5, atol=1e-9), \
-        "all-reduced gradients are not the mean of the ranks' gradients"
+    # two addends commute exactly; with more ranks the reduction order is the backend's: the bound is relative to the largest
+    # ADDEND of an entry (gradients of different ranks cancel, so the mean can be far smaller than what was summed)
+    bound = 1e-6 * every.abs().max(0).values + 1e-12
+    assert torch.equal(got, mean) if world <= 2 else bool(((got - mean).abs() <= bound).all()), \
+        f"all-reduced gradients are not the mean of the ranks' gradients: worst {float(((got - mean).abs() / bound).max()):.2f} x the bound"
     assert world == 1 or not torch.equal(every[0], every[-1]), "ranks were meant to train on different rays"
     opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in params])
