@@ -97,6 +97,23 @@ def test_off_menu_shapes_vs_oracle(ops, kw):
     assert mlp.flops_per_sample() == 2 * sum(a * b for _, a, b in S.mlp_layer_shapes(**desc)), "useful FLOP only: padding is not counted"
 
 
+def test_off_menu_shapes_vs_the_unmodified_reference(ops):
+    """The same family against outputs of the UNMODIFIED reference's FlexibleNeRFModel for seven off-menu shapes
+    (tests/golden/mlp_generic_points.npz, make_generic_golden.py; the oracle reproduces that file bit for bit)."""
+    import json
+    from tests.helpers import load_golden
+    g = load_golden("mlp_generic_points")
+    pts, dirs = torch.from_numpy(g["points"]).cuda(), torch.from_numpy(g["directions"]).cuda()
+    for tag in [k[len("kwargs_"):] for k in g.files if k.startswith("kwargs_")]:
+        kw = json.loads(str(g["kwargs_" + tag]))
+        w = S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw)
+        mlp = ops.HipMLP(w, kw, "cuda")
+        assert mlp.kernel_variant()[0] >= 1000, tag
+        got, ref = mlp.sample_points(pts, dirs).cpu(), torch.from_numpy(g["radiance_" + tag])
+        _close(got[:, :3], ref[:, :3], 2e-5, f"{tag}: rgb vs the reference")
+        _close(got[:, 3], ref[:, 3], 2e-5 * (float(ref[:, 3].abs().max()) + 1.0), f"{tag}: sigma vs the reference")
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(hidden_size=128), dict(hidden_size=64, num_layers=4, num_encoding_fn_xyz=6),
                                 dict(hidden_size=128, num_layers=6, skip_step=2, num_encoding_fn_xyz=6), dict(use_viewdirs=False)])
 def test_generic_family_reproduces_the_tuned_kernels_bit_for_bit(ops, kw):

@@ -109,6 +109,22 @@ def test_mlp_without_view_directions_matches_reference():
         assert np.array_equal(got.numpy(), ref), (tag, float(np.abs(got.numpy() - ref).max()))
 
 
+def test_off_menu_network_shapes_match_reference():
+    """Round 4: seven FlexibleNeRFModel shapes no shipped config uses (wide / odd hidden sizes, 1 .. 15 encoding functions,
+    include_input_* off, linear frequency sampling, with and without view directions) through the UNMODIFIED reference
+    (tests/golden/make_generic_golden.py): the oracle reproduces each bit for bit -- it is what the generic-shape kernel
+    family is held to on the GPU (tests/test_gpu_generic.py)."""
+    import json
+    g = load_golden("mlp_generic_points")
+    tags = [k[len("kwargs_"):] for k in g.files if k.startswith("kwargs_")]
+    assert len(tags) == 7
+    for tag in tags:
+        kw = json.loads(str(g["kwargs_" + tag]))
+        w = S.make_mlp_weights(int(g["seed"]), density_gain=float(g["gain"]), density_bias=float(g["bias"]), **kw)
+        got = O.mlp_forward(w, O.MLPSpec(**kw), torch.from_numpy(g["points"]), torch.from_numpy(g["directions"]))
+        assert np.array_equal(got.numpy(), g["radiance_" + tag]), (tag, float(np.abs(got.numpy() - g["radiance_" + tag]).max()))
+
+
 def test_grid_radiance_and_iso_match_reference():
     g = load_golden("grid_8x256_res20")
     w = gen_weights(g["seed"], g["gain"], g["bias"])
