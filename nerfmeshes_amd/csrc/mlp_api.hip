@@ -107,7 +107,8 @@ static int encoding_stage_g(std::vector<StepCols>& out, int F, bool include_inpu
 
 // A-operand stream of one generic stage: per k-step ceil(ntiles / 4) blocks of 4 tiles (1 KiB each; tiles beyond ntiles and rows
 // beyond `rows` are zeros)
-static void pack_gemm_g(std::vector<int32_t>& out, int tensor, int ld, int rows, int ntiles, const std::vector<StepCols>& steps) {
+static void pack_gemm_g(std::vector<int32_t>& out, int tensor, int ld, int rows, int ntiles, const std::vector<StepCols>& steps,
+                        bool transposed = false) {
     const int nb = (ntiles + 3) / 4;
     for (const StepCols& c : steps)
         for (int b = 0; b < nb; ++b)
@@ -115,7 +116,8 @@ static void pack_gemm_g(std::vector<int32_t>& out, int tensor, int ld, int rows,
                 for (int q = 0; q < 4; ++q) {
                     const int n = 16 * (4 * b + q) + (l & 15);
                     const int k = c[l >> 4];
-                    out.push_back((4 * b + q < ntiles && n < rows && k >= 0) ? (int32_t)((tensor << 24) | (int32_t)((int64_t)n * ld + k)) : -1);
+                    const int64_t off = transposed ? (int64_t)k * ld + n : (int64_t)n * ld + k;    // transposed: W^T (the delta stream)
+                    out.push_back((4 * b + q < ntiles && n < rows && k >= 0) ? (int32_t)((tensor << 24) | (int32_t)off) : -1);
                 }
 }
 
@@ -134,8 +136,8 @@ static void pack_head_row_g(std::vector<int32_t>& out, int tensor, int row_offse
 
 struct BlobLayout { size_t off_bias, off_wa, off_wr, off_bwd; uint32_t skip_mask; int chx, chd; };
 
-// The whole blob of a generic plan as an index map (layout: mlp_device_g.h's kernel): forward stream | biases | fc_alpha |
-// fc_rgb (or fc_out's colour rows).  No backward stream: the training kernels are instantiated for the tuned shapes only.
+// The whole blob of a generic plan as an index map (layout: mlp_device_g.h's kernels): forward stream | biases | fc_alpha |
+// fc_rgb (or fc_out's colour rows) | backward stream (the transposed layers in reverse order, hidden columns only).
 static BlobLayout build_index_generic(std::vector<int32_t>& index, const nm_mlp_desc& d, const MlpPlan& plan) {
     const int H = d.hidden_size, L = d.num_layers, FX = d.num_encoding_fn_xyz, FD = d.num_encoding_fn_dir;
     const bool no_view = d.use_viewdirs == 0;
@@ -185,7 +187,14 @@ static BlobLayout build_index_generic(std::vector<int32_t>& index, const nm_mlp_
     }
     pad_to(index, 64);
     lay.off_bwd = index.size();
-    index.resize(index.size() + 1024, -1);
+    std::vector<StepCols> hid_half;
+    hidden_steps_g(hid_half, NTD, H / 2, 0);
+    if (!no_view) {
+        pack_gemm_g(index, T_DIRW, H + dd, H, NT, hid_half, true);     // delta_v (H/2 columns) -> delta at relu(fc_feat) (H rows)
+        pack_gemm_g(index, T_FEATW, H, H, NT, hid, true);
+    }
+    for (int i = L - 2; i >= 0; --i) pack_gemm_g(index, T_XYZ0 + 2 * i, H + (is_skip(d, i) ? dx : 0), H, NT, hid, true);
+    index.resize(index.size() + 8192, -1);
     pad_to(index, 64);
     return lay;
 }
@@ -574,6 +583,8 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         a.g_tab = m->d_enc_tab;
         a.g_nsx = (3 * FX + 1) / 2; a.g_idx = d.include_input_xyz ? 1 : 0; a.g_chx = lay.chx;
         a.g_nsd = no_view ? 0 : (3 * FD + 1) / 2; a.g_idd = (!no_view && d.include_input_dir) ? 1 : 0; a.g_chd = lay.chd;
+        a.g_h = H; a.g_hd = H / 2;
+        m->bwd.g_h = H; m->bwd.g_hd = H / 2;
     }
     m->bwd.wstream = reinterpret_cast<const char*>(base + lay.off_bwd);
     m->bwd.walpha = a.walpha;

@@ -112,7 +112,50 @@ __device__ __forceinline__ void encode_g(float (&enc)[G_ENC_STEPS], const float 
     }
 }
 
-template <int NT, int NW, int KCH>
+// ---- training tape of the generic family: row-major [sample][width] rows of the REAL width (padding never leaves the
+// registers).  16-byte accesses when the row stride allows it (width % 4 == 0), element-wise otherwise (e.g. the 50-wide view
+// layer of a 100-wide network).
+template <int NT>
+__device__ __forceinline__ void store_rows_g(float* base, int width, int64_t sample, bool valid, const float (&op)[4 * NT], int g) {
+    if (!valid) return;
+    float* row = base + sample * width;
+    const bool vec = (width & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int k0 = 16 * nt + 4 * g;
+        if (vec && k0 + 3 < width) {
+            const f32x4 v = {op[4 * nt], op[4 * nt + 1], op[4 * nt + 2], op[4 * nt + 3]};
+            *reinterpret_cast<f32x4*>(row + k0) = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k0 + r < width) row[k0 + r] = op[4 * nt + r];
+        }
+    }
+}
+
+// the same rows back into D layout (zeros beyond the real width): the backward pass takes ReLU' from the taped activations
+template <int NT>
+__device__ __forceinline__ void load_rows_g(const float* base, int width, int64_t sample, float (&op)[4 * NT], int g) {
+    const float* row = base + sample * width;
+    const bool vec = (width & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int k0 = 16 * nt + 4 * g;
+        if (vec && k0 + 3 < width) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + k0);
+            op[4 * nt] = v[0]; op[4 * nt + 1] = v[1]; op[4 * nt + 2] = v[2]; op[4 * nt + 3] = v[3];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) op[4 * nt + r] = k0 + r < width ? row[k0 + r] : 0.0f;
+        }
+    }
+}
+
+// TAPE (nm_mlp_forward_train on a generic-shape handle): the post-activations leave the registers once, as those rows
+// (tape_h[0] = layer1's output, tape_h[1 + i] = relu(layers_xyz[i]), tape_feat, tape_v); no ReLU masks are written --
+// the generic backward kernel reads the signs off the tape.  The radiance is the inference kernel's bit for bit.
+template <int NT, int NW, int KCH, bool TAPE = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const MlpArgs args, const int num_layers,
                                                                        const int density_only) {
     constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
@@ -165,6 +208,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const M
         gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
         gw += enc_x_bytes;
         acc_to_operand<NT, false>(acc, in);
+        if constexpr (TAPE) store_rows_g<NT>(args.tape_h, args.g_h, sample, valid, in, g);
 
         // ---- layers_xyz[0 .. L-2], then (full evaluation only) fc_feat as iteration L-1 (models.py:63-70)
         float sigma = 0.0f;
@@ -195,6 +239,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const M
                 gw = after;
             }
             acc_to_operand<NT, true>(acc, in);
+            if constexpr (TAPE) {
+                float* dst = is_feat ? args.tape_feat : args.tape_h + (int64_t)(1 + i) * args.n * args.g_h;
+                store_rows_g<NT>(dst, args.g_h, sample, valid, in, g);
+            }
         }
 
         if (density_only) {
@@ -221,6 +269,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const M
             }
         }
         acc_to_operand<NTD, true>(accd, v);
+        if constexpr (TAPE) store_rows_g<NTD>(args.tape_v, args.g_hd, sample, valid, v, g);
 
         // ---- fc_rgb + sigmoid (models.py:75), 3-row GEMV on the VALU
         float rgb[3];
@@ -240,6 +289,140 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const M
         if (valid && g == 0) {
             f32x4 o4 = {rgb[0], rgb[1], rgb[2], sigma};
             *reinterpret_cast<f32x4*>(args.out + 4 * sample) = o4;
+        }
+    }
+}
+
+
+// ---- delta propagation of the generic family (nm_mlp_backward on a generic-shape handle): what nerf_train.hip's
+// mlp_backward_kernel does for the tuned shapes -- the transposed layers in reverse order on the same register-resident chain
+// (hidden columns only; the encodings have no gradient) -- with the padded width classes of this header, ReLU' read off the
+// taped activations (a zero activation passes no gradient: the subgradient autograd uses) and each delta stored as rows of
+// the real width once its stage is done.  Stream: [layers_dir.0^T | fc_feat^T |] layers_xyz[L-2 .. 0]^T (mlp_api.hip).
+template <int NT>
+__device__ __forceinline__ void relu_gate(const f32x4 (&acc)[NT], const float* base, int width, int64_t sample, float (&op)[4 * NT], int g) {
+    const float* row = base + sample * width;      // the taped activation of this lane's sample, read tile by tile (no second register array)
+    const bool vec = (width & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int k0 = 16 * nt + 4 * g;
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (vec && k0 + 3 < width) a = *reinterpret_cast<const f32x4*>(row + k0);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = k0 + r < width ? row[k0 + r] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[4 * nt + r] = a[r] > 0.0f ? acc[nt][r] : 0.0f;
+    }
+}
+
+template <int NT, int NW, int KCH>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_backward_kernel_g(const MlpBwdArgs args, const int num_layers,
+                                                                                const int flat) {
+    constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
+    constexpr int KH = 4 * NT, KD = 4 * NTD;
+    constexpr int NB = (NT + 3) / 4;
+    constexpr int STEP = NB * 1024, SLOT = KCH * STEP;
+    constexpr int FIRST_D = (KD < KCH ? KD : KCH) * STEP;       // first chunk of layers_dir.0^T (KD k-steps onto the trunk tiles)
+    constexpr int FIRST_H = (KH < KCH ? KH : KCH) * STEP;       // ... of a hidden^T stage
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_walpha = reinterpret_cast<float*>(lds + 2 * SLOT);   // [4][HP / 4]
+    float* lds_wrgb = lds_walpha + HP;                              // [3][4][HPD / 4], or (flat) [3][4][HP / 4]
+    for (int i = threadIdx.x; i < HP; i += NW * 64) lds_walpha[i] = args.walpha[i];
+    for (int i = threadIdx.x; i < (flat ? 3 * HP : 3 * HPD); i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int L = num_layers, H = args.g_h, HD = args.g_hd;
+    const int first_bytes = flat ? FIRST_H : FIRST_D;
+
+    const int64_t wg_iters = (args.n + NW * 16 - 1) / (NW * 16);
+    int par = 0;
+    if ((int64_t)blockIdx.x < wg_iters) stream_to_lds<NW>(args.wstream, lds, first_bytes, wave, lane);
+    __syncthreads();
+
+    for (int64_t it = blockIdx.x; it < wg_iters; it += gridDim.x) {
+        const bool has_next = it + gridDim.x < wg_iters;
+        const int wrap_bytes = has_next ? first_bytes : 0;
+        const int64_t sample = (it * NW + wave) * 16 + col;
+        const bool valid = sample < args.n;
+        const int64_t sidx = valid ? sample : args.n - 1;
+        // ---- head: sigmoid' (models.py:75 / :78)
+        const f32x4 go = *reinterpret_cast<const f32x4*>(args.grad_out + 4 * sidx);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(args.radiance + 4 * sidx);
+        float drgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) drgb[ch] = go[ch] * (y[ch] * (1.0f - y[ch]));
+        const float dsigma = go[3];
+        if (valid && g == 0) {
+            const f32x4 o4 = {drgb[0], drgb[1], drgb[2], dsigma};
+            *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = o4;
+        }
+        f32x4 acc[NT];
+        float in[KH];
+        const char* gw = args.wstream;
+        if (flat) {
+            // ---- fc_out^T on the VALU: delta at the trunk's output from the four head deltas (rows in fc_alpha's operand layout)
+            const float* wa = lds_walpha + g * (HP / 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
+                f32x4 a = {w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    w4 = *reinterpret_cast<const f32x4*>(lds_wrgb + ch * HP + g * (HP / 4) + 4 * nt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = fmaf(w4[r], drgb[ch], a[r]);
+                }
+                acc[nt] = a;
+            }
+        } else {
+            // ---- fc_rgb^T on the VALU, gated by the view layer's ReLU: delta at layers_dir.0's pre-activation
+            float dv[KD], av[KD];
+            load_rows_g<NTD>(args.tape_v, HD, sidx, av, g);
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                float a = lds_wrgb[(0 * 4 + g) * KD + s] * drgb[0];
+                a = fmaf(lds_wrgb[(1 * 4 + g) * KD + s], drgb[1], a);
+                a = fmaf(lds_wrgb[(2 * 4 + g) * KD + s], drgb[2], a);
+                dv[s] = av[s] > 0.0f ? a : 0.0f;
+            }
+            store_rows_g<NTD>(args.d_v, HD, sample, valid, dv, g);
+            // ---- layers_dir.0^T (hidden columns): -> delta at relu(fc_feat) -> gated -> delta at fc_feat's output
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            gemm_stage_g<NT, KD, NW, KCH, false>(acc, dv, 0, gw, gw + KD * STEP, FIRST_H, lds, SLOT, par, wave, lane);
+            gw += KD * STEP;
+            relu_gate<NT>(acc, args.tape_feat, H, sidx, in, g);
+            store_rows_g<NT>(args.d_feat, H, sample, valid, in, g);
+            // ---- fc_feat^T + fc_alpha^T: delta at the output of layers_xyz[L-2]
+            const float* wa = lds_walpha + g * (HP / 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
+                acc[nt] = f32x4{w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+            }
+            gemm_stage_g<NT, KH, NW, KCH, false>(acc, in, 0, gw, gw + KH * STEP, FIRST_H, lds, SLOT, par, wave, lane);
+            gw += KH * STEP;
+        }
+        relu_gate<NT>(acc, args.tape_h + (int64_t)(L - 1) * args.n * H, H, sidx, in, g);
+        store_rows_g<NT>(args.d_h + (int64_t)(L - 1) * args.n * H, H, sample, valid, in, g);
+        // ---- layers_xyz[i]^T, i = L-2 .. 0: delta at the input of layers_xyz[i] (gated by the ReLU of layers_xyz[i-1]; layer1 has none)
+#pragma unroll 1
+        for (int i = L - 2; i >= 0; --i) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const char* after = gw + KH * STEP;
+            gemm_stage_g<NT, KH, NW, KCH, false>(acc, in, 0, gw, i == 0 ? args.wstream : after, i == 0 ? wrap_bytes : FIRST_H, lds,
+                                                 SLOT, par, wave, lane);
+            gw = after;
+            if (i > 0) {
+                relu_gate<NT>(acc, args.tape_h + (int64_t)i * args.n * H, H, sidx, in, g);
+            } else {
+                acc_to_operand<NT, false>(acc, in);
+            }
+            store_rows_g<NT>(args.d_h + (int64_t)i * args.n * H, H, sample, valid, in, g);
         }
     }
 }

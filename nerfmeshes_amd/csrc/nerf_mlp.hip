@@ -46,13 +46,14 @@ template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool
 static MlpPlan make_plan(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 2 * Net<H, FX, FD, KCH>::LDSBUF, LBIAS,
                    &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false>, NW * 16, 8 / NW,
-                   (ABL == 0 && LBIAS) ? &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false, true> : nullptr, 0};
+                   (ABL == 0 && LBIAS) ? &mlp_kernel<H, FX, FD, NW, KCH, PIPE, KEEP_ENC, LBIAS, SPREAD, ABL, false, true> : nullptr, 0,
+                   nullptr, nullptr};
 }
 
 template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0>
 static MlpPlan make_plan3(int variant) {
     return MlpPlan{H, FX, FD, NW, KCH, variant, 3 * Net<H, FX, FD, KCH>::LDSBUF, true, &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL>,
-                   NW * 16, 8 / NW, ABL == 0 ? &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL, true> : nullptr, 0};
+                   NW * 16, 8 / NW, ABL == 0 ? &mlp_kernel3<H, FX, FD, NW, KCH, STAG, ABL, true> : nullptr, 0, nullptr, nullptr};
 }
 
 // variant 0 is the production choice and the ONLY one in libnerfmeshes_hip.so.  The others exist for within-process

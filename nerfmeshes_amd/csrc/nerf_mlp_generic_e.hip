@@ -13,7 +13,7 @@ static MlpPlan generic_plan() {
     constexpr int KCH = NT <= 16 ? 8 : 4;     // 32 KiB ring slots either way
     constexpr int SLOT = KCH * ((NT + 3) / 4) * 1024;
     return MlpPlan{16 * NT, -1, -1, NW, KCH, 0, 2 * SLOT, true, &mlp_kernel_g<NT, NW, KCH>, NW * 16, 1,
-                   &mlp_kernel_g<NT, NW, KCH>, NT};
+                   &mlp_kernel_g<NT, NW, KCH>, NT, &mlp_kernel_g<NT, NW, KCH, true>, &mlp_backward_kernel_g<NT, NW, KCH>};
 }
 
 void generic_plans_e(std::vector<MlpPlan>& out) {

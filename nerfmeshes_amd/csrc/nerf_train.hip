@@ -13,6 +13,7 @@
 // Roofline: MFMA.  557 056 MAC / sample for the 8x256 net (vs 593 408 forward).
 #include "nm_internal.h"
 #include "mlp_device.h"
+#include "mlp_device_g.h"
 
 namespace nm {
 
@@ -278,8 +279,28 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
     const nm_mlp_desc& d = m->desc;
     const bool flat = d.use_viewdirs == 0;      // models.py:77-79: the tape is the trunk's (d_h, d_mask_h); d_feat / d_v / d_mask_v are not touched
-    NM_REQUIRE(tape->d_h && tape->d_mask_h && (flat || (tape->d_feat && tape->d_v && tape->d_mask_v)), "incomplete tape");
+    const bool generic = m->plan->generic_nt != 0;     // generic-shape family: activation rows only, no ReLU masks (mlp_device_g.h)
+    NM_REQUIRE(tape->d_h && (generic || tape->d_mask_h) && (flat || (tape->d_feat && tape->d_v && (generic || tape->d_mask_v))), "incomplete tape");
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
+    if (generic) {
+        MlpArgs a = m->base;
+        a.mode = MODE_RAYS;
+        a.a = d_origins; a.b = d_dirs; a.c = d_t;
+        a.origins_per_ray = origins_per_ray; a.samples = samples;
+        a.n = rays * samples; a.out = d_radiance;
+        if (a.n == 0) return 0;
+        a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
+        a.tiles = (a.n + 15) / 16;
+        const MlpPlan* p = m->plan;
+        const int HP = 16 * p->generic_nt, L = d.num_layers;
+        const int lds_bytes = p->ring_bytes + (HP * (1 + L) + 16 * ((p->generic_nt + 1) / 2) + 4 + HP + 3 * HP) * 4 + 2 * G_ENC_ARGS * (int)sizeof(GEncArg);
+        if (int rc = set_lds((const void*)p->kernel_tape, lds_bytes)) return rc;
+        const int64_t wg_iters = (a.n + p->wg_samples - 1) / p->wg_samples;
+        hipLaunchKernelGGL(p->kernel_tape, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(p->NW * 64), lds_bytes,
+                           static_cast<hipStream_t>(stream), a, L, flat ? 2 : 0);
+        NM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const TrainPlan* plan = nullptr;
     for (const TrainPlan& p : g_train_plans)
         if (p.H == d.hidden_size && p.FX == d.num_encoding_fn_xyz && p.FD == (flat ? 4 : d.num_encoding_fn_dir)) plan = &p;
@@ -310,10 +331,27 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
     NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && deltas && n >= 0, "bad argument");
     const nm_mlp_desc& d = m->desc;
     const bool flat = d.use_viewdirs == 0;
-    NM_REQUIRE(tape->d_mask_h && (flat || tape->d_mask_v), "incomplete tape");
+    const bool generic = m->plan->generic_nt != 0;
+    NM_REQUIRE(generic ? (tape->d_h && (flat || (tape->d_feat && tape->d_v))) : (tape->d_mask_h && (flat || tape->d_mask_v)), "incomplete tape");
     NM_REQUIRE(deltas->d_h && deltas->d_last && (flat || (deltas->d_feat && deltas->d_v)), "incomplete delta buffers");
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
     if (n == 0) return 0;
+    if (generic) {
+        MlpBwdArgs a = m->bwd;
+        a.radiance = d_radiance; a.grad_out = d_grad_radiance;
+        a.n = n; a.tiles = (n + 15) / 16;
+        a.d_h = deltas->d_h; a.d_feat = deltas->d_feat; a.d_v = deltas->d_v; a.d_last = deltas->d_last;
+        a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
+        const MlpPlan* p = m->plan;
+        const int HP = 16 * p->generic_nt;
+        const int lds_bytes = p->ring_bytes + (HP + 3 * HP) * 4;
+        if (int rc = set_lds((const void*)p->kernel_bwd, lds_bytes)) return rc;
+        const int64_t wg_iters = (n + p->wg_samples - 1) / p->wg_samples;
+        hipLaunchKernelGGL(p->kernel_bwd, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(p->NW * 64), lds_bytes,
+                           static_cast<hipStream_t>(stream), a, (int)d.num_layers, flat ? 1 : 0);
+        NM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const BwdPlan* plan = nullptr;
     for (const BwdPlan& p : g_bwd_plans)
         if (p.H == d.hidden_size) plan = &p;

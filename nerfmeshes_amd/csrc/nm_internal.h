@@ -32,7 +32,7 @@ void set_error(const std::string& msg);
 // ---- fused MLP ------------------------------------------------------------------------------
 constexpr int KC = 8;          // k-steps (of 4 input features) per LDS weight chunk
 constexpr int MAX_FREQ_XYZ = 16;
-constexpr int MAX_FREQ_DIR = 8;
+constexpr int MAX_FREQ_DIR = 16;
 
 enum MlpMode : int { MODE_POINTS = 0, MODE_RAYS = 1, MODE_GRID = 2, MODE_VIEW = 3 };
 
@@ -121,6 +121,7 @@ struct MlpArgs {
     const void* g_tab;       // device: GEncArg[2][48] (xyz, dir): coordinate and frequency band of every encoding argument
     int32_t g_nsx, g_idx, g_chx;   // xyz: k-steps that carry arguments, 1 = an identity step follows, whole chunks in the stream
     int32_t g_nsd, g_idd, g_chd;   // direction encoding likewise (g_chd = 0: no encoded direction columns at all)
+    int32_t g_h, g_hd;             // the REAL widths hidden_size and hidden_size // 2: row strides of the generic training tape
 };
 
 // Kernel arguments of the backward (delta propagation) kernel.
@@ -137,6 +138,11 @@ struct MlpBwdArgs {
     float* d_feat;           // (n, H)
     float* d_v;              // (n, H/2)
     float* d_last;           // (n, 4): pre-sigmoid rgb gradient, sigma gradient
+    // generic-shape backward (mlp_device_g.h): ReLU' comes from the taped activations instead of masks
+    const float* tape_h;     // (L, n, H)
+    const float* tape_feat;  // (n, H)
+    const float* tape_v;     // (n, H / 2)
+    int32_t g_h, g_hd;       // real widths (row strides)
 };
 
 // Flat addressing of the trainable tensors (index maps of the packed blob: tensor id << 24 | element)
@@ -156,6 +162,8 @@ struct MlpPlan {
     int wg_per_cu;       // workgroups co-resident on a CU
     void (*kernel_flat)(const MlpArgs, const int, const int);   // the FLAT instantiation (use_viewdirs = 0 networks), or null
     int generic_nt;      // 0: a tuned plan for exactly (H, FX, FD) | NT: the generic family's width class (mlp_device_g.h), H = 16 NT
+    void (*kernel_tape)(const MlpArgs, const int, const int);        // generic family: the taping forward ...
+    void (*kernel_bwd)(const MlpBwdArgs, const int, const int);      // ... and the delta kernel (null for tuned plans: nerf_train.hip)
 };
 
 // fused MLP over rays generated from a camera pose (mlp_api.hip; used by the render path in ray_ops.hip)

@@ -227,6 +227,8 @@ def render_rays(coarse, fine, origins, dirs, near, far, u_coarse, u_fine, lindis
     ft, fout = (None, None) if fine is None else _alloc_bundle(rays, sc + nf, device)
     per_ray_o = int(origins.shape[0] == rays and rays > 1)
     per_ray_b = int(near.numel() == rays and rays > 1)
+    if rays == 0:      # an empty shard (more ranks than rays): empty bundles, no launch (zero-size tensors have no address to pass)
+        return ct, ft
     check(lib.nm_render_rays(coarse.handle, fine.handle if fine is not None else None, C.byref(cfg), _ptr(origins),
                              per_ray_o, _ptr(dirs), _ptr(near), _ptr(far), per_ray_b, _ptr(u_coarse), _ptr(u_f),
                              rays, _ptr(ws), C.byref(cout), C.byref(fout) if fout is not None else None, _stream()),

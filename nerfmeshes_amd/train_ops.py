@@ -6,8 +6,10 @@ What `loss.backward()` does in the reference's `NeRFModel.training_step`
 * `mlp_rays`       -- FlexibleNeRFModel.forward over ray samples as a `torch.autograd.Function`:
                       forward = the fused HIP kernel recording a tape, backward = the HIP delta kernel +
                       the hand-written weight-gradient kernels (dW = delta^T @ activation rows: nm_weight_grad for
-                      the 128- / 256-wide layers, nm_head_grad for fc_alpha / fc_rgb); 64-wide networks and sample
-                      counts that are not a multiple of 16 take a library GEMM (torch.bmm split-K, `_tn`).
+                      the 128- / 256-wide layers, nm_head_grad for fc_alpha / fc_rgb); 64-wide networks, sample
+                      counts that are not a multiple of 16 and the off-menu shapes of the generic kernel family take a
+                      library GEMM for these plain products (torch.bmm split-K, `_tn`).  Every shape nm_mlp_create
+                      accepts trains: tuned kernels for the shipped configs' shapes, the generic family otherwise.
 * `composite`      -- VolumeRenderer.forward (noise + ReLU + alpha compositing) with a HIP backward.
 * `perturb_intervals`, `sample_pdf_rand` -- the stochastic depth samplers; random numbers are torch's.
 
@@ -72,6 +74,7 @@ def forward_train(mlp, origins, dirs, t):
     tiles = (n + 15) // 16
     f32 = dict(dtype=torch.float32, device=mlp.device)
     flat = not mlp.desc.get("use_viewdirs", True)      # trunk-only tape: no fc_feat / layers_dir activations
+    generic = mlp.kernel_variant()[0] >= 1000          # generic-shape family: ReLU' is read off the activation rows, no masks
     tape_bytes = 4 * n * (L * H + (0 if flat else H + H // 2))
     if 2.1 * tape_bytes > torch.cuda.get_device_properties(mlp.device).total_memory:     # tape + deltas of the backward
         raise _lib.HipLibraryError(
@@ -79,8 +82,8 @@ def forward_train(mlp, origins, dirs, t):
             "deltas): use a smaller ray chunk, or torch.no_grad() if this is inference")
     tape = dict(h=torch.empty(L, n, H, **f32), feat=None if flat else torch.empty(n, H, **f32),
                 v=None if flat else torch.empty(n, H // 2, **f32),
-                mask_h=torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
-                mask_v=None if flat else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
+                mask_h=None if generic else torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
+                mask_v=None if flat or generic else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
     out = torch.empty(rays, samples, 4, **f32)
     ct = _tape_struct(tape)
     check(lib.nm_mlp_forward_train(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays, samples,
@@ -90,7 +93,7 @@ def forward_train(mlp, origins, dirs, t):
 
 def _tape_struct(tape):
     opt = lambda x: None if x is None else _ptr(x)   # noqa: E731
-    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(tape["v"]), _ptr(tape["mask_h"]), opt(tape["mask_v"]))
+    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(tape["v"]), opt(tape["mask_h"]), opt(tape["mask_v"]))
 
 
 def encode_samples(mlp, origins, dirs, t):

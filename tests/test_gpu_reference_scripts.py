@@ -75,6 +75,6 @@ def test_reference_train_nerf_main_over_the_hip_kernels(tmp_path):
     nm_mlp_backward, Adam, LoggerCallback lines, checkpoints; the loss falls and the resumed run moves the weights."""
     out = _run("train", tmp_path)
     assert "[TRAIN] Iter: 2 LOSS:" in out["stdout"] and "[VAL] =======> Iter: 3" in out["stdout"] and "Done!" in out["stdout"]
-    assert "model_last.ckpt" in out["checkpoints"] and out["hparams_yaml"] and out["state_dict_keys"] == 38      # 4x64 here: a menu shape (training kernels)
+    assert "model_last.ckpt" in out["checkpoints"] and out["hparams_yaml"] and out["state_dict_keys"] == 38
     assert out["train_losses"][-1] < out["train_losses"][0]
     assert out["resumed_global_step"] > out["global_step"] and out["weights_moved"]

@@ -153,8 +153,9 @@ def main():
     full = render(0, hh * ww)                                # what one process produces
     sharded = nd.render_view_sharded(render, hh * ww)        # ragged all-gather over RCCL
     assert sharded.shape == full.shape and torch.equal(sharded, full), "sharded pixels differ from the 1-rank render"
-    even = nd.render_view_sharded(render, 4096 * world)      # equal shards: single-collective fast path
-    assert torch.equal(even, full[:4096 * world])
+    per = min(4096, hh * ww // world)
+    even = nd.render_view_sharded(render, per * world)       # equal shards: single-collective fast path
+    assert torch.equal(even, full[:per * world])
 
     n = 37                                                   # 37 planes: ragged slabs
     ax = torch.linspace(-1.2, 1.2, n).to(dev)

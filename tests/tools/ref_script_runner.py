@@ -49,9 +49,6 @@ if HIP and not torch.cuda.is_available():
     raise SystemExit("NM_REF_BACKEND=hip needs a MI355X")
 DEVICE = "cuda" if HIP else "cpu"
 MLP = dict(num_layers=4, hidden_size=32, skip_step=2, num_encoding_fn_xyz=4, num_encoding_fn_dir=2)
-if HIP and len(sys.argv) > 1 and sys.argv[1] == "train":
-    # the training kernels are instantiated for the shipped configs' shapes (the generic family is inference-only)
-    MLP = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
 MODEL_NAME = "NeRFModel" if HIP else "OracleNeRFModel"      # the class the checkpoints name, i.e. what the scripts instantiate
 H, W, FOCAL = 10, 14, 16.0
 
