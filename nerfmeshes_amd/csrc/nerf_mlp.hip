@@ -37,6 +37,9 @@
 #include "mlp_device_r3.h"
 #include "mlp_device_b3.h"
 #include "mlp_device_g.h"
+#ifdef NM_ABLATIONS
+#include "mlp_device_g2.h"
+#endif
 
 namespace nm {
 
@@ -105,6 +108,11 @@ static const std::vector<MlpPlan>& all_plans() {
     static const std::vector<MlpPlan> plans = [] {
         std::vector<MlpPlan> v(std::begin(g_tuned_plans), std::end(g_tuned_plans));
         generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_e(v);
+#ifdef NM_ABLATIONS
+        // experiment (NM_MLP_VARIANT=200 + NM_KERNEL_GENERIC): two 16-sample column tiles per wave (mlp_device_g2.h)
+        v.push_back(MlpPlan{64, -1, -1, 8, 8, 200, 2 * 8 * 1024, true, &mlp_kernel_g2<4, 8, 8>, 8 * 32, 1, nullptr, 4, nullptr, nullptr});
+        v.push_back(MlpPlan{128, -1, -1, 8, 8, 200, 2 * 8 * 2 * 1024, true, &mlp_kernel_g2<8, 8, 8>, 8 * 32, 1, nullptr, 8, nullptr, nullptr});
+#endif
         return v;
     }();
     return plans;
@@ -144,8 +152,12 @@ const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
 }
 
 const MlpPlan* find_generic_plan(int H) {
+    int want = 0;
+#ifdef NM_ABLATIONS
+    if (const char* v = getenv("NM_MLP_VARIANT")) want = atoi(v) == 200 ? 200 : 0;
+#endif
     for (const MlpPlan& p : all_plans())
-        if (p.generic_nt && p.H >= H) return &p;
+        if (p.generic_nt && p.variant == want && p.H >= H) return &p;
     return nullptr;
 }
 
