@@ -28,7 +28,11 @@ extern "C" {
 
 /* 2 (round 3): + nm_mc_count_slab / nm_mc_emit_slab, nm_np_chunk_count / nm_np_chunk_sums / nm_np_finish, use_viewdirs = 0
  * handles; nm_mc_workspace_bytes grew (per-cube decision table, cut-cube list).  Everything in version 1 is unchanged. */
-#define NM_ABI_VERSION 2
+/* 3 (round 4): nm_mlp_create accepts every FlexibleNeRFModel shape (generic kernel family; nm_mlp_kernel_variant >= 1000),
+ * NM_KERNEL_GENERIC, training entry points for use_viewdirs = 0 and generic-shape handles (tape / delta fields those do not use
+ * may be NULL), nm_mc_emit_slab accepts NULL outputs for an empty own share.  No signature changed; everything in version 2 is
+ * unchanged. */
+#define NM_ABI_VERSION 3
 
 const char* nm_last_error(void);
 int nm_abi_version(void);
@@ -222,7 +226,11 @@ int nm_render_view(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
 int nm_mlp_refresh(nm_mlp* mlp, const nm_mlp_weights* d_weights, void* stream);
 
 /* Activations recorded by the training forward, n = rays * samples, tiles = ceil(n / 16), L = num_layers,
- * H = hidden_size.  Rows are the operands of the weight-gradient GEMMs (dW = delta^T @ rows). */
+ * H = hidden_size.  Rows are the operands of the weight-gradient GEMMs (dW = delta^T @ rows).
+ * A use_viewdirs = 0 handle tapes the trunk only: d_feat, d_v and d_mask_v are not touched and may be NULL (likewise the
+ * d_feat / d_v of nm_mlp_deltas).  A generic-shape handle (nm_mlp_kernel_variant >= 1000) writes no masks -- its backward
+ * kernel reads ReLU' off the activation rows, which nm_mlp_backward therefore needs (d_h, d_feat, d_v) --: d_mask_h and
+ * d_mask_v may be NULL. */
 typedef struct nm_mlp_tape {
     float* d_h;          /* (L, n, H): [0] layer1 output; [1+i] relu(layers_xyz[i](.))               */
     float* d_feat;       /* (n, H): relu(fc_feat(x))                                               */
