@@ -517,6 +517,16 @@ def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=2, cpu_size
     launches, kernel_ms, kernel_flops = hip_ops.mlp_profile_read()
     hip_ops.mlp_profile_enable(False)
     achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    # what the UNMODIFIED script's loop shape costs: every call is one cfg.nerf.validation.chunksize = 2048-ray chunk
+    # (eval_nerf.py:62-65), i.e. 313 calls of ~8 launches per view instead of 10
+    vs1 = [(S.orbit_poses(views)[0], H, W, S.LEGO_FOCAL_800, photograph)]
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        E.eval_views(model, vs1, cfg, dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        small_losses, _, _, _ = E.eval_views(model, vs1, cfg, dev)
+        torch.cuda.synchronize()
+        wall_2048 = time.perf_counter() - t1
     out = {"workload": f"config 3 at N = 1: {views} orbit views of 800x800 through the eval_nerf mirror (eval_views), 8x256 coarse+fine, 64+128, "
                        f"rays generated in the kernels, rendered in calls of {render_chunk} rays, loss bookkeeping per 2048 rays / float batch_count 312.5",
            "value": views * H * W / wall, "unit": "rays/s", "views": views, "ms_per_view": wall / views * 1e3,
@@ -524,7 +534,11 @@ def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=2, cpu_size
            "per_view_psnr_db_min_max": [float(min(-10.0 * torch.log10(l) for l in losses)), float(max(-10.0 * torch.log10(l) for l in losses))],
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "launches": launches,
-                        "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / wall}}
+                        "mlp_kernel_share_of_wall": kernel_ms * 1e-3 / wall},
+           "at_reference_chunksize": {"chunk_rays": int(cfg.nerf.validation.chunksize), "value": H * W / wall_2048, "unit": "rays/s",
+                                      "ms_per_view": wall_2048 * 1e3, "same_loss_as_large_calls": bool(float(small_losses[0]) == float(losses[0])),
+                                      "note": "one view rendered in the reference's own 2048-ray calls (313 per view): what the unmodified "
+                                              "eval_nerf.py loop gets without raising nerf.validation.chunksize"}}
     if not cpu_legs:
         return out
     from oracle import nerf_oracle as O, parity
