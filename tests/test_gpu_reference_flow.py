@@ -196,3 +196,28 @@ def test_train_nerf_resume_from_log_checkpoint(trained):
     assert after["global_step"] == before["global_step"] + 4 == 16 and trainer.global_step == 16
     assert any(not torch.equal(before["state_dict"][k], after["state_dict"][k]) for k in before["state_dict"])
     assert after["optimizer_states"][0]["state"][0]["step"] >= 15
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_train_nerf_two_ranks_keep_identical_replicas(scene, deterministic):
+    """`train_nerf` under torch.distributed.run.  Two ranks on the one GPU (NERFMESHES_RANKS_PER_GPU=2, gloo)
+    run the reference's command line; without --deterministic every rank builds its own randomly initialised model, with it
+    every rank seeds alike: either way the ranks must end with EQUAL parameters (rank 0's broadcast + averaged gradients),
+    must have trained on DIFFERENT rays, and must share one version directory; rank 0's checkpoint is that model."""
+    import subprocess
+    import sys
+    import socket
+    root, _ = scene
+    cfg_path, hp = _config(root, **{"experiment.id": f"ddp{int(deterministic)}", "experiment.train_iters": 8, "experiment.validate_every": 8})
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NERFMESHES_RANKS_PER_GPU="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(here, "tools", "train_worker.py"), cfg_path, str(int(deterministic))],
+                       cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)
+    tb = r.stderr[r.stderr.find("Traceback"):][:3000] if "Traceback" in r.stderr else r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout[-1500:] + tb
+    assert "TRAIN_DDP_OK world=2 steps=8" in r.stdout, r.stdout[-1500:]
