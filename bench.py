@@ -170,20 +170,20 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
     wc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.model_coarse.named_parameters()}
     wf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.model_fine.named_parameters()}
 
-    def cpu_iter():
-        t_c = O.perturb_intervals(O.coarse_intervals(NEAR, FAR, NUM_COARSE, cpu_rays), torch.rand(cpu_rays, NUM_COARSE))
+    def cpu_iter(n=cpu_rays):
+        t_c = O.perturb_intervals(O.coarse_intervals(NEAR, FAR, NUM_COARSE, n), torch.rand(n, NUM_COARSE))
         loss, tt = 0.0, t_c
         for w_, first in ((wc, True), (wf, False)):
-            pts = O.ray_points(tt, dc, oc).reshape(-1, 3)
-            dirs_ = dc[:, None, :].expand(-1, tt.shape[1], -1).reshape(-1, 3)
-            rad = O.mlp_forward(w_, spec, pts, dirs_, keep_graph=True).reshape(cpu_rays, -1, 4)
-            b = O.composite(rad, tt, dc, rs, noise=0.2 * torch.randn(cpu_rays, tt.shape[1]))
-            loss = loss + torch.nn.functional.mse_loss(b["rgb_map"], tgt)
+            pts = O.ray_points(tt, dc[:n], oc).reshape(-1, 3)
+            dirs_ = dc[:n, None, :].expand(-1, tt.shape[1], -1).reshape(-1, 3)
+            rad = O.mlp_forward(w_, spec, pts, dirs_, keep_graph=True).reshape(n, -1, 4)
+            b = O.composite(rad, tt, dc[:n], rs, noise=0.2 * torch.randn(n, tt.shape[1]))
+            loss = loss + torch.nn.functional.mse_loss(b["rgb_map"], tgt[:n])
             if first:
-                tt = O.sample_pdf_intervals(t_c, b["weights"].detach(), NUM_FINE, u=torch.rand(cpu_rays, NUM_FINE))
+                tt = O.sample_pdf_intervals(t_c, b["weights"].detach(), NUM_FINE, u=torch.rand(n, NUM_FINE))
         loss.backward()
 
-    threads = _pick_threads(cpu_iter, os.cpu_count() or 1)
+    threads = _pick_threads(lambda: cpu_iter(64), os.cpu_count() or 1)      # the thread count is chosen on a quarter-size batch
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
@@ -476,7 +476,7 @@ def buff_probe(dev, cpu_rays=2048, rank=0, world=1, use_dist=False, cpu_legs=Tru
     return out
 
 
-def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=2, cpu_size=80, cpu_legs=True):
+def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=2, cpu_size=72, cpu_legs=True):
     """BASELINE config 3 at N = 1 (`eval_nerf.py` over a test set, /root/reference/src/eval_nerf.py:50-105): `views` orbit
     views of 800x800 through the eval_nerf mirror (`eval_views`: per-view loss = sum of per-2048-ray-chunk MSEs divided by
     the FLOAT batch count 312.5, dataset loss = mean over views, PSNR of that), every view scored against a seeded noisy
