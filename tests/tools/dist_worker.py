@@ -153,6 +153,8 @@ def main():
     full = render(0, hh * ww)                                # what one process produces
     sharded = nd.render_view_sharded(render, hh * ww)        # ragged all-gather over RCCL
     assert sharded.shape == full.shape and torch.equal(sharded, full), "sharded pixels differ from the 1-rank render"
+    if world == 1:      # the ragged path's collective (a broadcast per non-empty shard) on a one-rank RCCL communicator as well
+        assert torch.equal(nd.all_gather_v(full[:1001].contiguous(), [1001]), full[:1001])
     per = min(4096, hh * ww // world)
     even = nd.render_view_sharded(render, per * world)       # equal shards: single-collective fast path
     assert torch.equal(even, full[:per * world])
