@@ -159,7 +159,7 @@ __device__ __forceinline__ float b3_convert(const f32x4 (&acc)[NT], Split3 (&out
 template <int H, int FX, int FD, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, const int num_layers, const int density_only) {
     constexpr int NT = H / 16, KB = H / 32, NTD = H / 32, KBX = 2, KBD = 1;
-    static_assert(6 * FX + 3 <= 64 && 6 * FD + 3 <= 32, "encoding slots");
+    static_assert(6 * FX + 3 <= 64 && 6 * FD + 3 <= 32 && FX <= 16 && FD <= 16, "encoding slots");
     static_assert(NT * KBX >= 2 * B3_CHUNK_UNITS && NTD * (KB + KBD) >= 2 * B3_CHUNK_UNITS, "stages must span two chunks");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_bias = reinterpret_cast<float*>(lds + 3 * B3_SLOT);
@@ -169,6 +169,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
     for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
     for (int i = threadIdx.x; i < H; i += NW * 64) lds_walpha[i] = args.walpha[i];
     for (int i = threadIdx.x; i < 3 * H / 2; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    // the frequency bands as an LDS table: read where they are used (held in registers across the sample loop they were
+    // what the compiler spilled to scratch)
+    float* lds_bands = lds_wrgb + 3 * H / 2;
+    if (threadIdx.x < FX) lds_bands[threadIdx.x] = args.bands_xyz[threadIdx.x];
+    if (threadIdx.x < FD) lds_bands[16 + threadIdx.x] = args.bands_dir[threadIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
@@ -200,9 +205,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         const bool valid = sample < args.n;
         const SamplePD smp = fetch_sample(args, valid ? sample : args.n - 1);
         const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
-        Split3 encx[KBX];
-#pragma unroll
-        for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, args.bands_xyz, m, g, encx[m]);
         const B3Next wrap = next_of(args.wstream, U_ENC, has_next);
         const Split3 none[1] = {};
 
@@ -211,7 +213,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         const char* gw = args.wstream;
         // ---- layer1 (no activation)
         load_bias<NT>(acc, lds_bias, g);
-        gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, next_of(gw + U_ENC * B3_UNIT, U_HID, true), lds, slot, carry, wave, lane);
+        {
+            Split3 encx[KBX];
+#pragma unroll
+            for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, g, encx[m]);
+            gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, next_of(gw + U_ENC * B3_UNIT, U_HID, true), lds, slot, carry, wave, lane);
+        }
         gw += U_ENC * B3_UNIT;
         b3_convert<NT, false>(acc, in, lds_walpha + g * (H / 4), false);
 
@@ -235,6 +242,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
             if (skip) {
                 const char* after = gw + U_ENC * B3_UNIT;
                 const B3Next nx = last_density ? wrap : next_of(after, U_HID, true);
+                // the encoding is recomputed here instead of being held across the trunk (24 registers for 8 sincosf:
+                // what took the kernel over its 256-register budget into scratch); same values, same bits
+                Split3 encx[KBX];
+#pragma unroll
+                for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, g, encx[m]);
                 gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, nx, lds, slot, carry, wave, lane);
                 gw = after;
             }
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         f32x4 accd[NTD];
         load_bias<NTD>(accd, lds_bias + H * (1 + num_layers), g);
         Split3 encd[KBD];
-        b3_encode_block<FD>(d, args.bands_dir, 0, g, encd[0]);
+        b3_encode_block<FD>(d, lds_bands + 16, 0, g, encd[0]);
         gemm_stage_b3<NTD, KB, KBD, NW>(accd, in, encd, gw, wrap, lds, slot, carry, wave, lane);
         float v[4 * NTD];
         acc_to_operand<NTD, true>(accd, v);

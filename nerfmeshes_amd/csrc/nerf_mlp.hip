@@ -187,7 +187,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     if (m->precision == NM_PREC_BF16X3) {
         const B3Plan* b = find_b3_plan(H, m->desc.num_encoding_fn_xyz, m->desc.num_encoding_fn_dir);
         NM_REQUIRE(b && m->d_stream_b3, "no bf16x3 kernel for this network");
-        const int lds_bytes = 3 * B3_SLOT + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2) * 4 + 255) & ~255);
+        const int lds_bytes = 3 * B3_SLOT + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2 + 32) * 4 + 255) & ~255);   // + the two band tables
         NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (bf16x3 ring + bias cache): too many layers");
         NM_HIP_CHECK(hipFuncSetAttribute((const void*)b->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         MlpArgs a = args;
