@@ -205,6 +205,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         const bool valid = sample < args.n;
         const SamplePD smp = fetch_sample(args, valid ? sample : args.n - 1);
         const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
+        // the lane group as a value the compiler cannot see through at each encoding site: the per-lane slot arithmetic
+        // (a / F, a % F, a < 3F) is then computed where it is used instead of being hoisted out of the sample and trunk
+        // loops and spilled (with the band table in LDS and the skip layer's re-encoding: 246 VGPRs, no scratch; was 104 B)
+        auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
         const B3Next wrap = next_of(args.wstream, U_ENC, has_next);
         const Split3 none[1] = {};
 
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         {
             Split3 encx[KBX];
 #pragma unroll
-            for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, g, encx[m]);
+            for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, opaque(g), encx[m]);
             gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, next_of(gw + U_ENC * B3_UNIT, U_HID, true), lds, slot, carry, wave, lane);
         }
         gw += U_ENC * B3_UNIT;
@@ -242,11 +246,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
             if (skip) {
                 const char* after = gw + U_ENC * B3_UNIT;
                 const B3Next nx = last_density ? wrap : next_of(after, U_HID, true);
-                // the encoding is recomputed here instead of being held across the trunk (24 registers for 8 sincosf:
-                // what took the kernel over its 256-register budget into scratch); same values, same bits
+                // the encoding is recomputed here instead of being held across the trunk (24 registers for 8 sincosf);
+                // same values, same bits
                 Split3 encx[KBX];
 #pragma unroll
-                for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, g, encx[m]);
+                for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, opaque(g), encx[m]);
                 gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, nx, lds, slot, carry, wave, lane);
                 gw = after;
             }
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         f32x4 accd[NTD];
         load_bias<NTD>(accd, lds_bias + H * (1 + num_layers), g);
         Split3 encd[KBD];
-        b3_encode_block<FD>(d, lds_bands + 16, 0, g, encd[0]);
+        b3_encode_block<FD>(d, lds_bands + 16, 0, opaque(g), encd[0]);
         gemm_stage_b3<NTD, KB, KBD, NW>(accd, in, encd, gw, wrap, lds, slot, carry, wave, lane);
         float v[4 * NTD];
         acc_to_operand<NTD, true>(accd, v);
