@@ -39,6 +39,7 @@
 #include "mlp_device_g.h"
 #ifdef NM_ABLATIONS
 #include "mlp_device_g2.h"
+#include "mlp_device_b3w.h"
 #endif
 
 namespace nm {
@@ -122,10 +123,16 @@ static const std::vector<MlpPlan>& all_plans() {
 struct B3Plan {
     int H, FX, FD;
     void (*kernel)(const MlpArgs, const int, const int);
+    void (*kernel_w)(const MlpArgs, const int, const int);      // ablation library: two column tiles per wave (mlp_device_b3w.h)
 };
 static const B3Plan g_b3_plans[] = {
-    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>},
-    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>},
+#ifdef NM_ABLATIONS
+    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>, &mlp_kernel_b3w<256, 10, 4, 4>},
+    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>, &mlp_kernel_b3w<256, 6, 4, 4>},
+#else
+    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>, nullptr},
+    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>, nullptr},
+#endif
 };
 static const B3Plan* find_b3_plan(int H, int FX, int FD) {
     for (const B3Plan& p : g_b3_plans)
@@ -189,7 +196,13 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
         NM_REQUIRE(b && m->d_stream_b3, "no bf16x3 kernel for this network");
         const int lds_bytes = 3 * B3_SLOT + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2 + 32) * 4 + 255) & ~255);   // + the two band tables
         NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (bf16x3 ring + bias cache): too many layers");
-        NM_HIP_CHECK(hipFuncSetAttribute((const void*)b->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        auto b3_kernel = b->kernel;
+        unsigned b3_threads = 512;
+#ifdef NM_ABLATIONS
+        if (const char* v = getenv("NM_MLP_VARIANT"))       // experiment: 4 waves x 32 samples, the same 128-sample workgroup
+            if (atoi(v) == 300) { b3_kernel = b->kernel_w; b3_threads = 256; }
+#endif
+        NM_HIP_CHECK(hipFuncSetAttribute((const void*)b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         MlpArgs a = args;
         a.wstream = static_cast<const char*>(m->d_stream_b3);
         const int64_t wg_iters = (a.n + 127) / 128;
@@ -198,7 +211,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
             const int64_t rounds = (wg_iters + grid - 1) / grid;
             grid = (wg_iters + rounds - 1) / rounds;
         }
-        hipLaunchKernelGGL(b->kernel, dim3((unsigned)grid), dim3(512), lds_bytes, stream, a, L, density_only);
+        hipLaunchKernelGGL(b3_kernel, dim3((unsigned)grid), dim3(b3_threads), lds_bytes, stream, a, L, density_only);
         NM_HIP_CHECK(hipGetLastError());
         return 0;
     }
