@@ -862,11 +862,15 @@ static const unsigned char* equal_keys_table() {
 // one overflow flag per device (allocated on the device the call runs on)
 static int* overflow_flag() {
     static int* flags[64] = {};
+    static std::mutex lock;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(lock);
     if (!flags[dev]) {
-        if (hipMalloc(&flags[dev], sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(flags[dev], 0, sizeof(int)) != hipSuccess) return nullptr;
+        int* f = nullptr;
+        if (hipMalloc(&f, sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(f, 0, sizeof(int)) != hipSuccess) { (void)hipFree(f); return nullptr; }
+        flags[dev] = f;
     }
     return flags[dev];
 }

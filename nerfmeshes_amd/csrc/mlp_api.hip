@@ -549,6 +549,16 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     m->precision = precision;
     int prev_device = -1;
     (void)hipGetDevice(&prev_device);
+    // every early return below (a failed hip call) gives back the half-built handle and the staging buffer and leaves the
+    // caller's device current
+    struct Rollback {
+        nm_mlp* m; float* d_flat; int prev, dev; bool keep;
+        ~Rollback() {
+            if (d_flat) (void)hipFree(d_flat);
+            if (!keep) nm_mlp_destroy(m);
+            if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+        }
+    } rollback{m, nullptr, prev_device, device, false};
     NM_HIP_CHECK(hipSetDevice(device));
     hipDeviceProp_t prop;
     NM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -609,8 +619,8 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         stage(T_RGBW, w->fc_rgb_w, (size_t)3 * (H / 2));
     }
     stage(T_RGBB, w->fc_rgb_b, 3);
-    float* d_flat = nullptr;
-    NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_flat), flat.size() * 4));
+    NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&rollback.d_flat), flat.size() * 4));
+    float* const d_flat = rollback.d_flat;
     NM_HIP_CHECK(hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     WeightPtrs ptrs;
     std::memset(&ptrs, 0, sizeof(ptrs));
@@ -619,9 +629,8 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     for (int t = T_FEATW; t < T_COUNT; ++t) ptrs.p[t] = d_flat + offs[t];
     int rc = launch_gather(m, ptrs, nullptr);
     if (rc == 0 && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("parameter gather failed"); rc = 1; }
-    (void)hipFree(d_flat);
-    if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);   // leave the caller's device current
-    if (rc) { nm_mlp_destroy(m); return rc; }
+    if (rc) return rc;
+    rollback.keep = true;
     *out = m;
     return 0;
 }
