@@ -30,11 +30,12 @@ struct NextChunks {          // the first two chunks of whatever stage runs next
 // STAG: 0 every wave issues its DMA pieces at block 0 of a chunk | 1 waves 0..NW/2-1 at block 0, the others half a chunk
 // later.  ABL (timing-only ablations, ablation library): 1 barriers do not wait for the DMA | 2 no DMA | 4 one lane per
 // DMA instruction | 8 round-1 DMA form (global_load_lds with per-lane address VGPRs).
-template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, int STAG, int ABL = 0>
+// STORE (training): b1 is written to `store_row` a few tiles per chunk while the stage consumes it (see gemm_stage).
+template <int NT, int KS1, int KS2, int NW, int LDSBUF, int KCH, int STAG, int ABL = 0, bool STORE = false>
 __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[KS1],
                                             const float (&b2)[(KS2 > 0 ? KS2 : 1)], const char* gw,
                                             const NextChunks nx, char* lds, int& slot, f32x4 (&carry)[2],
-                                            int wave, int lane) {
+                                            int wave, int lane, float* store_row = nullptr) {
     constexpr int KS = KS1 + KS2;
     constexpr int NCH = (KS + KCH - 1) / KCH;
     constexpr int NB = NT / 4;
@@ -60,6 +61,19 @@ __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[
         char* dst = lds + slot2 * LDSBUF;
         const char* buf = lds + slot * LDSBUF + lane * 16;
         const char* nbuf = lds + slot1 * LDSBUF + lane * 16;
+        if constexpr (STORE) {
+            constexpr int TILES = KS1 / 4, PER_CHUNK = (TILES + NCH - 1) / NCH;
+            if (store_row) {
+#pragma unroll
+                for (int q = 0; q < PER_CHUNK; ++q) {
+                    const int nt = c * PER_CHUNK + q;
+                    if (nt < TILES) {
+                        const f32x4 v4 = {b1[4 * nt], b1[4 * nt + 1], b1[4 * nt + 2], b1[4 * nt + 3]};
+                        *reinterpret_cast<f32x4*>(store_row + 16 * nt) = v4;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < nblk; ++j) {
             auto dma = [&]() {
@@ -99,7 +113,11 @@ __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[
     carry[1] = ab[(TOTAL + 1) % 3];
 }
 
-template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0, bool FLAT = false>   // FLAT: see mlp_kernel
+// TAPE (EXPERIMENT, instantiated in the ablation library only -- nerf_train.hip, NM_MLP_VARIANT=3): the taping forward on this
+// dataflow, writing the same tape as mlp_kernel<..., TAPE> (activation rows while the next stage consumes them, ReLU bit masks
+// per tile), the same bits.  Measured 4.7 % SLOWER than the 2-slot taping kernel (3.54 vs 3.38 ms per 393 216 samples of the
+// 8x256 network, profiles/r04_train_three_slot.json): the training kernels stay on mlp_device.h's dataflow.
+template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0, bool FLAT = false, bool TAPE = false>   // FLAT: see mlp_kernel
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, const int num_layers,
                                                           const int density_only) {
     using N = Net<H, FX, FD, KCH>;
@@ -159,6 +177,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
                                                               slot, carry, wave, lane);
         gw += N::EX * N::STEP;
         acc_to_operand<N::NT, false>(acc, in);
+        const int64_t tile = it * NW + wave;
+        float* tape_row = (TAPE && valid) ? args.tape_h + sample * H + 4 * g : nullptr;
 
         // ---- layers_xyz[0 .. L-2], then (full evaluation only) fc_feat as iteration L-1 (models.py:63-70)
         float sigma = 0.0f;
@@ -176,7 +196,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
                 if (skip) nx = enc_next(after, true);
                 else if (is_feat) nx = dir_next(after);
                 else if (last_density) nx = wrap;
-                gemm_stage3<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, STAG, ABL>(acc, in, dummy, gw, nx, lds, slot, carry, wave, lane);
+                gemm_stage3<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, STAG, ABL, TAPE>(acc, in, dummy, gw, nx, lds, slot, carry, wave, lane,
+                                                                                 tape_row ? tape_row + (int64_t)i * args.n * H : nullptr);
                 gw = after;
             }
             if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)
@@ -186,12 +207,18 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
                 gw = after;
             }
             acc_to_operand<N::NT, true>(acc, in);
+            if constexpr (TAPE) {
+                if (tile < args.tiles) args.mask_h[((int64_t)i * args.tiles + tile) * 64 + lane] = positive_mask(in);
+            }
         }
 
         if (density_only) {
             sigma = alpha_gemv<H>(in, lds_walpha, g) + tail_bias[0];
-            if (FLAT && density_only == 2) flat_head<H>(args, in, lds_wrgb, tail_bias, sigma, sample, valid, g);   // use_viewdirs = 0
-            else if (valid && g == 0) args.out[sample] = sigma;
+            if (FLAT && density_only == 2) {   // use_viewdirs = 0
+                flat_head<H>(args, in, lds_wrgb, tail_bias, sigma, sample, valid, g);
+                // TAPE: the trunk's last activation has no stage behind it that would write it while consuming it
+                if constexpr (TAPE) store_rows<N::NT>(args.tape_h + (int64_t)(num_layers - 1) * args.n * H, H, sample, valid, in, g);
+            } else if (valid && g == 0) args.out[sample] = sigma;
             continue;
         }
 
@@ -201,8 +228,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, co
         load_bias<N::NTD>(accd, lds_bias + H * (1 + num_layers), g);
         float encd[N::ED];
         encode<FD, N::ED, 0>(encd, d, args.bands_dir, g);
-        gemm_stage3<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, STAG, ABL>(accd, in, encd, gw, wrap, lds, slot, carry, wave, lane);
+        gemm_stage3<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, STAG, ABL, TAPE>(accd, in, encd, gw, wrap, lds, slot, carry, wave, lane,
+                                                                             (TAPE && valid) ? args.tape_feat + sample * H + 4 * g : nullptr);
         acc_to_operand<N::NTD, true>(accd, v);
+        if constexpr (TAPE) {
+            store_rows<N::NTD>(args.tape_v, H / 2, sample, valid, v, g);
+            if (tile < args.tiles) args.mask_v[tile * 64 + lane] = positive_mask(v);
+        }
 
         // ---- fc_rgb + sigmoid (models.py:75), 3-row GEMV on the VALU
         float rgb[3];

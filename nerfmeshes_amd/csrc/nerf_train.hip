@@ -13,6 +13,10 @@
 // Roofline: MFMA.  557 056 MAC / sample for the 8x256 net (vs 593 408 forward).
 #include "nm_internal.h"
 #include "mlp_device.h"
+#ifdef NM_ABLATIONS
+#include <cstdlib>
+#include "mlp_device_r3.h"
+#endif
 #include "mlp_device_g.h"
 
 namespace nm {
@@ -228,18 +232,31 @@ __global__ __launch_bounds__(256) void encode_samples64_kernel(const EncodeArgs 
 // ---- plan tables -------------------------------------------------------------------------------------------
 struct TrainPlan {
     int H, FX, FD;
+    int ring_slots;                                                // LDS ring: 3 (mlp_kernel3 dataflow) or 2
     void (*forward)(const MlpArgs, const int, const int);
     void (*forward_flat)(const MlpArgs, const int, const int);     // the taping kernel that also serves use_viewdirs = 0 networks
 };
 template <int H, int FX, int FD>
 static TrainPlan make_train_plan() {
-    return TrainPlan{H, FX, FD, &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true>,
+    return TrainPlan{H, FX, FD, 2, &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true>,
                      &mlp_kernel<H, FX, FD, 8, KC, true, true, true, false, 0, true, true>};
 }
 static const TrainPlan g_train_plans[] = {
     make_train_plan<256, 10, 4>(), make_train_plan<128, 10, 4>(), make_train_plan<64, 10, 4>(),
     make_train_plan<256, 6, 4>(),  make_train_plan<128, 6, 4>(),  make_train_plan<64, 6, 4>(),
 };
+#ifdef NM_ABLATIONS
+// experiment (ablation library, NM_MLP_VARIANT=3): the 256- and 128-wide networks tape on the inference kernel's dataflow
+// (3-slot ring, operand stream across chunk and stage boundaries, staggered DMA: mlp_device_r3.h) -- same tape, same bits,
+// measured slower (see mlp_kernel3)
+template <int H, int FX, int FD>
+static TrainPlan make_train_plan3() {
+    return TrainPlan{H, FX, FD, 3, &mlp_kernel3<H, FX, FD, 8, KC, 1, 0, false, true>, &mlp_kernel3<H, FX, FD, 8, KC, 1, 0, true, true>};
+}
+static const TrainPlan g_train_plans3[] = {
+    make_train_plan3<256, 10, 4>(), make_train_plan3<128, 10, 4>(), make_train_plan3<256, 6, 4>(), make_train_plan3<128, 6, 4>(),
+};
+#endif
 
 struct BwdPlan {
     int H;
@@ -305,6 +322,12 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     for (const TrainPlan& p : g_train_plans)
         if (p.H == d.hidden_size && p.FX == d.num_encoding_fn_xyz && p.FD == (flat ? 4 : d.num_encoding_fn_dir)) plan = &p;
     NM_REQUIRE(plan, "no training kernel instantiated for this network shape");
+#ifdef NM_ABLATIONS
+    if (const char* v = getenv("NM_MLP_VARIANT"))
+        if (atoi(v) == 3)
+            for (const TrainPlan& p : g_train_plans3)
+                if (p.H == plan->H && p.FX == plan->FX && p.FD == plan->FD) { plan = &p; break; }
+#endif
     MlpArgs a = m->base;
     a.mode = MODE_RAYS;
     a.a = d_origins; a.b = d_dirs; a.c = d_t;
@@ -315,7 +338,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
     a.tiles = (a.n + 15) / 16;
     const int H = d.hidden_size, L = d.num_layers;
-    const int ring = 2 * KC * (H / 16) * 256;
+    const int ring = plan->ring_slots * KC * (H / 16) * 256;
     const int lds_bytes = ring + (((H * (1 + L) + H / 2 + 4 + H + (flat ? 3 * H : 3 * H / 2)) * 4 + 255) & ~255);
     const auto kernel = flat ? plan->forward_flat : plan->forward;
     if (int rc = set_lds((const void*)kernel, lds_bytes)) return rc;
