@@ -17,8 +17,12 @@
 // The values are the tuned kernels': the same sincosf on the same products, fp32 MFMA chains over the same column order
 // (the padded k-steps add exact zeros at the end of a chain), so on a menu shape this kernel reproduces the tuned one bit
 // for bit (tests/test_gpu_generic.py).  Dataflow = round 1's (2-slot ring, one barrier per chunk, scalar-addressed DMA) with
-// round 2's block-granular operand prefetch inside a chunk; wide classes (NT > 16: 2 * 4 * NT activation + accumulator
-// registers per lane exceed 256) run 4-wave workgroups, one wave per SIMD, on the 512-register budget.
+// round 2's block-granular operand prefetch inside a chunk.  Classes up to 24 tiles (hidden_size <= 384) run 8-wave
+// workgroups, two waves per SIMD, like the tuned kernels: 2 * 4 * NT activation + accumulator registers leave room in 256
+// up to NT = 20; classes 21 -- 24 re-encode the position at the skip layer instead of holding it and still spill a few dozen
+// registers at the stage boundaries, outside the k-step loops -- measured 0.89 -- 0.91 of the peak against 0.80 with one wave per SIMD (the partner
+// wave hides a wave's LDS and barrier latency; round 4, profiles/r04_mlp_shapes.json).  Beyond 24 tiles the two arrays alone
+// exceed 256: 4-wave workgroups, one wave per SIMD, on the 512-register budget.
 #pragma once
 #include "mlp_device.h"
 
@@ -197,15 +201,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const M
         const int64_t sidx = valid ? sample : args.n - 1;
         const SamplePD smp = fetch_sample(args, sidx);
         const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
-        float encx[G_ENC_STEPS];
-        encode_g(encx, p, lds_tab, args.g_nsx, args.g_idx, g);
+        // classes 21 -- 24 at two waves per SIMD have no 24 registers to hold the encoding across the trunk: the skip layer
+        // computes it again (the same values; `opaque` keeps the compiler from hoisting the second evaluation back up here)
+        constexpr bool KEEP_ENC = !(NW == 8 && NT > 20);
+        auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+        float encx[KEEP_ENC ? G_ENC_STEPS : 1];
 
         f32x4 acc[NT];
         float in[KH];
         const char* gw = args.wstream;
         // ---- layer1: xyz_enc -> H, no activation (models.py:62)
         load_bias<NT>(acc, lds_bias, g);
-        gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
+        if constexpr (KEEP_ENC) {
+            encode_g(encx, p, lds_tab, args.g_nsx, args.g_idx, g);
+            gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
+        } else {
+            float e[G_ENC_STEPS];
+            encode_g(e, p, lds_tab, args.g_nsx, args.g_idx, opaque(g));
+            gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, e, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
+        }
         gw += enc_x_bytes;
         acc_to_operand<NT, false>(acc, in);
         if constexpr (TAPE) store_rows_g<NT>(args.tape_h, args.g_h, sample, valid, in, g);
@@ -235,7 +249,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const M
                 const char* tsrc = after;
                 int tbytes = FIRST_H;
                 if (last_density) { tsrc = args.wstream; tbytes = wrap_bytes; }
-                gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                if constexpr (KEEP_ENC) {
+                    gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                } else {
+                    float e[G_ENC_STEPS];
+                    encode_g(e, p, lds_tab, args.g_nsx, args.g_idx, opaque(g));
+                    gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, e, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                }
                 gw = after;
             }
             acc_to_operand<NT, true>(acc, in);

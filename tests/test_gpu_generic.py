@@ -44,10 +44,10 @@ OFF_MENU = [
     dict(hidden_size=192, num_layers=6, skip_step=3, include_input_xyz=False),
     dict(hidden_size=256, include_input_dir=False, include_input_xyz=False),                          # no inputs in the encodings (a tuned plan serves it: zero weights on its identity step)
     dict(hidden_size=256, num_encoding_fn_xyz=15, num_encoding_fn_dir=15),                            # the longest encodings: 24 k-steps each
-    dict(hidden_size=272, num_layers=4),                                                              # 17 tiles -> class 20 (4 waves, 512 registers)
+    dict(hidden_size=272, num_layers=4),                                                              # 17 tiles -> class 18
     dict(hidden_size=320, num_layers=5, num_encoding_fn_xyz=6),
-    dict(hidden_size=384, num_layers=4, num_encoding_fn_dir=0),                                       # direction = the raw vector only
-    dict(hidden_size=448, num_layers=3, num_encoding_fn_xyz=0),                                       # xyz = the raw point only
+    dict(hidden_size=384, num_layers=4, num_encoding_fn_dir=0),                                       # direction = the raw vector only; class 24: two waves per SIMD, the skip layer re-encodes
+    dict(hidden_size=448, num_layers=3, num_encoding_fn_xyz=0),                                       # xyz = the raw point only; a 4-wave class (512 registers)
     dict(hidden_size=128, num_encoding_fn_dir=0, include_input_dir=False),                            # no direction columns at all
     dict(hidden_size=64, num_layers=2, num_encoding_fn_xyz=3, log_sampling_xyz=False, log_sampling_dir=False),
     dict(hidden_size=16, num_layers=2, num_encoding_fn_xyz=2, num_encoding_fn_dir=1),                 # one tile
@@ -143,7 +143,9 @@ def test_generic_family_reproduces_the_tuned_kernels_bit_for_bit(ops, kw):
 TRAIN_SHAPES = [
     dict(num_layers=4, hidden_size=100, skip_step=2, num_encoding_fn_xyz=7, num_encoding_fn_dir=1),      # 50-wide view rows: element-wise tape accesses
     dict(num_layers=3, hidden_size=48, num_encoding_fn_xyz=5, num_encoding_fn_dir=3),
-    dict(num_layers=4, hidden_size=320, num_encoding_fn_xyz=6),                                           # a 4-wave class (512 registers)
+    dict(num_layers=4, hidden_size=320, num_encoding_fn_xyz=6),                                           # class 20: the widest that holds the encoding in registers at two waves per SIMD
+    dict(num_layers=5, hidden_size=384, skip_step=2, num_encoding_fn_xyz=6),                              # class 24: re-encoding skip layers, spilled registers outside the k-step loops
+    dict(num_layers=3, hidden_size=448, num_encoding_fn_xyz=4),                                           # a 4-wave class (512 registers)
     dict(num_layers=5, hidden_size=80, skip_step=2, include_input_xyz=False, include_input_dir=False),
     dict(num_layers=8, hidden_size=256, num_encoding_fn_xyz=8),                                           # menu width: the hand-written dW kernels take the rows
     dict(num_layers=4, hidden_size=144, num_encoding_fn_xyz=9, use_viewdirs=False),
