@@ -320,7 +320,9 @@ __device__ __forceinline__ SamplePD fetch_sample(const MlpArgs& args, int64_t si
 // FLAT: the instantiation that also serves use_viewdirs = 0 networks (`density_only` == 2, see flat_head); a separate
 // instantiation so that the production kernels compile exactly as they did without it
 template <int H, int FX, int FD, int NW, int KCH, bool PIPE, bool KEEP_ENC, bool LBIAS, bool SPREAD, int ABL, bool TAPE, bool FLAT = false>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_kernel(const MlpArgs args, const int num_layers,
+// (occupancy: see mlp_kernel3 -- inference instances up to 128 wide are compiled for four waves per SIMD; the taping ones, whose
+// extra registers would all be spilled for it, measured no gain and stay at two)
+__global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kernel(const MlpArgs args, const int num_layers,
                                                       const int density_only) {
     using N = Net<H, FX, FD, KCH>;
     extern __shared__ __attribute__((aligned(16))) char lds[];

@@ -159,8 +159,12 @@ __device__ __forceinline__ void load_rows_g(const float* base, int width, int64_
 // TAPE (nm_mlp_forward_train on a generic-shape handle): the post-activations leave the registers once, as those rows
 // (tape_h[0] = layer1's output, tape_h[1 + i] = relu(layers_xyz[i]), tape_feat, tape_v); no ReLU masks are written --
 // the generic backward kernel reads the signs off the tape.  The radiance is the inference kernel's bit for bit.
+// Occupancy: classes up to 10 tiles (hidden_size <= 160) are compiled for four waves per SIMD (128 registers; classes 6 -- 10
+// spill 3 -- 88 registers for it, outside the k-step loops): +5 -- +6.5 points at 96 and 144 wide, +4.6 on the 8x128 shape, +1.2
+// at 160; wider classes lose more to spills than the two extra waves hide.  The training kernels of these classes measured
+// within +-3 % either way and simply share the bound.
 template <int NT, int NW, int KCH, bool TAPE = false>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_kernel_g(const MlpArgs args, const int num_layers,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp_kernel_g(const MlpArgs args, const int num_layers,
                                                                        const int density_only) {
     constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
     constexpr int KH = 4 * NT, KD = 4 * NTD;
@@ -338,7 +342,7 @@ __device__ __forceinline__ void relu_gate(const f32x4 (&acc)[NT], const float* b
 }
 
 template <int NT, int NW, int KCH>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mlp_backward_kernel_g(const MlpBwdArgs args, const int num_layers,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp_backward_kernel_g(const MlpBwdArgs args, const int num_layers,
                                                                                 const int flat) {
     constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
     constexpr int KH = 4 * NT, KD = 4 * NTD;

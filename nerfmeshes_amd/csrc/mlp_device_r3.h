@@ -118,7 +118,10 @@ __device__ __forceinline__ void gemm_stage3(f32x4 (&acc)[NT], const float (&b1)[
 // per tile), the same bits.  Measured 4.7 % SLOWER than the 2-slot taping kernel (3.54 vs 3.38 ms per 393 216 samples of the
 // 8x256 network, profiles/r04_train_three_slot.json): the training kernels stay on mlp_device.h's dataflow.
 template <int H, int FX, int FD, int NW, int KCH, int STAG, int ABL = 0, bool FLAT = false, bool TAPE = false>   // FLAT: see mlp_kernel
-__global__ __launch_bounds__(NW * 64, 2) void mlp_kernel3(const MlpArgs args, const int num_layers,
+// Occupancy: networks up to 128 wide are compiled for FOUR waves per SIMD (128 registers: two 8-wave workgroups per CU; the
+// 128-wide instances spill 9 -- 17 registers outside the k-step loops for it).  With VALU issue time adding to matrix time on
+// narrow networks two more waves per SIMD are worth +2.7 points at 8x128 (0.875 -> 0.902, same bits).
+__global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kernel3(const MlpArgs args, const int num_layers,
                                                           const int density_only) {
     using N = Net<H, FX, FD, KCH>;
     static_assert(N::EX > KCH && N::KH >= 2 * KCH, "stages must span two chunks");

@@ -32,7 +32,7 @@ __device__ __forceinline__ void masked_operand(const f32x4 (&acc)[NT], uint64_t 
 // FLAT: a network without view directions (models.py:77-79: the trunk ends in fc_out, 4 rows): no layers_dir / fc_feat stages;
 // the delta at the trunk's output is fc_out^T applied to the four head deltas on the VALU.
 template <int H, int NW, int KCH, bool FLAT = false>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_backward_kernel(const MlpBwdArgs args, const int num_layers) {
+__global__ __launch_bounds__(NW * 64, H <= 128 ? 4 : 2) void mlp_backward_kernel(const MlpBwdArgs args, const int num_layers) {
     using N = Net<H, 10, 4, KCH>;   // only the hidden-width constants are used here
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_walpha = reinterpret_cast<float*>(lds + 2 * N::LDSBUF);   // [4][H/4]
