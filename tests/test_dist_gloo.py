@@ -205,6 +205,36 @@ def test_all_gather_v_places_ragged_and_empty_shards_exactly(world):
 
 
 # ---- the Trainer stand-in under a launcher: identical replicas, distinct ray streams, one version dir ----
+def _assemble_job_7(rank, world):
+    return _assemble_job(rank, world, 7)
+
+
+def _assemble_job_3(rank, world):
+    return _assemble_job(rank, world, 3)
+
+
+def _assemble_job(rank, world, n0):
+    """What `mesh_nerf --gather triangles --use-cached-mesh` does for the mesh cache: every rank holds the planes of its slab
+    (ghost planes included) and the whole grid is assembled from the planes each rank accounts for."""
+    from nerfmeshes_amd import mesh_nerf
+    n1, n2 = 3, 5
+    full = torch.arange(n0 * n1 * n2, dtype=torch.float32).reshape(n0, n1, n2) * 0.5
+    lo, hi, below, above, p_lo, p_hi = nd.slab_layers(n0, rank, world)
+    slab = None if hi == lo else full[p_lo:p_hi].reshape(-1).clone()        # a rank without a cube layer holds no slab
+    return mesh_nerf._assemble_grid_from_slabs(slab, (n0, n1, n2), torch.device("cpu")).numpy()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world,job,n0", [(2, _assemble_job_7, 7), (3, _assemble_job_7, 7), (4, _assemble_job_3, 3)])
+def test_mesh_cache_grid_is_assembled_from_the_ranks_slabs(world, job, n0):
+    """mesh_nerf.py:139-144 under --gather triangles: the cached density grid equals the single-process grid on every rank --
+    ghost planes counted once, the top plane by the last rank that has a cube layer, ranks without a layer (4 ranks, 2 layers)
+    contributing nothing but entering the collective."""
+    want = (np.arange(n0 * 3 * 5, dtype=np.float32).reshape(n0, 3, 5) * 0.5)
+    for got in _run(job, world=world):
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def _fit_worker(rank, world, port, tmp, deterministic, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     from nerfmeshes_amd import lightning_compat as LC
