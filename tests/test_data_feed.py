@@ -137,3 +137,34 @@ def test_reads_a_cache_written_by_the_reference(tmp_path):
     # (a reference quirk preserved in the files: DataBundle.__getitem__ indexes EVERY tensor whose first dimension equals
     # the image count, so with exactly two images the (2,) ray_bounds is cut down to one scalar -- data_helpers.py:98-101)
     assert item["ray_bounds"].shape == () and np.array_equal(item["ray_bounds"].numpy(), rec["val.ray_bounds"])
+
+
+def test_tie_order_auto_falls_back_to_stable_beyond_the_reference_kernels_limit(monkeypatch):
+    """`tree.tie_order = "auto"` while training wants the reference's voxel-id order (nm_buff_intersect_ex, NM_TIES_REFERENCE),
+    whose kernel holds at most 8192 voxels: beyond that "auto" continues in the stable order and says so ONCE instead of
+    failing in the middle of a training run; an explicit "reference" is passed through (and would raise in the library)."""
+    import warnings
+    from nerfmeshes_amd import hip_ops
+    from nerfmeshes_amd.nerf.tree import TreeSampling
+    seen = []
+    monkeypatch.setattr(hip_ops, "buff_intersect", lambda voxels, o, d, near, far, n, ids: seen.append(ids) or "ok")
+    tree = TreeSampling.__new__(TreeSampling)          # no device work: only the order selection is under test
+    tree.config = CfgNode({"tree": {"use_random_sampling": False}})
+    tree.tie_order, tree.training = "auto", True
+    o, d = torch.zeros(1, 3), torch.ones(4, 3)
+    tree.voxels = torch.zeros(hip_ops.BUFF_REFERENCE_MAX_VOXELS, 2, 3)
+    assert tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8) == "ok" and seen == ["reference"]
+    tree.voxels = torch.zeros(hip_ops.BUFF_REFERENCE_MAX_VOXELS + 1, 2, 3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
+        tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
+    assert seen[1:] == ["stable", "stable"] and tree.tie_order == "stable"
+    assert len([x for x in w if "tie_order" in str(x.message)]) == 1, "said once"
+    tree.training = False
+    tree.tie_order = "auto"
+    tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
+    assert seen[-1] == "stable"                        # evaluation: the geometrically consistent order, whatever the size
+    tree.tie_order = "reference"
+    tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
+    assert seen[-1] == "reference"                     # explicit request: not second-guessed
