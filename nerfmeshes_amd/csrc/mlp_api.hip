@@ -409,6 +409,7 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     NM_REQUIRE(d.num_layers >= 2 && d.num_layers <= 32, "num_layers out of range");
     NM_REQUIRE(d.skip_step >= 1, "skip_step must be >= 1");
     NM_REQUIRE(d.hidden_size >= 1 && d.num_encoding_fn_xyz >= 0 && d.num_encoding_fn_dir >= 0, "negative network dimension");
+    NM_REQUIRE(no_view || d.hidden_size >= 2, "hidden_size = 1 with view directions: layers_dir[0] would have hidden_size // 2 = 0 rows");
     NM_REQUIRE(d.num_encoding_fn_xyz > 0 || d.include_input_xyz,
                "the xyz encoding is empty (num_encoding_fn_xyz = 0 without include_input_xyz): layer1 would have no input");
     // every tensor the packer will read, checked before anything dereferences one

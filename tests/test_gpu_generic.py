@@ -51,6 +51,8 @@ OFF_MENU = [
     dict(hidden_size=128, num_encoding_fn_dir=0, include_input_dir=False),                            # no direction columns at all
     dict(hidden_size=64, num_layers=2, num_encoding_fn_xyz=3, log_sampling_xyz=False, log_sampling_dir=False),
     dict(hidden_size=16, num_layers=2, num_encoding_fn_xyz=2, num_encoding_fn_dir=1),                 # one tile
+    dict(hidden_size=2, num_layers=2, num_encoding_fn_xyz=1, num_encoding_fn_dir=1),                  # the narrowest network with a view layer (1 row)
+    dict(hidden_size=5, num_layers=3, num_encoding_fn_xyz=2),                                         # 5 of 16 rows real; 2-row view layer
     dict(hidden_size=224, num_layers=10, skip_step=1),                                                # a skip at every layer
     dict(hidden_size=144, use_viewdirs=False, num_encoding_fn_xyz=9),
     dict(hidden_size=400, num_layers=4, use_viewdirs=False),
@@ -242,7 +244,7 @@ def test_render_and_module_surface_on_an_off_menu_shape(ops):
 
 def test_limits_of_the_family_are_errors_with_a_reason(ops):
     from nerfmeshes_amd import _lib
-    for kw, why in ((dict(hidden_size=528, num_layers=2), "512"), (dict(num_encoding_fn_xyz=16), "k-steps"),
+    for kw, why in ((dict(hidden_size=528, num_layers=2), "512"), (dict(hidden_size=1, num_layers=2), "0 rows"), (dict(num_encoding_fn_xyz=16), "k-steps"),
                     (dict(num_encoding_fn_xyz=0, include_input_xyz=False), "empty")):
         spec, desc = _desc(kw)
         w = {f"{name}.{part}": np.zeros((n_out, n_in) if part == "weight" else (n_out,), dtype=np.float32)
