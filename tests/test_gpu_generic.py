@@ -145,6 +145,8 @@ def test_generic_family_reproduces_the_tuned_kernels_bit_for_bit(ops, kw):
 TRAIN_SHAPES = [
     dict(num_layers=4, hidden_size=100, skip_step=2, num_encoding_fn_xyz=7, num_encoding_fn_dir=1),      # 50-wide view rows: element-wise tape accesses
     dict(num_layers=3, hidden_size=48, num_encoding_fn_xyz=5, num_encoding_fn_dir=3),
+    dict(num_layers=3, hidden_size=5, num_encoding_fn_xyz=2, num_encoding_fn_dir=1),                      # 5 real rows of 16, 2-row view layer
+    dict(num_layers=2, hidden_size=2, num_encoding_fn_xyz=1, num_encoding_fn_dir=1),                      # the narrowest network with a view layer
     dict(num_layers=4, hidden_size=320, num_encoding_fn_xyz=6),                                           # class 20: the widest that holds the encoding in registers at two waves per SIMD
     dict(num_layers=5, hidden_size=384, skip_step=2, num_encoding_fn_xyz=6),                              # class 24: re-encoding skip layers, spilled registers outside the k-step loops
     dict(num_layers=3, hidden_size=448, num_encoding_fn_xyz=4),                                           # a 4-wave class (512 registers)
