@@ -32,7 +32,11 @@ extern "C" {
  * NM_KERNEL_GENERIC, training entry points for use_viewdirs = 0 and generic-shape handles (tape / delta fields those do not use
  * may be NULL), nm_mc_emit_slab accepts NULL outputs for an empty own share.  No signature changed; everything in version 2 is
  * unchanged. */
-#define NM_ABI_VERSION 3
+/* 4 (round 5): + nm_weight_grad_ex / nm_head_grad_ex (+ their workspace functions, nm_weight_grad_plan): weight gradients of
+ * every layer shape, row stride and sample count; nm_weight_grad / nm_head_grad forward to them (their shape and n % 16
+ * restrictions are gone), nm_encode_samples_strided writes whole rows for any stride.  No signature changed; everything in
+ * version 3 is unchanged. */
+#define NM_ABI_VERSION 4
 
 const char* nm_last_error(void);
 int nm_abi_version(void);
@@ -50,8 +54,8 @@ typedef struct nm_mlp_desc {
     int32_t num_encoding_fn_dir;  /* models.py:11  */
     int32_t include_input_xyz;    /* models.py:12  */
     int32_t include_input_dir;    /* models.py:13  */
-    int32_t use_viewdirs;         /* models.py:16 -- 1: all shipped configs.  0 (models.py:77-79, trunk -> fc_out): inference entry
-                                   * points only, fp32; the training entry points refuse such a handle */
+    int32_t use_viewdirs;         /* models.py:16 -- 1: all shipped configs.  0 (models.py:77-79, trunk -> fc_out): fp32, inference
+                                   * and training (the tape is the trunk's; see nm_mlp_tape) */
 } nm_mlp_desc;
 
 /* Host pointers to the tensors of FlexibleNeRFModel.state_dict(), torch.nn.Linear layout
@@ -77,8 +81,8 @@ typedef struct nm_mlp nm_mlp;
  * 64 / 128 / 256, 6 or 10 xyz and 4 direction functions) by kernels tuned for exactly them, every other one -- any hidden_size
  * up to 512, 0..15 encoding functions per input (16 without the input itself), include_input_* on or off -- by the
  * generic-shape kernel family (padded to the next width class; nm_mlp_kernel_variant reports 1000 + class).  Only a
- * hidden_size above 512 or an encoding beyond those limits fails, with a message.  Training entry points and
- * NM_PREC_BF16X3 exist for the tuned shapes only. */
+ * hidden_size above 512 or an encoding beyond those limits fails, with a message.  Every handle trains (generic-shape
+ * handles through the tape-row path: masks may be NULL, nm_mlp_tape); NM_PREC_BF16X3 exists for 256-wide tuned shapes only. */
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
 
 /* Arithmetic of the GEMMs.  NM_PREC_F32 (default, what nm_mlp_create builds): fp32 MFMA, the reference's fp32 arithmetic
@@ -265,8 +269,9 @@ int nm_encode_samples(nm_mlp* mlp, const float* d_origins, int origins_per_ray, 
                       const float* d_t, int64_t rays, int32_t samples, float* d_enc_xyz, float* d_enc_dir,
                       void* stream);
 
-/* The same with explicit row strides (floats per row >= encoding width).  With both strides 64 (the layout
- * nm_weight_grad consumes) whole rows are written, zero padding included; otherwise the rest of a row is not touched. */
+/* The same with explicit row strides (floats per row >= encoding width): whole rows are written, zero padding up to the
+ * stride included (64-float rows are what the tuned nm_weight_grad kernel streams; any stride serves nm_weight_grad_ex, a
+ * multiple of 4 floats gives it 16-byte DMA pieces).  d_enc_dir must be NULL for use_viewdirs = 0 handles. */
 int nm_encode_samples_strided(nm_mlp* mlp, const float* d_origins, int origins_per_ray, const float* d_dirs,
                               const float* d_t, int64_t rays, int32_t samples, float* d_enc_xyz, int32_t stride_xyz,
                               float* d_enc_dir, int32_t stride_dir, void* stream);
@@ -290,6 +295,26 @@ int nm_weight_grad(int num_cus, const float* d_delta, int32_t out_features, cons
 int64_t nm_head_grad_workspace_bytes(int32_t in_features);
 int nm_head_grad(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace,
                  float* d_dw, float* d_dbias, void* stream);
+
+/* The general forms (ABI v4): ANY out_features / in_features (what FlexibleNeRFModel's constructor accepts,
+ * src/nerf/models.py:5-58), ANY row strides (floats; >= the feature counts), ANY n >= 1 -- no padding of rows or columns is
+ * required or written: columns beyond a width only reach dW entries nobody reads, rows beyond n are read as zeros through
+ * the buffer descriptor's exact extent.  Same dataflow as nm_weight_grad (fp32 MFMA, operands DMA'd HBM -> LDS as they lie
+ * in memory, one workgroup per CU, order-fixed reduction: deterministic), its geometry -- tiles per wave, how the 8 waves of
+ * a workgroup split the output block and the samples, how many blocks a wide output is cut into -- picked from the shape
+ * alone by a planner (nm_weight_grad_plan reports it: [nba, nbb, wa, wb, wk, ta, tb, rows per chunk]).  nm_weight_grad and
+ * nm_head_grad forward here for every shape / sample count their tuned kernels do not serve, so no weight gradient of any
+ * network the library accepts is a library GEMM. */
+int64_t nm_weight_grad_workspace_bytes_ex(int32_t out_features, int32_t delta_stride, int32_t in_features, int32_t act_stride,
+                                          int32_t num_cus);
+int nm_weight_grad_ex(int num_cus, const float* d_delta, int32_t out_features, int32_t delta_stride, const float* d_act,
+                      int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace, float* d_dw, int32_t dw_ld,
+                      int32_t dw_col0, float* d_dbias, void* stream);
+int nm_weight_grad_plan(int32_t out_features, int32_t delta_stride, int32_t in_features, int32_t act_stride,
+                        int32_t aligned16, int32_t num_cus, int32_t* plan8);
+int64_t nm_head_grad_workspace_bytes_ex(int32_t in_features);
+int nm_head_grad_ex(const float* d_dlast, const float* d_act, int32_t in_features, int32_t act_stride, int64_t n,
+                    void* d_workspace, float* d_dw, float* d_dbias, void* stream);
 
 /* RaySampleInterval.forward's stratified jitter (src/nerf/modules.py:171-184): d_rand (rays,samples) in [0,1). */
 int nm_perturb_intervals(const float* d_t, const float* d_rand, int64_t rays, int32_t samples, float* d_t_out,

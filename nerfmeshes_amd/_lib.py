@@ -107,6 +107,12 @@ SIGNATURES = {
     "nm_weight_grad_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "nm_weight_grad": (C.c_int, [C.c_int, c_void_p, C.c_int32, c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_p, c_void_p,
                                  C.c_int32, C.c_int32, c_void_p, c_void_p]),
+    "nm_weight_grad_workspace_bytes_ex": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "nm_weight_grad_ex": (C.c_int, [C.c_int, c_void_p, C.c_int32, C.c_int32, c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_p,
+                                    c_void_p, C.c_int32, C.c_int32, c_void_p, c_void_p]),
+    "nm_weight_grad_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "nm_head_grad_workspace_bytes_ex": (C.c_int64, [C.c_int32]),
+    "nm_head_grad_ex": (C.c_int, [c_void_p, c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_head_grad_workspace_bytes": (C.c_int64, [C.c_int32]),
     "nm_head_grad": (C.c_int, [c_void_p, c_void_p, C.c_int32, C.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_perturb_intervals": (C.c_int, [c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p, c_void_p]),

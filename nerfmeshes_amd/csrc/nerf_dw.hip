@@ -314,28 +314,31 @@ static const DwPlan g_dw_plans[] = {
 
 using namespace nm;
 
-extern "C" int64_t nm_weight_grad_workspace_bytes(int32_t out_features, int32_t in_features, int32_t num_cus) {
-    if (out_features <= 0 || in_features <= 0 || num_cus <= 0) return 0;
-    const int64_t ab = (out_features + 63) / 64, bb = (in_features + 63) / 64;
-    return (int64_t)num_cus * 4 * (ab * 64 * bb * 64 + ab * 64) * 4;
+extern "C" int64_t nm_weight_grad_workspace_bytes(int32_t out_features, int32_t act_stride, int32_t num_cus) {
+    return nm_weight_grad_workspace_bytes_ex(out_features, out_features, act_stride, act_stride, num_cus);
 }
 
-// d_delta (n, out_features) and d_act (n, act_stride) row-major, n a multiple of 16, out_features and act_stride
-// multiples of 64 (act rows may carry zero padding beyond in_features).  Writes d_dw[o * dw_ld + dw_col0 + c] for
-// c < in_features and, when d_dbias != NULL, d_dbias[o] = sum_n delta[n][o].
-extern "C" int nm_weight_grad(int device_cus, const float* d_delta, int32_t out_features, const float* d_act,
-                              int32_t act_stride, int32_t in_features, int64_t n, void* d_workspace, float* d_dw,
-                              int32_t dw_ld, int32_t dw_col0, float* d_dbias, void* stream_) {
-    NM_REQUIRE(d_delta && d_act && d_workspace && d_dw && n > 0, "bad argument");
-    NM_REQUIRE(n % DW_ROWS == 0, "weight_grad: the row count must be a multiple of 16 (pad the tape with zero rows)");
-    NM_REQUIRE(out_features % 64 == 0 && act_stride % 64 == 0 && in_features >= 1 && in_features <= act_stride,
-               "weight_grad: feature counts must be multiples of 64 (pad the activation rows with zeros)");
+namespace nm {
+
+int64_t weight_grad_tuned_workspace_bytes(int32_t out_features, int32_t act_stride, int32_t num_cus) {
+    if (out_features % 64 || act_stride % 64) return 0;
+    for (const DwPlan& p : g_dw_plans)
+        if (p.ab == out_features / 64 && p.bb == act_stride / 64)
+            return (int64_t)num_cus * p.ksplit * ((int64_t)out_features * act_stride + out_features) * 4;
+    return 0;
+}
+
+// The kernel above for the shipped configs' six (out, stride) pairs, n a multiple of 16, delta rows of stride out_features.
+// Returns -1 when it does not serve the call (nm_weight_grad_ex then takes the general kernel, nerf_dw_g.hip).
+int weight_grad_tuned(int device_cus, const float* d_delta, int32_t out_features, const float* d_act, int32_t act_stride,
+                      int32_t in_features, int64_t n, void* d_workspace, float* d_dw, int32_t dw_ld, int32_t dw_col0,
+                      float* d_dbias, hipStream_t stream) {
+    if (n % DW_ROWS || out_features % 64 || act_stride % 64) return -1;
     const int ab = out_features / 64, bb = act_stride / 64;
     const DwPlan* plan = nullptr;
     for (const DwPlan& p : g_dw_plans)
         if (p.ab == ab && p.bb == bb) plan = &p;
-    NM_REQUIRE(plan, "weight_grad: no kernel instantiated for this (out, in) block shape");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!plan) return -1;
     const int64_t chunks = n / DW_ROWS;
     const int cus = device_cus > 0 ? device_cus : 256;
     const int grid = (int)(chunks < cus ? chunks : cus);
@@ -355,18 +358,25 @@ extern "C" int nm_weight_grad(int device_cus, const float* d_delta, int32_t out_
     return 0;
 }
 
-extern "C" int64_t nm_head_grad_workspace_bytes(int32_t in_features) {
-    return in_features > 0 ? (int64_t)HEAD_MAX_PARTS * 4 * (in_features + 1) * 4 : 0;
+}  // namespace nm
+
+// d_delta (n, out_features) and d_act (n, act_stride) row-major.  Writes d_dw[o * dw_ld + dw_col0 + c] for c < in_features
+// and, when d_dbias != NULL, d_dbias[o] = sum_n delta[n][o].  = nm_weight_grad_ex with delta rows of stride out_features.
+extern "C" int nm_weight_grad(int device_cus, const float* d_delta, int32_t out_features, const float* d_act,
+                              int32_t act_stride, int32_t in_features, int64_t n, void* d_workspace, float* d_dw,
+                              int32_t dw_ld, int32_t dw_col0, float* d_dbias, void* stream_) {
+    return nm_weight_grad_ex(device_cus, d_delta, out_features, out_features, d_act, in_features, act_stride, n, d_workspace,
+                             d_dw, dw_ld, dw_col0, d_dbias, stream_);
 }
 
-// d_dlast (n, 4) and d_act (n, in_features) row-major, in_features 64, 128 or 256.  Writes d_dw[r * in_features + k] =
-// sum_n dlast[n][r] * act[n][k] (4 rows) and, when d_dbias != NULL, d_dbias[r] = sum_n dlast[n][r].
-extern "C" int nm_head_grad(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace,
-                            float* d_dw, float* d_dbias, void* stream_) {
-    NM_REQUIRE(d_dlast && d_act && d_workspace && d_dw && n > 0, "bad argument");
-    NM_REQUIRE(in_features == 64 || in_features == 128 || in_features == 256,
-               "head_grad: no kernel instantiated for this activation width");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+extern "C" int64_t nm_head_grad_workspace_bytes(int32_t in_features) { return nm_head_grad_workspace_bytes_ex(in_features); }
+
+namespace nm {
+
+// head_grad_kernel<K> for contiguous 64- / 128- / 256-wide rows; -1 when it does not serve the call (-> nerf_dw_g.hip)
+int head_grad_tuned(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace, float* d_dw,
+                    float* d_dbias, hipStream_t stream) {
+    if (!(in_features == 64 || in_features == 128 || in_features == 256)) return -1;
     const int rpp = 256 / (in_features / 4);
     int64_t rows = (n + HEAD_MAX_PARTS - 1) / HEAD_MAX_PARTS;
     rows = (rows + 8 * rpp - 1) / (8 * rpp) * (8 * rpp);        // whole unrolled passes
@@ -384,4 +394,13 @@ extern "C" int nm_head_grad(const float* d_dlast, const float* d_act, int32_t in
                        elems, d_dw, d_dbias);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+}  // namespace nm
+
+// d_dlast (n, 4) and d_act (n, in_features) row-major.  Writes d_dw[r * in_features + k] = sum_n dlast[n][r] * act[n][k]
+// (4 rows) and, when d_dbias != NULL, d_dbias[r] = sum_n dlast[n][r].  = nm_head_grad_ex with rows of stride in_features.
+extern "C" int nm_head_grad(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace,
+                            float* d_dw, float* d_dbias, void* stream_) {
+    return nm_head_grad_ex(d_dlast, d_act, in_features, in_features, n, d_workspace, d_dw, d_dbias, stream_);
 }

@@ -166,44 +166,15 @@ struct EncodeArgs {
     int32_t stride_x, stride_d;   // floats per output row (>= the encoding width; the tail of a row is left untouched)
 };
 
-__device__ __forceinline__ void encode_row(float* row, const float (&x)[3], int F, int include, const float* bands) {
-    const int base = include ? 3 : 0;
-    if (include) { row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; }
-    for (int a = 0; a < 3 * F; ++a) {
-        float sv, cv;
-        sincosf(x[a / F] * bands[a % F], &sv, &cv);   // the same call, on the same product, as encode<>()
-        row[base + a] = sv;
-        row[base + 3 * F + a] = cv;
-    }
-}
-
-__global__ __launch_bounds__(256) void encode_samples_kernel(const EncodeArgs args) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= args.n) return;
-    const int64_t ray = i / args.samples;
-    const float t = args.t[i];
-    const float* o = args.origins + (args.origins_per_ray ? 3 * ray : 0);
-    float p[3], d[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        d[k] = args.dirs[3 * ray + k];
-        const float dt = d[k] * t;
-        p[k] = o[k] + dt;
-    }
-    const int dx = 6 * args.fx + (args.include_x ? 3 : 0), dd = 6 * args.fd + (args.include_d ? 3 : 0);
-    (void)dx; (void)dd;
-    if (args.enc_x) encode_row(args.enc_x + i * args.stride_x, p, args.fx, args.include_x, args.bands_xyz);
-    if (args.enc_d) encode_row(args.enc_d + i * args.stride_d, d, args.fd, args.include_d, args.bands_dir);
-}
-
-// The same rows for the weight-gradient kernel: 64-float zero-padded rows, ONE OUTPUT ELEMENT PER THREAD so that a
-// wavefront writes 256 contiguous bytes (the row-per-thread kernel above issues 4-byte stores 256 B apart: 0.63 ms for
-// 393 216 samples; this one is bandwidth-bound).  sincosf is evaluated on the same product as encode<>() / encode_row()
-// and one of its two results kept, so the values are bit-identical to the forward kernel's.
-__global__ __launch_bounds__(256) void encode_samples64_kernel(const EncodeArgs args) {
+// PositionalEncoding rows for the weight-gradient kernels: WHOLE rows of the given strides (zero padding included), ONE
+// OUTPUT ELEMENT PER THREAD so that a wavefront writes 256 contiguous bytes (a row-per-thread kernel issues 4-byte stores a
+// row apart: 0.63 ms for 393 216 samples; this one is bandwidth-bound).  sincosf is evaluated on the same product as
+// encode<>() and one of its two results kept, so the values are bit-identical to the forward kernel's.
+// Thread e serves column e % smax of sample e / smax in both encodings (smax = the larger stride; 64 for the tuned shapes).
+__global__ __launch_bounds__(256) void encode_samples_rows_kernel(const EncodeArgs args, const int smax) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = e >> 6;
-    const int j = (int)(e & 63);
+    const int64_t i = smax == 64 ? e >> 6 : e / smax;
+    const int j = (int)(e - i * smax);
     if (i >= args.n) return;
     const int64_t ray = i / args.samples;
     const float t = args.t[i];
@@ -219,14 +190,14 @@ __global__ __launch_bounds__(256) void encode_samples64_kernel(const EncodeArgs 
         const int base = include ? 3 : 0;
         if (j < base) return x[j];
         const int a = j - base;
-        if (a >= 6 * F) return 0.0f;                       // zero padding up to 64
+        if (a >= 6 * F) return 0.0f;                       // zero padding up to the stride
         const int arg = a < 3 * F ? a : a - 3 * F;
         float sv, cv;
         sincosf(x[arg / F] * bands[arg % F], &sv, &cv);
         return a < 3 * F ? sv : cv;
     };
-    if (args.enc_x) args.enc_x[i * 64 + j] = element(p, args.fx, args.include_x, args.bands_xyz);
-    if (args.enc_d) args.enc_d[i * 64 + j] = element(d, args.fd, args.include_d, args.bands_dir);
+    if (args.enc_x && j < args.stride_x) args.enc_x[i * args.stride_x + j] = element(p, args.fx, args.include_x, args.bands_xyz);
+    if (args.enc_d && j < args.stride_d) args.enc_d[i * args.stride_d + j] = element(d, args.fd, args.include_d, args.bands_dir);
 }
 
 // ---- plan tables -------------------------------------------------------------------------------------------
@@ -406,19 +377,19 @@ int nm_encode_samples_strided(nm_mlp* m, const float* d_origins, int origins_per
     a.include_x = m->desc.include_input_xyz; a.include_d = m->desc.include_input_dir;
     const int dx = 6 * a.fx + (a.include_x ? 3 : 0), dd = 6 * a.fd + (a.include_d ? 3 : 0);
     NM_REQUIRE((!d_enc_xyz || stride_xyz >= dx) && (!d_enc_dir || stride_dir >= dd), "encode_samples: row stride too small");
+    // a handle without view directions keeps no direction bands (nm_mlp_create only range-checks what the kernels use)
+    NM_REQUIRE(a.fx <= MAX_FREQ_XYZ && (!d_enc_dir || (a.fd <= MAX_FREQ_DIR && m->desc.use_viewdirs)),
+               "encode_samples: this handle has no such encoding (use_viewdirs = 0 handles encode positions only)");
     for (int f = 0; f < MAX_FREQ_XYZ; ++f) a.bands_xyz[f] = m->base.bands_xyz[f];
     for (int f = 0; f < MAX_FREQ_DIR; ++f) a.bands_dir[f] = m->base.bands_dir[f];
     a.enc_x = d_enc_xyz; a.enc_d = d_enc_dir;
     a.stride_x = stride_xyz; a.stride_d = stride_dir;
     if (a.n == 0) return 0;
-    if (stride_xyz == 64 && stride_dir == 64 && d_enc_xyz && d_enc_dir && dx <= 64 && dd <= 64) {
-        // the weight-gradient layout: whole 64-float rows written (padding included), one element per thread
-        hipLaunchKernelGGL(encode_samples64_kernel, dim3((unsigned)((a.n * 64 + 255) / 256)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), a);
-    } else {
-        hipLaunchKernelGGL(encode_samples_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), a);
-    }
+    // whole rows, one element per thread (zero padding up to the stride included)
+    const int smax = (d_enc_xyz ? stride_xyz : 0) > (d_enc_dir ? stride_dir : 0) ? stride_xyz : stride_dir;
+    if (smax <= 0) return 0;
+    hipLaunchKernelGGL(encode_samples_rows_kernel, dim3((unsigned)((a.n * smax + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a, smax);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }

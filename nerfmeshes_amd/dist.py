@@ -3,9 +3,10 @@ xGMI on the MI355X node, "gloo" in the CPU tests).
 
 The path is embarrassingly parallel: rays never interact, grid voxels never interact,
 weights (2.4 MB / network) are replicated.  So there is NO collective inside the data path; each rank renders
-a contiguous range of rays / axis-0 slab of the grid, and ONE all-gather at the end assembles the pixels or the
-density grid on every rank (marching cubes then runs on the full grid, which keeps the vertex numbering
-identical to the single-GPU result by construction).
+a contiguous range of rays / axis-0 slab of the grid, and ONE all-gather at the end assembles the pixels, or the
+emitted triangles of the per-slab marching cubes (`marching_cubes_sharded`: vertex ownership follows the global
+plane index, so the ranks' arrays concatenated in rank order ARE the single-GPU mesh, vertex numbering included),
+or -- `density_grid_sharded`, kept as the cross-check -- the density grid itself.
 """
 import torch
 

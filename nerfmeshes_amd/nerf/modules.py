@@ -1,8 +1,9 @@
 """Render primitives with the reference's class names and signatures
 (/root/reference/src/nerf/modules.py:8-248), dispatching to the gfx950 kernels through the C ABI.
 
-Every forward requires GPU tensors and `torch.no_grad()`-style use: there is no CPU or eager fallback
-(training-time noise / stratified jitter / random u are reference rows (f)-2 and raise)."""
+Every forward requires GPU tensors: there is no CPU or eager fallback.  In training mode (reference rows (f)-2) the
+stratified jitter, the density noise and the random `u` of the fine resampling are drawn from torch's generator and
+handed to the HIP kernels (`train_ops`), and the modules are differentiable through the hand-written backward."""
 from dataclasses import dataclass
 
 import torch

@@ -5,11 +5,11 @@ What `loss.backward()` does in the reference's `NeRFModel.training_step`
 
 * `mlp_rays`       -- FlexibleNeRFModel.forward over ray samples as a `torch.autograd.Function`:
                       forward = the fused HIP kernel recording a tape, backward = the HIP delta kernel +
-                      the hand-written weight-gradient kernels (dW = delta^T @ activation rows: nm_weight_grad for
-                      the 128- / 256-wide layers, nm_head_grad for fc_alpha / fc_rgb); 64-wide networks, sample
-                      counts that are not a multiple of 16 and the off-menu shapes of the generic kernel family take a
-                      library GEMM for these plain products (torch.bmm split-K, `_tn`).  Every shape nm_mlp_create
-                      accepts trains: tuned kernels for the shipped configs' shapes, the generic family otherwise.
+                      the hand-written weight-gradient kernels (dW = delta^T @ activation rows: nm_weight_grad_ex,
+                      nm_head_grad_ex for fc_alpha / fc_rgb / fc_out) -- the kernels tuned for the shipped configs'
+                      128- / 256-wide layers when they apply, the general ones (nerf_dw_g.hip: any width, any stride,
+                      any sample count) otherwise.  No library GEMM and no library reduction is left on any shape
+                      nm_mlp_create accepts: tuned kernels for the shipped configs' shapes, the generic family otherwise.
 * `composite`      -- VolumeRenderer.forward (noise + ReLU + alpha compositing) with a HIP backward.
 * `perturb_intervals`, `sample_pdf_rand` -- the stochastic depth samplers; random numbers are torch's.
 
@@ -110,61 +110,46 @@ def encode_samples(mlp, origins, dirs, t):
     return ex, ed
 
 
-def _tn(a, b):
-    """a^T @ b for tall operands (n,p), (n,q): the weight-gradient GEMM.  rocBLAS runs the (p x n) @ (n x q) shape
-    with p, q <= 320 and n ~ 4e5 on a handful of workgroups (56 TFLOP/s measured); an explicit split-K -- one
-    batched GEMM over row chunks, then a sum -- fills the chip (123 TFLOP/s)."""
-    n = a.shape[0]
-    chunks = min(128, n // 2048)
-    if chunks < 2 or not (a.is_contiguous() and b.is_contiguous()):
-        return a.t() @ b
-    m = (n // chunks) * chunks
-    out = torch.bmm(a[:m].view(chunks, -1, a.shape[1]).transpose(1, 2), b[:m].view(chunks, -1, b.shape[1])).sum(0)
-    if m < n:
-        out += a[m:].t() @ b[m:]
-    return out
-
-
-_DW_SHAPES = {(256, 256), (256, 64), (128, 256), (128, 128), (128, 64), (64, 128)}     # (out, padded in) of nm_weight_grad
 _dw_ws = {}
 
 
-def _weight_grad(mlp, delta, act, in_features, out=None, col0=0, bias=True):
-    """dW = delta^T @ act[:, :in_features] (+ column sums of delta) through nm_weight_grad: fp32 MFMA, split over the
-    samples across the CUs, order-fixed reduction.  delta (n, out) / act (n, stride) contiguous, n % 16 == 0."""
-    lib = _lib.load()
-    n, o = delta.shape
-    stride = act.shape[1]
-    cus = int(lib.nm_mlp_num_cus(mlp.handle))
-    need = int(lib.nm_weight_grad_workspace_bytes(o, stride, cus))
-    key = (mlp.device, torch.cuda.current_stream(mlp.device).cuda_stream)
+def _workspace(mlp, tag, need):
+    key = (mlp.device, torch.cuda.current_stream(mlp.device).cuda_stream, tag)
     ws = _dw_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=mlp.device)
+    return ws
+
+
+def _weight_grad(mlp, delta, act, in_features, out=None, col0=0, bias=True):
+    """dW = delta^T @ act[:, :in_features] (+ column sums of delta) through nm_weight_grad_ex: fp32 MFMA, split over the
+    samples across the CUs, order-fixed reduction.  delta (n, out) / act (n, stride >= in_features): row-major views of
+    ANY width, stride and row count -- the kernel tuned for the shipped configs' shapes when it applies, the general
+    one (nerf_dw_g.hip) otherwise; never a library GEMM."""
+    lib = _lib.load()
+    n, o = delta.shape
+    assert delta.stride(1) == 1 and act.stride(1) == 1 and act.shape[0] == n
+    lda, ldb = delta.stride(0), act.stride(0)
+    cus = int(lib.nm_mlp_num_cus(mlp.handle))
+    ws = _workspace(mlp, "dw", int(lib.nm_weight_grad_workspace_bytes_ex(o, lda, in_features, ldb, cus)))
     if out is None:
         out = torch.empty(o, in_features, dtype=torch.float32, device=mlp.device)
     db = torch.empty(o, dtype=torch.float32, device=mlp.device) if bias else None
-    check(lib.nm_weight_grad(cus, _ptr(delta), o, _ptr(act), stride, in_features, n, _ptr(ws), _ptr(out), out.shape[1],
-                             col0, _ptr(db), _stream()), "nm_weight_grad")
+    check(lib.nm_weight_grad_ex(cus, _ptr(delta), o, lda, _ptr(act), in_features, ldb, n, _ptr(ws), _ptr(out), out.shape[1],
+                                col0, _ptr(db), _stream()), "nm_weight_grad_ex")
     return out, db
 
 
-_HEAD_WIDTHS = (64, 128, 256)
-
-
 def _head_grad(mlp, dlast, act, bias=False):
-    """(4, K) = dlast^T @ act for the heads that share dlast (n, 4) (+ its column sums): nm_head_grad, HBM-bound VALU
-    kernel with the order-fixed partial reduction."""
+    """(4, K) = dlast^T @ act for the heads that share dlast (n, 4) (+ its column sums): nm_head_grad_ex, HBM-bound VALU
+    kernel with the order-fixed partial reduction; any activation width."""
     lib = _lib.load()
     n, k = act.shape
-    need = int(lib.nm_head_grad_workspace_bytes(k))
-    key = (mlp.device, torch.cuda.current_stream(mlp.device).cuda_stream, "head")
-    ws = _dw_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _dw_ws[key] = torch.empty(need, dtype=torch.uint8, device=mlp.device)
+    ws = _workspace(mlp, "head", int(lib.nm_head_grad_workspace_bytes_ex(k)))
     out = torch.empty(4, k, dtype=torch.float32, device=mlp.device)
     db = torch.empty(4, dtype=torch.float32, device=mlp.device) if bias else None
-    check(lib.nm_head_grad(_ptr(dlast), _ptr(act), k, n, _ptr(ws), _ptr(out), _ptr(db), _stream()), "nm_head_grad")
+    check(lib.nm_head_grad_ex(_ptr(dlast), _ptr(act), k, act.stride(0), n, _ptr(ws), _ptr(out), _ptr(db), _stream()),
+          "nm_head_grad_ex")
     return out, db
 
 
@@ -185,62 +170,42 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
           "nm_mlp_backward")
     h, feat, v = tape["h"], tape["feat"], tape["v"]
     dx = 6 * int(d["num_encoding_fn_xyz"]) + (3 if d.get("include_input_xyz", True) else 0)
-    dd = 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
+    dd = 0 if flat else 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
     is_skip = lambda i: i % skip_step == 0 and i > 0 and i != L - 1   # noqa: E731  (cat(x, xyz): models.py:64-65)
-    # hand-written weight-gradient kernel (nm_weight_grad) when the tape rows fit its tiling; the library GEMM
-    # (torch.bmm split-K, _tn) otherwise -- 64-wide networks, ragged sample counts
-    fast = n % 16 == 0 and H in (128, 256) and dx <= 64 and dd <= 64
+    # the encoding rows the layer1 / skip / view gradients contract with: 64-float rows (what the tuned weight-gradient
+    # kernel streams; padding written) when both encodings fit, rows of the next multiple of 4 floats otherwise (16-byte
+    # DMA pieces for the general kernel; whatever lies beyond the width only reaches dW entries that are never read)
+    origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
+    rays, samples = t.shape
+    sx, sd = (64, 64) if dx <= 64 and dd <= 64 else ((dx + 3) & ~3, (max(dd, 1) + 3) & ~3)
+    enc_x, enc_d = torch.empty(n, sx, **f32), (torch.empty(n, sd, **f32) if dd else None)
+    check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
+                                        samples, _ptr(enc_x), sx, _ptr(enc_d), sd, _stream()), "nm_encode_samples_strided")
     g = {}
-    if fast:
-        origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
-        rays, samples = t.shape
-        enc_x, enc_d = torch.empty(n, 64, **f32), torch.empty(n, 64, **f32)      # 64-float rows, padding written by the kernel
-        check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
-                                            samples, _ptr(enc_x), 64, _ptr(enc_d), 64, _stream()), "nm_encode_samples_strided")
-        g["layer1.weight"], g["layer1.bias"] = _weight_grad(mlp, dh[0], enc_x, dx)
-        for i in range(L - 1):
-            delta = dh[1 + i]
-            if is_skip(i):
-                gw = torch.empty(H, H + dx, **f32)
-                _, gb = _weight_grad(mlp, delta, h[i], H, out=gw, col0=0)
-                _weight_grad(mlp, delta, enc_x, dx, out=gw, col0=H, bias=False)
-            else:
-                gw, gb = _weight_grad(mlp, delta, h[i], H)
-            g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, gb
-        if not flat:
-            g["fc_feat.weight"], g["fc_feat.bias"] = _weight_grad(mlp, dfeat, h[L - 1], H)
-            gw = torch.empty(H // 2, H + dd, **f32)
-            _, g["layers_dir.0.bias"] = _weight_grad(mlp, dv, feat, H, out=gw, col0=0)
-            if (H // 2, 64) in _DW_SHAPES:
-                _weight_grad(mlp, dv, enc_d, dd, out=gw, col0=H, bias=False)
-            else:
-                gw[:, H:] = _tn(dv, enc_d[:, :dd].contiguous())
-            g["layers_dir.0.weight"] = gw
-    else:
-        enc_x, enc_d = encode_samples(mlp, origins, dirs, t)
-        g.update({"layer1.weight": _tn(dh[0], enc_x), "layer1.bias": dh[0].sum(0)})
-        for i in range(L - 1):
-            delta = dh[1 + i]
-            gw = _tn(delta, h[i])
-            if is_skip(i):
-                gw = torch.cat((gw, _tn(delta, enc_x)), dim=1)
-            g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, delta.sum(0)
-        if not flat:
-            g["fc_feat.weight"], g["fc_feat.bias"] = _tn(dfeat, h[L - 1]), dfeat.sum(0)
-            g["layers_dir.0.weight"] = torch.cat((_tn(dv, feat), _tn(dv, enc_d)), dim=1)   # cat(feat, view): models.py:72
-            g["layers_dir.0.bias"] = dv.sum(0)
+    g["layer1.weight"], g["layer1.bias"] = _weight_grad(mlp, dh[0], enc_x, dx)
+    for i in range(L - 1):
+        delta = dh[1 + i]
+        if is_skip(i):
+            gw = torch.empty(H, H + dx, **f32)
+            _, gb = _weight_grad(mlp, delta, h[i], H, out=gw, col0=0)
+            _weight_grad(mlp, delta, enc_x, dx, out=gw, col0=H, bias=False)
+        else:
+            gw, gb = _weight_grad(mlp, delta, h[i], H)
+        g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, gb
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
     if flat:
         # fc_out (4, H) over the trunk output: rows 0..2 take the pre-sigmoid colour deltas, row 3 the density delta --
         # exactly dlast^T @ h[L-1] and dlast's column sums (models.py:77-79)
-        gh, last_sums = _head_grad(mlp, dlast, h[L - 1], bias=True) if H in _HEAD_WIDTHS else (_tn(dlast, h[L - 1]), dlast.sum(0))
-        g["fc_out.weight"], g["fc_out.bias"] = gh, last_sums
+        g["fc_out.weight"], g["fc_out.bias"] = _head_grad(mlp, dlast, h[L - 1], bias=True)
         return g
-    if H in _HEAD_WIDTHS and H // 2 in _HEAD_WIDTHS:
-        (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, h[L - 1], bias=True), _head_grad(mlp, dlast, v)
-    else:
-        gh, gv, last_sums = _tn(dlast, h[L - 1]), _tn(dlast, v), dlast.sum(0)
+    g["fc_feat.weight"], g["fc_feat.bias"] = _weight_grad(mlp, dfeat, h[L - 1], H)
+    gw = torch.empty(H // 2, H + dd, **f32)                                            # cat(feat, view): models.py:72
+    _, g["layers_dir.0.bias"] = _weight_grad(mlp, dv, feat, H, out=gw, col0=0)
+    if dd:
+        _weight_grad(mlp, dv, enc_d, dd, out=gw, col0=H, bias=False)
+    g["layers_dir.0.weight"] = gw
+    (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, h[L - 1], bias=True), _head_grad(mlp, dlast, v)
     g["fc_alpha.weight"], g["fc_alpha.bias"] = gh[3:4], last_sums[3:4]
     g["fc_rgb.weight"], g["fc_rgb.bias"] = gv[:3], last_sums[:3]
     return g

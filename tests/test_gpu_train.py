@@ -487,3 +487,71 @@ def test_head_grad_kernel_vs_fp64(n, k):
     assert float((dw.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5)
     assert float((db.double().cpu() - dlast.double().sum(0)).abs().max()) <= 2e-6 * float(dlast.abs().sum(0).max() + 1)
     assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dw, dw3), "not deterministic"
+
+
+GENERAL_DW_SHAPES = [
+    # out, delta stride, in, act stride: everything the tuned kernel does not serve
+    (64, 64, 64, 64), (64, 64, 39, 40), (32, 32, 64, 64), (100, 100, 100, 100), (50, 50, 100, 100), (50, 50, 27, 28),
+    (100, 100, 63, 63), (5, 5, 2, 2), (2, 2, 5, 5), (1, 1, 1, 1), (96, 96, 96, 96), (144, 144, 144, 144), (320, 320, 320, 320),
+    (160, 160, 320, 320), (400, 400, 400, 400), (400, 400, 93, 96), (512, 512, 512, 512), (256, 512, 256, 300),
+    (272, 272, 272, 272), (256, 256, 256, 256), (128, 128, 63, 64),
+]
+
+
+@pytest.mark.parametrize("out_f,lda,in_f,ldb", GENERAL_DW_SHAPES, ids=lambda v: str(v))
+@pytest.mark.parametrize("n", [1, 583, 4099, 40000])
+def test_general_weight_grad_kernel_vs_fp64(n, out_f, lda, in_f, ldb, monkeypatch):
+    """nm_weight_grad_ex's general kernel (nerf_dw_g.hip): any widths, any strides, any row count, operands at bases that are
+    not 16-byte aligned -- vs delta^T @ act in fp64.  The operand buffers are filled with NaN beyond the widths (nothing may
+    depend on padding) and the rows beyond n of the last chunk come from the buffer descriptor's extent (rows of ANOTHER
+    tensor follow in memory: they must not be read).  Deterministic; column window of a wider output."""
+    from nerfmeshes_amd import hip_ops, train_ops as T
+    monkeypatch.setenv("NM_DW_GENERAL", "1")       # the tuned shapes too go through the general kernel here
+    kw = dict(num_layers=4, hidden_size=128, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    mlp = hip_ops.HipMLP({k: torch.as_tensor(v) for k, v in S.make_mlp_weights(3, **kw).items()}, kw, "cuda")
+    g = torch.Generator().manual_seed(n + out_f + 7 * in_f)
+    delta = torch.randn(n, out_f, generator=g) * (torch.rand(n, 1, generator=g) < 0.7)
+    act = torch.relu(torch.randn(n, in_f, generator=g))
+    for shift in (0, 1):      # second pass: both operands start 4 bytes off a 16-byte boundary
+        # rows n .. n + 40 exist in memory and hold NaN: a kernel that reads past its n rows fails loudly
+        da = torch.full(((n + 40) * lda + 8,), float("nan"), device="cuda")
+        aa = torch.full(((n + 40) * ldb + 8,), float("nan"), device="cuda")
+        dv = da[shift:shift + n * lda].view(n, lda)
+        av = aa[shift:shift + n * ldb].view(n, ldb)
+        dv[:, :out_f] = delta.cuda()
+        av[:, :in_f] = act.cuda()
+        dc, ac = dv[:, :out_f], av[:, :in_f]
+        wide = torch.full((out_f, in_f + 10), 7.0, device="cuda")
+        dw, db = T._weight_grad(mlp, dc, ac, in_f)
+        dw2, db2 = T._weight_grad(mlp, dc, ac, in_f, out=wide, col0=10)
+        ref = (delta.double().t() @ act.double())
+        scale = float(ref.abs().max()) + 1e-30
+        assert torch.isfinite(dw).all() and torch.isfinite(db).all(), "read beyond the operands' widths or rows"
+        assert float((dw.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5)
+        assert float((db.double().cpu() - delta.double().sum(0)).abs().max()) <= 2e-6 * float(delta.abs().sum(0).max() + 1)
+        assert torch.equal(wide[:, 10:], dw) and torch.equal(db2, db), "not deterministic / column window wrong"
+        assert bool((wide[:, :10] == 7.0).all()), "wrote outside its column window"
+
+
+@pytest.mark.parametrize("k,ld", [(1, 1), (32, 32), (50, 50), (100, 100), (160, 160), (200, 256), (400, 400), (512, 512), (1000, 1000), (64, 64)])
+@pytest.mark.parametrize("n", [1, 37, 4096, 131072 + 5])
+def test_general_head_grad_kernel_vs_fp64(n, k, ld, monkeypatch):
+    """nm_head_grad_ex's general kernel: any activation width / stride, vs fp64; deterministic."""
+    from nerfmeshes_amd import hip_ops, train_ops as T
+    monkeypatch.setenv("NM_DW_GENERAL", "1")
+    kw = dict(num_layers=4, hidden_size=128, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    mlp = hip_ops.HipMLP({k_: torch.as_tensor(v) for k_, v in S.make_mlp_weights(3, **kw).items()}, kw, "cuda")
+    g = torch.Generator().manual_seed(n + k)
+    dlast = torch.randn(n, 4, generator=g)
+    act = torch.relu(torch.randn(n, k, generator=g))
+    buf = torch.full((n, ld), float("nan"), device="cuda")
+    buf[:, :k] = act.cuda()
+    dc, ac = dlast.cuda().contiguous(), buf[:, :k]
+    dw, db = T._head_grad(mlp, dc, ac, bias=True)
+    dw2, db2 = T._head_grad(mlp, dc, ac, bias=True)
+    ref = dlast.double().t() @ act.double()
+    scale = float(ref.abs().max()) + 1e-30
+    assert dw.shape == (4, k) and db.shape == (4,)
+    assert float((dw.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5)
+    assert float((db.double().cpu() - dlast.double().sum(0)).abs().max()) <= 2e-6 * float(dlast.abs().sum(0).max() + 1)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "not deterministic"
