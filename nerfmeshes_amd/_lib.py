@@ -181,7 +181,7 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.nm_abi_version() != 3:
+    if lib.nm_abi_version() != 4:
         raise HipLibraryError("ABI version mismatch between _lib.py and libnerfmeshes_hip.so")
     _lib = lib
     return lib
