@@ -161,6 +161,29 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
                         "floor_ms_at_peak": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                         "note": "whole-iteration wall time (taping forward, delta kernel, dW kernels, encodings, compositing, Adam) "
                                 "against the fp32 MFMA peak"}}
+    # ---- where the iteration's time goes (HIP events around the stages of train_ops, a separate pass of `iters` iterations):
+    # the three matrix stages each against the fp32 MFMA peak on their own algorithmic FLOP, everything else as milliseconds
+    from nerfmeshes_amd import train_ops
+    train_ops.profile_stages(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    torch.cuda.synchronize()
+    ms_prof = (time.perf_counter() - t0) / iters * 1e3
+    stages = {k: v / iters for k, v in train_ops.profile_stages(False).items()}
+    work = {"taping_forward": samples * fwd, "delta": samples * delta, "weight_gradients": samples * fwd}
+    kernels = {}
+    for name, ms_stage in sorted(stages.items(), key=lambda kv: -kv[1]):
+        kernels[name] = {"ms": ms_stage}
+        if name in work:
+            kernels[name].update(tflops=work[name] / (ms_stage * 1e-3) / 1e12, frac=work[name] / (ms_stage * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+    kernels["rest"] = {"ms": ms_prof - sum(stages.values()),
+                       "what": "sample_pdf, stratified jitter, random draws, the two MSE losses, autograd bookkeeping, parameter re-pack, Adam"}
+    out["kernels"] = kernels
+    out["kernels_note"] = (f"per-iteration averages over a separate pass of {iters} iterations with HIP events around the stages "
+                           f"({ms_prof:.2f} ms per iteration in that pass); weight_gradients includes the order-fixed reductions and the "
+                           "64-wide encoding products, head_gradients the fc_alpha / fc_rgb rows")
     if not cpu_legs:
         return out
     # ---- the same iteration through torch autograd over the CPU oracle, bounded
@@ -282,8 +305,8 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
                                     "note": "whole-job: all ranks' points / slowest rank's wall time, peak x ranks; per rank: own slab / own kernel time"}},
         "marching_cubes": {"iso": iso, "vertices": int(v.shape[0]), "faces": int(f.shape[0]), "ms_min": m_min, "ms_avg": m_avg,
                            "algorithmic_bytes": vol_bytes,
-                           "roofline": {"bound": "hbm", "achieved": vol_bytes / (m_min * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": vol_bytes / (m_min * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "roofline": {"bound": "hbm", "achieved": vol_bytes / (m_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": vol_bytes / (m_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,   # averages, as every other frac
                                         **_mc_traffic_from_profile(res)},
                            "note": "whole nm_mc_count + nm_mc_emit call on the full grid incl. workspace allocation and the host sync"},
     }
@@ -360,6 +383,7 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
     scale = float(ref[:, 3].abs().max()) + 1.0
     out["grid_query"]["parity"] = {"max_abs_dsigma_over_scale": float((got[:, 3] - ref[:, 3]).abs().max()) / scale,
                                    "max_abs_drgb": float((got[:, :3] - ref[:, :3]).abs().max()), "points": int(pts.shape[0])}
+    out["appearance"], out["end_to_end_s"] = appearance_probe(dev, weights, res, limit, iso_request)
     # ---- end-to-end topology against the CPU path (mesh_nerf.py:73-79) at a size the oracle's grid takes seconds for:
     # HIP grid -> GPU iso level -> nm_mc_* vs oracle grid -> numpy iso level -> C marching cubes
     from oracle import parity
@@ -381,6 +405,101 @@ def mesh_probe(dev, weights, fine, res=480, limit=1.2, iso_request=32.0, cpu_poi
                              "each at its own adaptive iso level; on an identical grid the two marching cubes agree bitwise (marching_cubes."
                              "bitwise_identical_to_oracle)"}
     return out
+
+
+def appearance_probe(dev, weights, res, limit, iso_request, max_bound=1.0, cpu_rays=2048):
+    """The rest of BASELINE config 4 (next row (f)-1, /root/reference/src/mesh_nerf.py:131-201 + export_obj,
+    src/nerf/nerf_helpers.py:86-111): `export_marching_cubes` of the mirror, whole, on the README's command
+    (`--res 480 --iso-level 32 --limit 1.2 --view-disparity-max-bound 1e0`) -- geometry, the per-vertex appearance re-query
+    (a full coarse+fine ray per vertex from v + 0.01 n along -n, per-ray origins), the OBJ text -- timed stage by stage;
+    then the `--no-view-dependence` branch (one network evaluation per vertex).  Roofline of the re-query: V rays x
+    303.8 MFLOP against the fp32 MFMA peak over the stage's wall time.  CPU leg: the oracle on a bounded vertex sample,
+    which is also the parity check."""
+    import contextlib, io, tempfile
+    from nerfmeshes_amd import mesh_nerf, models
+    from nerfmeshes_amd.nerf import CfgNode
+    from nerfmeshes_amd.models.model_helpers import nest_dict
+    hp = S.hparams()
+    model = models.NeRFModel(hp)
+    sd = model.state_dict()
+    for k, v in weights.items():
+        sd["model_coarse." + k] = torch.from_numpy(v)
+        sd["model_fine." + k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model = model.eval().to(dev)
+    cfg = CfgNode(nest_dict(hp, sep="."))
+    tmp = tempfile.mkdtemp(prefix="nm_bench_mesh_")
+    stages, kept = {}, {}
+
+    def timed(name, fn):
+        def wrapper(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res_ = fn(*a, **k)
+            torch.cuda.synchronize()
+            stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
+            return res_
+        return wrapper
+
+    orig = mesh_nerf.export_obj, mesh_nerf.extract_geometry
+    mesh_nerf.export_obj, mesh_nerf.extract_geometry = timed("obj_text_s", orig[0]), timed("geometry_s", orig[1])
+    out = {}
+    try:
+        for branch, extra in (("view_dependent", []), ("no_view_dependence", ["--no-view-dependence"])):
+            args = mesh_nerf.build_parser().parse_args(["--res", str(res), "--iso-level", str(iso_request), "--limit", str(limit),
+                                                        "--view-disparity-max-bound", str(max_bound), "--save-dir", tmp] + extra)
+            for _ in range(2):                 # the second run is the warm one
+                stages.clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+                    vertices, triangles, normals, diffuse = mesh_nerf.export_marching_cubes(model, args, cfg, dev)
+                torch.cuda.synchronize()
+                total = time.perf_counter() - t0
+            V = int(vertices.shape[0])
+            requery = total - stages["geometry_s"] - stages["obj_text_s"]
+            size = os.path.getsize(os.path.join(tmp, args.mesh_name))
+            flops = V * (256 * coarse_flops_per_sample() if branch == "view_dependent" else coarse_flops_per_sample())
+            out[branch] = {"vertices": V, "faces": int(triangles.shape[0]), "end_to_end_s": total, "geometry_s": stages["geometry_s"],
+                           "requery_s": requery, "requery_rays_per_s": V / requery,
+                           "roofline": {"bound": "mfma", "achieved": flops / requery / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": flops / requery / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                        "note": "V x algorithmic FLOP of the branch over the stage's WALL time (D2H of the colours and host glue included)"},
+                           "obj_text_s": stages["obj_text_s"], "obj_bytes": size, "obj_MBps": size / stages["obj_text_s"] / 1e6}
+            kept[branch] = (vertices, normals, torch.as_tensor(diffuse))
+    finally:
+        mesh_nerf.export_obj, mesh_nerf.extract_geometry = orig
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    # ---- CPU leg + parity on a bounded, strided vertex sample: the oracle's NeRFModel.query over per-ray origins
+    from oracle import nerf_oracle as O, parity
+    spec, rs = O.MLPSpec(**MLP_KW), O.RenderSpec(num_coarse=NUM_COARSE, num_fine=NUM_FINE)
+    vertices, normals, diffuse = kept["view_dependent"]
+    pick = torch.arange(0, vertices.shape[0], max(1, vertices.shape[0] // cpu_rays))[:cpu_rays]
+    tgt, dirs = vertices[pick.to(dev)].cpu(), -normals[pick.to(dev)].cpu()
+    origins = tgt - 0.01 * dirs
+    with torch.no_grad():
+        threads = _pick_threads(lambda: O.render(weights, weights, spec, spec, rs, origins[:256], dirs[:256], 0.0, max_bound), os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        ref = O.render(weights, weights, spec, spec, rs, origins, dirs, 0.0, max_bound)[1]["rgb_map"]
+        dt = time.perf_counter() - t0
+        ref_pts = O.mlp_forward(weights, spec, tgt, dirs)[:, :3]
+    out["view_dependent"]["cpu_baseline"] = {"value": pick.numel() / dt, "unit": "rays/s", "cores": threads, "host_cores": os.cpu_count(),
+                                             "kind": "port", "sample": f"{pick.numel()} strided vertices, per-ray origins, one call, {dt:.2f} s"}
+    out["view_dependent"]["speedup_vs_cpu"] = out["view_dependent"]["requery_rays_per_s"] / (pick.numel() / dt)
+    out["view_dependent"]["parity"] = parity.psnr_parity(diffuse[pick], ref, chunk=2048)
+    out["no_view_dependence"]["parity"] = {"max_abs_drgb": float((kept["no_view_dependence"][2][pick] - ref_pts).abs().max()),
+                                           "vertices": int(pick.numel())}
+    out["workload"] = (f"mesh_nerf --res {res} --iso-level {iso_request} --limit {limit} --view-disparity-max-bound {max_bound}: "
+                       "export_marching_cubes of the mirror, whole (geometry + per-vertex re-query + OBJ), warm run")
+    return out, out["view_dependent"]["end_to_end_s"]
+
+
+def coarse_flops_per_sample():
+    kw = MLP_KW
+    H_, L_, dx, dd = kw["hidden_size"], kw["num_layers"], 6 * kw["num_encoding_fn_xyz"] + 3, 6 * kw["num_encoding_fn_dir"] + 3
+    nskip = sum(1 for i in range(L_ - 1) if i % kw["skip_step"] == 0 and i > 0 and i != L_ - 1)
+    return 2 * (dx * H_ + (L_ - 1) * H_ * H_ + nskip * dx * H_ + H_ * H_ + H_ + (H_ + dd) * (H_ // 2) + 3 * (H_ // 2))
 
 
 def buff_probe(dev, cpu_rays=2048, rank=0, world=1, use_dist=False, cpu_legs=True):
@@ -476,7 +595,7 @@ def buff_probe(dev, cpu_rays=2048, rank=0, world=1, use_dist=False, cpu_legs=Tru
     return out
 
 
-def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=2, cpu_size=72, cpu_legs=True):
+def eval_probe(dev, weights, views=20, render_chunk=65536, cpu_views=4, cpu_size=92, cpu_legs=True):
     """BASELINE config 3 at N = 1 (`eval_nerf.py` over a test set, /root/reference/src/eval_nerf.py:50-105): `views` orbit
     views of 800x800 through the eval_nerf mirror (`eval_views`: per-view loss = sum of per-2048-ray-chunk MSEs divided by
     the FLOAT batch count 312.5, dataset loss = mean over views, PSNR of that), every view scored against a seeded noisy
@@ -664,6 +783,114 @@ def tiny_probe(dev, cpu_legs=True):
     return out
 
 
+class _Emergency:
+    """The headline must reach stdout whatever happens to a secondary object.  At N > 1 a rank that
+    dies inside a sharded object leaves the others inside a collective; the launcher then SIGTERMs them.  Rank 0 therefore
+    arms, as soon as the headline is computed, a watcher THREAD on the signal wake-up pipe (a Python-level handler would
+    not run while the main thread sits in a collective / device synchronisation; those calls release the GIL, so a thread
+    does): on SIGTERM / SIGINT it writes the ONE JSON line -- headline + {"error": ...} for the object in flight -- and exits."""
+
+    def __init__(self, json_fd):
+        self.json_fd, self.out, self.stage, self.done = json_fd, None, "headline", False
+
+    def arm(self, out):
+        import signal
+        import threading
+        self.out = out
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(sig, lambda *a: None)          # the C-level handler writes the signal number to the pipe
+
+        def watch():
+            os.read(r, 1)
+            self.emit(f"the job was terminated during '{self.stage}' (a rank left it; signal from the launcher)", code=3)
+
+        threading.Thread(target=watch, daemon=True).start()
+
+    def emit(self, error=None, code=None):
+        if self.done or self.out is None:
+            if code is not None:
+                os._exit(code)
+            return
+        self.done = True
+        if error is not None:
+            self.out.setdefault("errors", []).append(error)
+            if self.stage not in self.out:
+                self.out[self.stage] = {"error": error}
+        _annotate_ports(self.out)
+        os.write(self.json_fd, (json.dumps(self.out, default=repr) + "\n").encode())
+        if code is not None:
+            os._exit(code)
+
+
+PORT_OVER_REFERENCE_TIME = 1.15   # profiles/r04_port_vs_reference_cpu.json: the oracle (kind "port") takes 1.14 - 1.16 x the time of the
+                                  # unmodified reference modules on the same host (bit-identical outputs; first-touch of its activations)
+
+
+def _annotate_ports(node):
+    """Every CPU leg of kind "port" says by how much the port understates the reference's own CPU rate, so that no
+    GPU / CPU ratio on the line is read as more than an upper bound."""
+    if isinstance(node, dict):
+        if node.get("kind") == "port" and "port_over_reference_time" not in node:
+            node["port_over_reference_time"] = PORT_OVER_REFERENCE_TIME
+            node["port_note"] = ("the port runs 1.14-1.16x the unmodified reference's time on the same host (profiles/r04_port_vs_reference_cpu.json): "
+                                 "ratios against this leg are upper bounds by that factor")
+        for v in list(node.values()):
+            _annotate_ports(v)
+    elif isinstance(node, list):
+        for v in node:
+            _annotate_ports(v)
+
+
+def _inject(name, rank):
+    """Test hook (tests/test_gpu_dist.py): NM_BENCH_INJECT_FAILURE="mesh:1" raises inside that object on that rank,
+    "buff:all" on every rank."""
+    spec = os.environ.get("NM_BENCH_INJECT_FAILURE", "")
+    for item in spec.split(","):
+        obj, _, who = item.partition(":")
+        if obj == name and who in ("all", str(rank)):
+            raise RuntimeError(f"injected failure in '{name}' on rank {rank}")
+
+
+def _guarded(name, fn, rank, world, emergency, healthy_wait_s=1800, failed_wait_s=45):
+    """Run one secondary object so that its failure cannot take the line down or hang the job.  The object's own
+    collectives run on RCCL; the VERDICT on the object travels through the rendezvous store (no collective a failed rank could
+    mismatch): every rank posts "" or its error after leaving the object and waits for the others' posts.
+      * all ranks fail at the same place (a bug, an out-of-memory at this size): all post promptly, all skip together,
+        the line carries {"error": ...} for the object and the next object runs;
+      * one rank fails while the others sit in a collective it never joins: its wait for their posts times out
+        (`failed_wait_s`), it leaves the job, the launcher terminates the rest and rank 0's emergency writer emits the line."""
+    import datetime
+    emergency.stage = name
+    err, res = None, None
+    try:
+        _inject(name, rank)
+        res = fn()
+    except Exception as e:  # noqa: BLE001 -- the headline line must not depend on a secondary figure
+        err = repr(e)
+    if world == 1:
+        return {"error": err} if err else res
+    from torch.distributed.distributed_c10d import _get_default_store
+    store = _get_default_store()
+    keys = [f"nm_bench/{name}/{r}" for r in range(world)]
+    store.set(keys[rank], err or "")
+    try:
+        store.wait(keys, datetime.timedelta(seconds=failed_wait_s if err else healthy_wait_s))
+    except Exception:  # noqa: BLE001 -- the others never left the object: they are inside a collective this rank abandoned
+        msg = f"rank {rank} failed in '{name}' ({err}) while other ranks were inside a collective" if err else \
+              f"rank {rank}: other ranks never left '{name}'"
+        if rank == 0:
+            emergency.emit(msg, code=3)
+        os._exit(3)
+    errs = {r: store.get(k).decode() for r, k in enumerate(keys)}
+    failed = {r: e for r, e in errs.items() if e}
+    if failed:
+        return {"error": next(iter(failed.values())), "failed_ranks": sorted(failed)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -838,6 +1065,9 @@ def main():
     if rccl is not None:
         out["rccl"] = rccl
 
+    emergency = _Emergency(json_fd)
+    if rank == 0:
+        emergency.arm(out)        # from here on the line is written even if the job is torn down around rank 0
     solo = rank == 0 and world == 1
     ref_idx = ref_rgb = None
     if solo and not args.no_cpu_baseline:
@@ -875,12 +1105,7 @@ def main():
                            ("buff", args.no_buff_probe, lambda: buff_probe(dev, **shard))):
         if skip:
             continue
-        try:
-            res = fn()
-        except Exception as e:  # the headline line must not depend on a secondary figure
-            if world > 1:
-                raise           # a rank that leaves a collective early would hang the others: fail loudly instead
-            res = {"error": repr(e)}
+        res = _guarded(name, fn, rank, world, emergency)
         if rank == 0:
             out[name] = res
     # ... and single-GPU objects
@@ -890,15 +1115,13 @@ def main():
                            ("bf16x3", args.no_b3_probe,
                             lambda: b3_probe(dev, weights, views, near, far, u_c, u_f, args.chunk, ref_idx, ref_rgb))):
         if solo and not skip:
-            try:
-                out[name] = fn()
-            except Exception as e:
-                out[name] = {"error": repr(e)}
+            out[name] = _guarded(name, fn, 0, 1, emergency)
     if use_dist:
         dist.barrier()
     if rank == 0:
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emergency.stage = "done"
+        emergency.emit()
     if use_dist:
         dist.destroy_process_group()
 

@@ -66,6 +66,19 @@ def shutdown():
         dist.destroy_process_group()
 
 
+COLLECTIVES = {"count": 0}     # collectives issued by this module since import (tests and bench.py report the count per object)
+PADDED_GATHER_LIMIT = 1 << 30   # bytes of world x max(counts) rows up to which a ragged gather is ONE padded collective
+
+
+def _count():
+    COLLECTIVES["count"] += 1
+
+
+def _debug():
+    import os
+    return os.environ.get("NERFMESHES_DIST_DEBUG", "") not in ("", "0")
+
+
 def _via_host(t):
     """True when a collective on `t` has to be staged through host memory: a device tensor under the gloo backend."""
     return t.is_cuda and _dist().get_backend() == "gloo"
@@ -74,6 +87,7 @@ def _via_host(t):
 def all_gather_into(out, local):
     """`dist.all_gather_into_tensor(out, local)`; device tensors under gloo go through the host."""
     dist = _dist()
+    _count()
     if _via_host(local):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, local.cpu().contiguous())
@@ -86,6 +100,7 @@ def all_gather_into(out, local):
 def all_reduce(t, op=None):
     dist = _dist()
     op = op if op is not None else dist.ReduceOp.SUM
+    _count()
     if _via_host(t):
         host = t.cpu()
         dist.all_reduce(host, op=op)
@@ -98,6 +113,7 @@ def all_reduce(t, op=None):
 def broadcast(t, src=0):
     """`dist.broadcast(t, src)` in place; device tensors under gloo go through the host."""
     dist = _dist()
+    _count()
     if _via_host(t):
         host = t.cpu()
         dist.broadcast(host, src=src)
@@ -126,10 +142,9 @@ def slab_range(n0, rank, world_size):
 
 def all_gather_rows(local, counts):
     """All-gather a ragged first dimension: `local` is this rank's (counts[rank], ...) tensor; returns the
-    concatenation over ranks on every rank.  Equal shards take the single-collective fast path
-    (all_gather_into_tensor -> one RCCL ring over xGMI); ragged shards are an all-gatherv (`all_gather_v`): every
-    rank's rows land in their slice of ONE exact-size output -- no padding to the largest shard, no copy afterwards: a
-    surface that lives in the middle slabs moves sum(counts) rows per rank, not world * max(counts)."""
+    concatenation over ranks on every rank.  ONE collective either way: equal shards are all_gather_into_tensor
+    straight into the result (one RCCL ring over xGMI); ragged shards travel padded to the largest one
+    (`all_gather_v`) and are compacted on the device."""
     dist = _dist()
     rank, ws = world()
     if not (dist.is_available() and dist.is_initialized()):
@@ -138,6 +153,8 @@ def all_gather_rows(local, counts):
     # tests and `bench.py` exercise the same RCCL entry point the 8-GPU run uses
     if len(counts) != ws or counts[rank] != local.shape[0]:
         raise ValueError(f"all_gather_rows: rank {rank} holds {local.shape[0]} rows, counts = {list(counts)}")
+    if _debug():
+        check_counts(counts)
     tail = tuple(local.shape[1:])
     if len(set(counts)) == 1:
         out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
@@ -145,16 +162,41 @@ def all_gather_rows(local, counts):
     return all_gather_v(local, counts)
 
 
+def check_counts(counts):
+    """Debug aid (NERFMESHES_DIST_DEBUG=1): every rank must present the same `counts` to a ragged gather -- ranks that
+    disagree would otherwise size their buffers differently and hang or corrupt the collective.  One extra all-gather."""
+    rank, ws = world()
+    mine = torch.tensor(list(counts), dtype=torch.int64)
+    every = torch.empty(ws * len(counts), dtype=torch.int64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if _dist().get_backend() == "nccl" else torch.device("cpu")
+    every = all_gather_into(every.to(dev), mine.to(dev)).cpu().view(ws, -1)
+    if not bool((every == every[0]).all()):
+        raise RuntimeError(f"ragged gather: the ranks disagree about the shard sizes: {every.tolist()}")
+
+
 def all_gather_v(local, counts):
-    """The ragged case of `all_gather_rows` as an all-gatherv: ONE exact-size output (sum(counts) rows); rank r's rows are
-    broadcast from r straight into their slice of it (`counts` is known everywhere, so empty shards are simply skipped --
-    no zero-size collective).  Same calls under RCCL and gloo (gloo's own all_gather insists on equal sizes); device
-    tensors under gloo are staged through the host."""
+    """The ragged case of `all_gather_rows` as ONE collective: every rank contributes max(counts) rows (its own, padded),
+    all_gather_into_tensor assembles (world, max, ...) and the shards are compacted into the exact-size result by one
+    device-side concatenation.  At this path's sizes the padding is noise (triangles of a 480^3 mesh at 8 ranks: 8 x 9 MB
+    instead of 40 MB, 0.5 ms of xGMI time) while a broadcast per rank -- round 4's exact-size form -- costs `world`
+    latency-bound collectives; that form is kept for payloads beyond PADDED_GATHER_LIMIT.  Same calls under RCCL and gloo;
+    device tensors under gloo are staged through the host."""
     dist = _dist()
     rank, ws = world()
     tail = tuple(local.shape[1:])
+    row = local.element_size()
+    for d in tail:
+        row *= d
+    mx, total = max(counts), sum(counts)
+    if ws * mx * row <= PADDED_GATHER_LIMIT:
+        send = torch.empty((mx,) + tail, dtype=local.dtype, device=local.device)
+        send[:counts[rank]].copy_(local)
+        buf = torch.empty((ws * mx,) + tail, dtype=local.dtype, device=local.device)
+        all_gather_into(buf, send)
+        buf = buf.view((ws, mx) + tail)
+        return torch.cat([buf[r, :counts[r]] for r in range(ws) if counts[r]], dim=0) if total else buf[0, :0]
     host = _via_host(local)
-    out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device="cpu" if host else local.device)
+    out = torch.empty((total,) + tail, dtype=local.dtype, device="cpu" if host else local.device)
     lo = 0
     for r in range(ws):
         hi = lo + counts[r]
@@ -162,6 +204,7 @@ def all_gather_v(local, counts):
             piece = out[lo:hi]
             if r == rank:
                 piece.copy_(local)
+            _count()
             dist.broadcast(piece, src=r)
         lo = hi
     return out.to(local.device) if host else out
@@ -211,8 +254,9 @@ def marching_cubes_sharded(query_fn, n0, n1, n2, iso_fn):
     ((p_hi - p_lo) * n1 * n2,) densities; the 2 - 3 shared planes per boundary are recomputed rather than exchanged --,
     `iso_fn(slab, p_lo, own_lo, own_hi)` returns the iso level (collectively: numpy's statistics of the whole grid from
     per-rank chunk sums), every rank meshes its slab (nm_mc_count_slab / nm_mc_emit_slab: vertex ownership by GLOBAL plane
-    index, vertex ids offset by the vertex counts of the lower ranks, which are all-gathered), and the four arrays are
-    all-gathered in rank order.  The result equals the single-GPU mesh bit for bit, vertex numbering included.
+    index, vertex ids offset by the vertex counts of the lower ranks, which are all-gathered), and the four arrays travel
+    in ONE all-gather of a packed byte buffer per rank: 2 collectives at any world size (+ 2 for a whole-grid iso level,
+    `hip_ops.np_stats_sharded`).  The result equals the single-GPU mesh bit for bit, vertex numbering included.
     Returns (vertices, faces, normals, values, local slab (planes p_lo .. p_hi))."""
     from . import hip_ops
     rank, ws = world()
@@ -225,21 +269,33 @@ def marching_cubes_sharded(query_fn, n0, n1, n2, iso_fn):
     own_lo, own_hi = lo * plane, (hi + (1 if hi == n0 - 1 else 0)) * plane if not empty else lo * plane
     iso = iso_fn(slab, p_lo, own_lo, own_hi)
     dev = slab.device if slab is not None else torch.device("cuda", torch.cuda.current_device())
+    # TWO collectives for the mesh whatever the world size: (vertices, faces) of every rank -- the vertex bases of the
+    # ranks above need the counts below them --, then ONE gather of a byte buffer per rank that carries its four arrays
+    # back to back (vertices | normals | values | faces: 28 V + 12 F bytes)
+    piece = None if empty else hip_ops.marching_cubes_slab(slab, iso, p_lo, below, above)
+    mine = torch.tensor([[0, 0] if empty else [piece.vertices, piece.faces]],        # the slab's OWN counts (ghost layer excluded)
+                        dtype=torch.int64, device=dev)
+    counts = torch.empty(ws, 2, dtype=torch.int64, device=dev)
+    all_gather_into(counts, mine)
+    counts = counts.cpu()
+    # vertex ids of a slab are local id + (vertices of all lower slabs) - its ghost vertices (nm_mc_emit_slab)
+    nv, nf = [int(c) for c in counts[:, 0]], [int(c) for c in counts[:, 1]]
     if empty:
-        v = torch.empty(0, 3, dtype=torch.float32, device=dev)
-        parts = [v, torch.empty(0, 3, dtype=torch.int32, device=dev), v.clone(), torch.empty(0, dtype=torch.float32, device=dev)]
-        mine = torch.zeros(1, dtype=torch.int64, device=dev)
-        counts = torch.empty(ws, dtype=torch.int64, device=dev)
-        all_gather_into(counts, mine)
+        payload = torch.empty(0, dtype=torch.uint8, device=dev)
     else:
-        piece = hip_ops.marching_cubes_slab(slab, iso, p_lo, below, above)
-        mine = torch.tensor([piece.vertices], dtype=torch.int64, device=dev)
-        counts = torch.empty(ws, dtype=torch.int64, device=dev)
-        all_gather_into(counts, mine)
-        base = int(counts[:rank].sum())
-        parts = list(piece.emit(base - piece.ghost_vertices))
-    out = [all_gather_ragged(p.contiguous()) for p in parts]
-    return out[0], out[1], out[2], out[3], slab
+        v, f, nrm, val = piece.emit(sum(nv[:rank]) - piece.ghost_vertices)       # (verts, faces, normals, values)
+        payload = torch.cat([t.contiguous().view(-1).view(torch.uint8) for t in (v, nrm, val, f)])
+    sizes = [28 * a + 12 * b for a, b in zip(nv, nf)]
+    if payload.numel() != sizes[rank]:
+        raise RuntimeError(f"marching_cubes_sharded: rank {rank} emitted {payload.numel()} bytes, its counts say {sizes[rank]}")
+    flat = all_gather_rows(payload, sizes)
+    parts, lo = ([], [], [], []), 0
+    for a, b in zip(nv, nf):
+        for k, (n_items, dtype) in enumerate(((3 * a, torch.float32), (3 * a, torch.float32), (a, torch.float32), (3 * b, torch.int32))):
+            parts[k].append(flat[lo:lo + 4 * n_items].view(dtype))
+            lo += 4 * n_items
+    vertices, normals, values, faces = (torch.cat(p) for p in parts)
+    return vertices.view(-1, 3), faces.view(-1, 3), normals.view(-1, 3), values, slab
 
 
 def all_reduce_gradients(parameters, bucket_bytes=64 << 20):

@@ -404,8 +404,8 @@ def np_stats_sharded(x_local, first, n_total, own_lo, own_hi, gather):
     """`np_stats` of an array of `n_total` elements that is spread over several ranks, numpy's fp32 result bit for bit
     (nm_np_chunk_sums / nm_np_finish).  `x_local` holds the global elements [first, first + x_local.numel()); this rank is
     responsible for the 8192-element chunks that START in [own_lo, own_hi) (their elements must be among the ones it
-    holds: slabs carry a halo).  `gather(t)`: all-gather of a ragged 1-D float tensor in rank order (identity on one
-    rank).  Every rank returns the same dict."""
+    holds: slabs carry a halo).  `gather(t)`: all-gather of a tensor with a ragged first dimension in rank order (identity
+    on one rank); it is called once per pass (2 collectives in all).  Every rank returns the same dict."""
     lib = _lib.load()
     x = _dev32(x_local, name="x").reshape(-1)
     dev = x.device
@@ -422,9 +422,12 @@ def np_stats_sharded(x_local, first, n_total, own_lo, own_hi, gather):
             check(lib.nm_np_chunk_sums(_ptr(x), int(first), x.numel(), int(n_total), c_lo, c_hi, second,
                                        float(result.get("mean", 0.0)), _ptr(mine[0]), _ptr(mine[1]), _ptr(mine[2]), _stream()),
                   "nm_np_chunk_sums")
-        rows = [gather(mine[r, :m].contiguous()) for r in range(1 if second else 3)]
-        if rows[0].numel() != chunks:
-            raise RuntimeError(f"np_stats_sharded: the ranks cover {rows[0].numel()} of {chunks} chunks")
+        # one gather per pass: the (sum, min, max) rows of a rank's chunks travel as one (m, 3) block
+        nrows = 1 if second else 3
+        packed = gather(mine[:nrows, :m].t().contiguous())
+        if packed.shape[0] != chunks:
+            raise RuntimeError(f"np_stats_sharded: the ranks cover {packed.shape[0]} of {chunks} chunks")
+        rows = [packed[:, r].contiguous() for r in range(nrows)]
         check(lib.nm_np_finish(_ptr(rows[0]), _ptr(rows[1]) if not second else None, _ptr(rows[2]) if not second else None,
                                chunks, int(n_total), second, _ptr(d_out), out.ctypes.data_as(_lib.c_float_p), _stream()),
               "nm_np_finish")

@@ -24,6 +24,39 @@ from ._lib import BundleGrads, MlpDeltas, MlpTape, MlpWeights, check
 from .hip_ops import _dev32, _ptr, _stream
 
 
+_STAGES = None     # bench.py's per-stage breakdown: when a dict, name -> [(start event, end event), ...] on torch's current stream
+
+
+class _stage:
+    """`with _stage("delta"): ...` -- HIP events around a stage of the training step while `profile_stages(True)` is on."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _STAGES is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _STAGES is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _STAGES.setdefault(self.name, []).append((self.e0, e1))
+        return False
+
+
+def profile_stages(on):
+    """Start (True) / stop (False) collecting per-stage HIP-event times; stopping returns {stage: total ms} since the start."""
+    global _STAGES
+    if on:
+        _STAGES = {}
+        return None
+    torch.cuda.synchronize()
+    done, _STAGES = _STAGES or {}, None
+    return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in done.items()}
+
+
 def param_names(num_layers, use_viewdirs=True):
     names = ["layer1.weight", "layer1.bias"]
     for i in range(num_layers - 1):
@@ -86,8 +119,9 @@ def forward_train(mlp, origins, dirs, t):
                 mask_v=None if flat or generic else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
     out = torch.empty(rays, samples, 4, **f32)
     ct = _tape_struct(tape)
-    check(lib.nm_mlp_forward_train(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays, samples,
-                                   C.byref(ct), _ptr(out), _stream()), "nm_mlp_forward_train")
+    with _stage("taping_forward"):
+        check(lib.nm_mlp_forward_train(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays, samples,
+                                       C.byref(ct), _ptr(out), _stream()), "nm_mlp_forward_train")
     return out, tape
 
 
@@ -135,8 +169,9 @@ def _weight_grad(mlp, delta, act, in_features, out=None, col0=0, bias=True):
     if out is None:
         out = torch.empty(o, in_features, dtype=torch.float32, device=mlp.device)
     db = torch.empty(o, dtype=torch.float32, device=mlp.device) if bias else None
-    check(lib.nm_weight_grad_ex(cus, _ptr(delta), o, lda, _ptr(act), in_features, ldb, n, _ptr(ws), _ptr(out), out.shape[1],
-                                col0, _ptr(db), _stream()), "nm_weight_grad_ex")
+    with _stage("weight_gradients"):
+        check(lib.nm_weight_grad_ex(cus, _ptr(delta), o, lda, _ptr(act), in_features, ldb, n, _ptr(ws), _ptr(out), out.shape[1],
+                                    col0, _ptr(db), _stream()), "nm_weight_grad_ex")
     return out, db
 
 
@@ -148,8 +183,9 @@ def _head_grad(mlp, dlast, act, bias=False):
     ws = _workspace(mlp, "head", int(lib.nm_head_grad_workspace_bytes_ex(k)))
     out = torch.empty(4, k, dtype=torch.float32, device=mlp.device)
     db = torch.empty(4, dtype=torch.float32, device=mlp.device) if bias else None
-    check(lib.nm_head_grad_ex(_ptr(dlast), _ptr(act), k, act.stride(0), n, _ptr(ws), _ptr(out), _ptr(db), _stream()),
-          "nm_head_grad_ex")
+    with _stage("head_gradients"):
+        check(lib.nm_head_grad_ex(_ptr(dlast), _ptr(act), k, act.stride(0), n, _ptr(ws), _ptr(out), _ptr(db), _stream()),
+              "nm_head_grad_ex")
     return out, db
 
 
@@ -166,8 +202,9 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     dfeat, dv = (None, None) if flat else (torch.empty(n, H, **f32), torch.empty(n, H // 2, **f32))
     ct = _tape_struct(tape)
     cd = MlpDeltas(_ptr(dh), None if flat else _ptr(dfeat), None if flat else _ptr(dv), _ptr(dlast))
-    check(lib.nm_mlp_backward(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), _stream()),
-          "nm_mlp_backward")
+    with _stage("delta"):
+        check(lib.nm_mlp_backward(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), _stream()),
+              "nm_mlp_backward")
     h, feat, v = tape["h"], tape["feat"], tape["v"]
     dx = 6 * int(d["num_encoding_fn_xyz"]) + (3 if d.get("include_input_xyz", True) else 0)
     dd = 0 if flat else 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
@@ -179,8 +216,9 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     rays, samples = t.shape
     sx, sd = (64, 64) if dx <= 64 and dd <= 64 else ((dx + 3) & ~3, (max(dd, 1) + 3) & ~3)
     enc_x, enc_d = torch.empty(n, sx, **f32), (torch.empty(n, sd, **f32) if dd else None)
-    check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
-                                        samples, _ptr(enc_x), sx, _ptr(enc_d), sd, _stream()), "nm_encode_samples_strided")
+    with _stage("encodings"):
+        check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
+                                            samples, _ptr(enc_x), sx, _ptr(enc_d), sd, _stream()), "nm_encode_samples_strided")
     g = {}
     g["layer1.weight"], g["layer1.bias"] = _weight_grad(mlp, dh[0], enc_x, dx)
     for i in range(L - 1):
@@ -259,8 +297,9 @@ class _Composite(torch.autograd.Function):
     def forward(ctx, radiance, t, dirs, noise, thr, white_bg):
         rays, samples = t.shape
         tensors, out = hip_ops._alloc_bundle(rays, samples, radiance.device)
-        check(_lib.load().nm_composite_train(_ptr(radiance), _ptr(t), _ptr(dirs), _ptr(noise), rays, samples, float(thr),
-                                             int(white_bg), C.byref(out), _stream()), "nm_composite_train")
+        with _stage("compositing_forward"):
+            check(_lib.load().nm_composite_train(_ptr(radiance), _ptr(t), _ptr(dirs), _ptr(noise), rays, samples, float(thr),
+                                                 int(white_bg), C.byref(out), _stream()), "nm_composite_train")
         ctx.white_bg = bool(white_bg)
         ctx.noise = noise
         ctx.save_for_backward(radiance, t, dirs)
@@ -276,9 +315,10 @@ class _Composite(torch.autograd.Function):
         keep = [None if g is None else _dev32(g) for g in (g_rgb, g_acc, g_depth, g_weights)]
         grads = BundleGrads(*[_ptr(g) for g in keep])
         out = torch.empty_like(radiance)
-        check(_lib.load().nm_composite_backward(_ptr(radiance), _ptr(t), _ptr(dirs), _ptr(ctx.noise), rays, samples,
-                                                int(ctx.white_bg), C.byref(grads), _ptr(out), _stream()),
-              "nm_composite_backward")
+        with _stage("compositing_backward"):
+            check(_lib.load().nm_composite_backward(_ptr(radiance), _ptr(t), _ptr(dirs), _ptr(ctx.noise), rays, samples,
+                                                    int(ctx.white_bg), C.byref(grads), _ptr(out), _stream()),
+                  "nm_composite_backward")
         return out, None, None, None, None, None
 
 

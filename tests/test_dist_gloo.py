@@ -204,6 +204,43 @@ def test_all_gather_v_places_ragged_and_empty_shards_exactly(world):
         assert np.array_equal(rows, want_rows) and np.array_equal(ids, want_ids)
 
 
+def _count_job(rank, world):
+    """Collectives a ragged gather costs: ONE for known counts, TWO when the counts travel first; the oversized-payload
+    fallback (one broadcast per non-empty rank) gives the same rows; NERFMESHES_DIST_DEBUG catches ranks that disagree."""
+    counts = [5, 0, 2][:world] if world == 3 else [3, 4]
+    rows = torch.arange(counts[rank] * 3, dtype=torch.float32).reshape(counts[rank], 3) + 100.0 * rank
+    c0 = nd.COLLECTIVES["count"]
+    a = nd.all_gather_rows(rows, counts)
+    c1 = nd.COLLECTIVES["count"]
+    b = nd.all_gather_ragged(rows)
+    c2 = nd.COLLECTIVES["count"]
+    limit, nd.PADDED_GATHER_LIMIT = nd.PADDED_GATHER_LIMIT, 0
+    c = nd.all_gather_rows(rows, counts)
+    nd.PADDED_GATHER_LIMIT = limit
+    c3 = nd.COLLECTIVES["count"]
+    os.environ["NERFMESHES_DIST_DEBUG"] = "1"
+    nd.all_gather_rows(rows, counts)                      # agreeing counts pass the check
+    wrong = list(counts)
+    if rank == 1:
+        wrong[0] += 1                                      # rank 1 believes rank 0 holds one row more
+    try:
+        nd.all_gather_rows(rows, wrong)
+        caught = False
+    except RuntimeError as e:
+        caught = "disagree" in str(e)
+    os.environ.pop("NERFMESHES_DIST_DEBUG")
+    return (c1 - c0, c2 - c1, c3 - c2, torch.equal(a, b) and torch.equal(a, c), caught)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_ragged_gathers_are_single_collectives(world):
+    nonempty = 2
+    for one, two, fallback, same, caught in _run(_count_job, world=world):
+        assert (one, two, fallback) == (1, 2, nonempty), (one, two, fallback)
+        assert same and caught
+
+
 # ---- the Trainer stand-in under a launcher: identical replicas, distinct ray streams, one version dir (ADVICE r3) ----
 def _assemble_job_7(rank, world):
     return _assemble_job(rank, world, 7)

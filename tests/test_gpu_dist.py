@@ -120,6 +120,29 @@ def test_bench_two_ranks_on_one_gpu_carries_the_sharded_objects(mode):
     assert "cpu_baseline" not in line and "train" not in line            # N = 1 only
 
 
+@pytest.mark.parametrize("inject,expect", [("mesh:1", "asymmetric"), ("buff:all", "symmetric")])
+def test_bench_line_survives_a_failing_secondary_object_at_two_ranks(inject, expect):
+    """The first real N-GPU run must not be able to lose its headline to a secondary object.
+    `NM_BENCH_INJECT_FAILURE` raises inside an object: on rank 1 only -- rank 0 is then inside the object's first collective,
+    which rank 1 never joins; rank 1 gives up waiting for the others' verdicts, leaves, the launcher terminates rank 0 and
+    its emergency writer still emits the ONE line (headline + an error for the object) -- or on every rank, where all
+    ranks agree through the rendezvous store, skip the object together and the REST of the line is complete."""
+    env = _env()
+    env["NM_BENCH_INJECT_FAILURE"] = inject
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--ranks-per-gpu", "2", "--steps", "1", "--warmup", "1",
+                        "--mesh-res", "60", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    printed = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, (printed, r.stderr[-3000:])
+    line = json.loads(printed[0])
+    assert line["value"] > 1e5 and line["n_gpus"] == 1 and line["rccl"]["ranks_in_all_gather"] == 2, "the headline must be intact"
+    if expect == "asymmetric":
+        assert "error" in line["mesh"] and "errors" in line and r.returncode != 0
+    else:
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "injected failure" in line["buff"]["error"] and line["buff"]["failed_ranks"] == [0, 1]
+        assert line["mesh"]["marching_cubes"]["bitwise_identical_to_oracle"] is True, "the other objects still ran"
+
+
 def test_bench_eight_ranks_on_one_gpu():
     """`python bench.py --gpus 1 --ranks-per-gpu 8 --mesh-res 120`: the exact launch shape of the driver's 8-GPU scaling run
     (8 ranks, views dealt to the ranks, 8-way slab split of the mesh grid, ray-sharded BuFF view) rehearsed on one GPU over
