@@ -298,46 +298,72 @@ __global__ void perturb_intervals_kernel(const float* __restrict__ t, const floa
 //   w_k = alpha_k * T_k,  T_k = prod_{j<k} (1 - alpha_j + 1e-10),  alpha_k = 1 - exp(-relu(sigma_k + noise_k) * dist_k)
 //   dL/dw_k = G_rgb . rgb_k + G_acc + G_depth * t_k + G_w[k] (- sum(G_rgb) with a white background)
 //   dL/dalpha_k = dL/dw_k * T_k - (sum_{j>k} dL/dw_j * w_j) / (1 - alpha_k + 1e-10)
-// One thread per ray, two sweeps (T_k and alpha_k are parked in the output rows between them).
-__global__ __launch_bounds__(64) void composite_backward_kernel(const float* __restrict__ radiance,
-                                                                const float* __restrict__ t,
-                                                                const float* __restrict__ dirs,
-                                                                const float* __restrict__ noise, int64_t rays, int samples,
-                                                                int white_bg, nm_bundle_grads g,
-                                                                float* __restrict__ grad_radiance) {
-    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per ray, lane owns PER consecutive samples (the forward kernel's layout): T_k from the same fp64 exclusive
+// product scan as the forward, the suffix sums sum_{j>k} dL/dw_j * w_j from an fp64 suffix scan (reverse lane order).
+// (Until round 5: one THREAD per ray, two sequential sweeps over its samples with T_k / alpha_k parked in the output rows --
+// 2048 threads for a 2048-ray batch, 0.12 ms per call, 0.25 ms of every training iteration.)
+template <int PER>
+__global__ __launch_bounds__(256) void composite_backward_kernel(const float* __restrict__ radiance,
+                                                                 const float* __restrict__ t,
+                                                                 const float* __restrict__ dirs,
+                                                                 const float* __restrict__ noise, int64_t rays, int samples,
+                                                                 int white_bg, nm_bundle_grads g,
+                                                                 float* __restrict__ grad_radiance) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= rays) return;
     const float norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
     const float* tr = t + ray * samples;
     const f32x4* rr = reinterpret_cast<const f32x4*>(radiance) + ray * samples;
     f32x4* out = reinterpret_cast<f32x4*>(grad_radiance) + ray * samples;
-    double run = 1.0;
-    for (int s = 0; s < samples; ++s) {
-        float dist = (s + 1 < samples) ? (tr[s + 1] - tr[s]) : 1e10f;
-        dist = dist * norm;
-        const float sig = fmaxf(rr[s][3] + (noise ? noise[ray * samples + s] : 0.0f), 0.0f);
-        const float alpha = 1.0f - expf(-sig * dist);
-        out[s] = f32x4{alpha, dist, 0.0f, (float)run};
-        run *= (double)((1.0f - alpha) + 1e-10f);
-    }
     float gr = 0.0f, gg = 0.0f, gb = 0.0f;
     if (g.d_rgb_map) { gr = g.d_rgb_map[3 * ray]; gg = g.d_rgb_map[3 * ray + 1]; gb = g.d_rgb_map[3 * ray + 2]; }
     const float gacc = (g.d_acc_map ? g.d_acc_map[ray] : 0.0f) - (white_bg ? (gr + gg + gb) : 0.0f);
     const float gdepth = g.d_depth_map ? g.d_depth_map[ray] : 0.0f;
-    float suffix = 0.0f;   // sum_{j>k} dL/dw_j * w_j
-    for (int s = samples - 1; s >= 0; --s) {
-        const f32x4 parked = out[s];
-        const float alpha = parked[0], dist = parked[1], T = parked[3];
-        const f32x4 rad = rr[s];
-        const float w = alpha * T;
-        float dw = (gr * rad[0] + gg * rad[1] + gb * rad[2]) + gacc + gdepth * tr[s];
-        if (g.d_weights) dw += g.d_weights[ray * samples + s];
-        const float keep = (1.0f - alpha) + 1e-10f;
-        const float dalpha = dw * T - suffix / keep;
-        suffix += dw * w;
-        const float raw = rad[3] + (noise ? noise[ray * samples + s] : 0.0f);
-        const float dsigma = raw > 0.0f ? dalpha * dist * (1.0f - alpha) : 0.0f;
-        out[s] = f32x4{w * gr, w * gg, w * gb, dsigma};
+
+    float alpha[PER], dist[PER], dw[PER], raw[PER];
+    f32x4 rad[PER];
+    double local = 1.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int s = lane * PER + q;
+        alpha[q] = 0.0f; dist[q] = 0.0f; dw[q] = 0.0f; raw[q] = 0.0f; rad[q] = f32x4{0, 0, 0, 0};
+        if (s < samples) {
+            const float ts = tr[s];
+            rad[q] = rr[s];
+            float d = (s + 1 < samples) ? (tr[s + 1] - ts) : 1e10f;
+            d = d * norm;
+            dist[q] = d;
+            raw[q] = rad[q][3] + (noise ? noise[ray * samples + s] : 0.0f);
+            alpha[q] = 1.0f - expf(-fmaxf(raw[q], 0.0f) * d);
+            local *= (double)((1.0f - alpha[q]) + 1e-10f);
+            dw[q] = (gr * rad[q][0] + gg * rad[q][1] + gb * rad[q][2]) + gacc + gdepth * ts;
+            if (g.d_weights) dw[q] += g.d_weights[ray * samples + s];
+        }
+    }
+    double run = wave_exclusive_scan<true>(local, lane);      // product of everything before this lane
+    float T[PER];
+    double own = 0.0;                                          // sum of dL/dw_j * w_j over this lane's samples
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        T[q] = (float)run;                                     // fp64 running product rounded per element, as the forward
+        run *= (double)((1.0f - alpha[q]) + 1e-10f);
+        own += (double)(dw[q] * (alpha[q] * T[q]));
+    }
+    // suffix over the lanes above this one: exclusive additive scan in reversed lane order
+    double after = wave_exclusive_scan<false>(__shfl(own, 63 - lane), lane);
+    double suffix = __shfl(after, 63 - lane);
+#pragma unroll
+    for (int q = PER - 1; q >= 0; --q) {
+        const int s = lane * PER + q;
+        if (s < samples) {
+            const float w = alpha[q] * T[q];
+            const float keep = (1.0f - alpha[q]) + 1e-10f;
+            const float dalpha = dw[q] * T[q] - (float)suffix / keep;
+            suffix += (double)(dw[q] * w);
+            const float dsigma = raw[q] > 0.0f ? dalpha * dist[q] * (1.0f - alpha[q]) : 0.0f;
+            out[s] = f32x4{w * gr, w * gg, w * gb, dsigma};
+        }
     }
 }
 
@@ -460,9 +486,18 @@ int nm_composite_backward(const float* d_radiance, const float* d_t, const float
     NM_REQUIRE(d_radiance && d_t && d_dirs && grads && d_grad_radiance && rays >= 0, "bad argument");
     NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
     if (rays == 0) return 0;
-    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((rays + 63) / 64)), dim3(64), 0,
-                       static_cast<hipStream_t>(stream), d_radiance, d_t, d_dirs, d_noise, rays, samples, white_background,
-                       *grads, d_grad_radiance);
+    const dim3 grid((unsigned)((rays + 3) / 4)), block(256);
+#define NM_COMPOSITE_BWD(P)                                                                                                     \
+    hipLaunchKernelGGL(composite_backward_kernel<P>, grid, block, 0, static_cast<hipStream_t>(stream), d_radiance, d_t, d_dirs, \
+                       d_noise, rays, samples, white_background, *grads, d_grad_radiance)
+    switch ((samples + 63) / 64) {
+        case 1: NM_COMPOSITE_BWD(1); break;
+        case 2: NM_COMPOSITE_BWD(2); break;
+        case 3: NM_COMPOSITE_BWD(3); break;
+        case 4: NM_COMPOSITE_BWD(4); break;
+        default: NM_COMPOSITE_BWD(8); break;
+    }
+#undef NM_COMPOSITE_BWD
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -95,6 +95,29 @@ int main(int argc, char** argv) {
     if (hipMemcpy(out, dl.d_last, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return 9;
     fwrite(out, sizeof(float), (size_t)n * 4, f);
 
+    /* ---- one weight gradient from plain C: grad(layers_xyz[0].weight) = d_h[1]^T @ tape.h[0], n = 1000 rows (NOT a multiple
+     *      of 16: nm_weight_grad_ex takes any row count) + its bias gradient, and the fc_alpha / fc_rgb head rows */
+    {
+        const int cus = nm_mlp_num_cus(mlp);
+        void* d_ws;
+        float *d_dw, *d_db, *d_hw;
+        hipMalloc(&d_ws, (size_t)nm_weight_grad_workspace_bytes_ex(H, H, H, H, cus));
+        hipMalloc((void**)&d_dw, (size_t)H * H * 4); hipMalloc((void**)&d_db, (size_t)H * 4); hipMalloc((void**)&d_hw, (size_t)4 * H * 4);
+        if (nm_weight_grad_ex(cus, dl.d_h + (size_t)n * H, H, H, tape.d_h, H, H, n, d_ws, d_dw, H, 0, d_db, NULL)) {
+            fprintf(stderr, "weight_grad_ex: %s\n", nm_last_error()); return 14;
+        }
+        float* g = (float*)malloc((size_t)(H * H + H + 4 * H) * 4);
+        if (hipMemcpy(g, d_dw, (size_t)H * H * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+        if (hipMemcpy(g + H * H, d_db, (size_t)H * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+        void* d_hws;
+        hipMalloc(&d_hws, (size_t)nm_head_grad_workspace_bytes_ex(H));
+        if (nm_head_grad_ex(dl.d_last, tape.d_h + (size_t)(L - 1) * n * H, H, H, n, d_hws, d_hw, NULL, NULL)) {
+            fprintf(stderr, "head_grad_ex: %s\n", nm_last_error()); return 15;
+        }
+        if (hipMemcpy(g + H * H + H, d_hw, (size_t)4 * H * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+        fwrite(g, sizeof(float), (size_t)(H * H + H + 4 * H), f);
+    }
+
     /* ---- nm_render_rays: NeRFModel.forward in one call (src/models/model_nerf.py:37-78) */
     {
         enum { R = 256, NC = 16, NF = 24 };

@@ -41,7 +41,7 @@ def test_c_program_through_the_c_abi(tmp_path):
     res = subprocess.run([str(exe), str(tmp_path / "weights.bin"), str(tmp_path / "points.bin"), str(n), str(tmp_path / "out.bin")],
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
-    assert "abi 3" in res.stdout
+    assert "abi 4" in res.stdout
     blob = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     mlp_part = n * (4 + 4 + 64 + 4)
     rest = blob[mlp_part:]
@@ -60,6 +60,13 @@ def test_c_program_through_the_c_abi(tmp_path):
         ref_g = w64[name].grad.numpy()
         assert np.abs(ours - ref_g).max() <= 2e-4 * np.abs(ref_g).max(), name
 
+    # ---- nm_weight_grad_ex / nm_head_grad_ex from C on n = 1000 rows (ragged): layers_xyz.0's gradient, fc_alpha's row
+    Hh = 64
+    gw, rest = rest[:Hh * Hh + Hh + 4 * Hh], rest[Hh * Hh + Hh + 4 * Hh:]
+    for name, ours in (("layers_xyz.0.weight", gw[:Hh * Hh].reshape(Hh, Hh)), ("layers_xyz.0.bias", gw[Hh * Hh:Hh * Hh + Hh]),
+                       ("fc_alpha.weight", gw[Hh * Hh + Hh:].reshape(4, Hh)[3:4])):
+        ref_g = w64[name].grad.numpy()
+        assert np.abs(ours - ref_g).max() <= 2e-4 * np.abs(ref_g).max(), name
     # ---- nm_render_rays from C: 256 rays, 16 + 24 samples, one network as coarse and fine
     R, G = 256, 24
     img, rest = rest[:4 * R], rest[4 * R:]
