@@ -31,9 +31,22 @@ namespace nm {
 constexpr int G_ENC_STEPS = 24;     // k-steps one encoding may span: (3 F + 1) / 2 + include_input <= 24  (F <= 15; F = 16 without input)
 constexpr int G_ENC_ARGS = 2 * G_ENC_STEPS;
 
+// Dynamic LDS of the generic kernels beyond the weight ring -- ONE definition for the kernels' carve-up and for every launcher
+// (nerf_mlp.hip: inference; nerf_train.hip: taping forward, delta kernel).  Forward / taping: biases (layer1 | layers_xyz.* |
+// fc_feat | layers_dir.0 | fc_alpha.b | fc_rgb.b[3]: HP (1 + L) + HPD + 4), fc_alpha's row (HP), the colour rows (3 HP: fc_out's
+// three HP-wide rows of a use_viewdirs = 0 network, or fc_rgb's three HPD-wide ones), then the two encoding argument tables.
+__host__ __device__ constexpr int g_bias_floats(int nt, int layers) { return 16 * nt * (1 + layers) + 16 * ((nt + 1) / 2) + 4; }
+__host__ __device__ constexpr int g_head_floats(int nt) { return 16 * nt + 3 * 16 * nt; }
+struct GEncArg;
+__host__ inline int g_lds_bytes(int ring_bytes, int nt, int layers);      // defined below GEncArg
+__host__ inline int g_bwd_lds_bytes(int ring_bytes, int nt) { return ring_bytes + g_head_floats(nt) * 4; }
+
 // one encoding argument a < 3 F: coordinate a / F times frequency band a % F (modules.py:30-33, coordinate-major);
 // a >= 3 F (the odd tail): band 0 -> sin 0 / cos 1 against zero weights
 struct GEncArg { float band; int32_t coord; };
+__host__ inline int g_lds_bytes(int ring_bytes, int nt, int layers) {
+    return ring_bytes + (g_bias_floats(nt, layers) + g_head_floats(nt)) * 4 + 2 * G_ENC_ARGS * (int)sizeof(GEncArg);
+}
 
 // One GEMM stage of the generic kernel: acc[NT tiles] += W_stage * b, chunk by chunk through the 2-slot ring.
 // On entry the stage's first chunk is resident in slot `par`; on exit the chunk (tail_src, tail_bytes) -- the first chunk of
@@ -175,12 +188,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp
     constexpr int FIRST_HD = (KH < KCH ? KH : KCH) * STEPD;     // ... of layers_dir[0]'s hidden columns
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_bias = reinterpret_cast<float*>(lds + 2 * SLOT);
-    const int nbias = HP * (1 + num_layers) + HPD + 4;          // layer1 | layers_xyz.* | fc_feat | layers_dir.0 | fc_alpha.b | fc_rgb.b[3]
+    const int nbias = g_bias_floats(NT, num_layers);            // layer1 | layers_xyz.* | fc_feat | layers_dir.0 | fc_alpha.b | fc_rgb.b[3]
     float* lds_walpha = lds_bias + nbias;                       // [4][HP / 4]
     float* lds_wrgb = lds_walpha + HP;                          // [3][4][HPD / 4], or [3][4][HP / 4] for a use_viewdirs = 0 network
     const bool flat = density_only == 2;
     const int nrgb = flat ? 3 * HP : 3 * HPD;
-    GEncArg* lds_tab = reinterpret_cast<GEncArg*>(lds_wrgb + (3 * HP > 3 * HPD ? 3 * HP : 3 * HPD));   // [2][G_ENC_ARGS]
+    GEncArg* lds_tab = reinterpret_cast<GEncArg*>(lds_walpha + g_head_floats(NT));   // [2][G_ENC_ARGS]
     for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
     for (int i = threadIdx.x; i < HP; i += NW * 64) lds_walpha[i] = args.walpha[i];
     for (int i = threadIdx.x; i < nrgb; i += NW * 64) lds_wrgb[i] = args.wrgb[i];

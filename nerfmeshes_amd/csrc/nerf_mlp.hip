@@ -220,8 +220,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     const int rgb_floats = density_only == 2 ? 3 * H : 3 * H / 2;
     int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + rgb_floats) * 4 + 255) & ~255) : 0);
     if (p->generic_nt) {    // padded widths, both head layouts, the two argument tables (mlp_device_g.h)
-        const int HP = 16 * p->generic_nt, HPD = 16 * ((p->generic_nt + 1) / 2);
-        lds_bytes = p->ring_bytes + (HP * (1 + L) + HPD + 4 + HP + 3 * HP) * 4 + 2 * G_ENC_ARGS * (int)sizeof(GEncArg);
+        lds_bytes = g_lds_bytes(p->ring_bytes, p->generic_nt, L);
     }
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     // the dynamic-LDS attribute is per device: tracked per (device, plan)

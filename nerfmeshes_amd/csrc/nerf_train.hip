@@ -11,6 +11,10 @@
 //   * weight gradients dW = delta^T @ activation are plain (H x n) @ (n x H) GEMMs over those rows: library work
 //     (rocBLAS through torch.mm in hip_ops.py), per the "library GEMMs only for plain GEMMs" rule.
 // Roofline: MFMA.  557 056 MAC / sample for the 8x256 net (vs 593 408 forward).
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "nm_internal.h"
 #include "mlp_device.h"
 #ifdef NM_ABLATIONS
@@ -250,9 +254,21 @@ static unsigned persistent_grid(int64_t wg_iters, int num_cus) {
     return (unsigned)grid;
 }
 
+// The dynamic-LDS attribute of a kernel is per device; it is raised once per (device, kernel) and when a call needs more --
+// not on every launch -- under a lock (two host threads training two models would otherwise race on it), as the inference
+// launcher does.
 static int set_lds(const void* fn, int bytes) {
     NM_REQUIRE(bytes <= 160 * 1024, "LDS budget exceeded");
-    NM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    static std::mutex lock;
+    static std::map<std::pair<int, const void*>, int> have;
+    int dev = 0;
+    NM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> guard(lock);
+    int& cur = have[{dev, fn}];
+    if (cur < bytes) {
+        NM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        cur = bytes;
+    }
     return 0;
 }
 
@@ -280,8 +296,8 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
         a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
         a.tiles = (a.n + 15) / 16;
         const MlpPlan* p = m->plan;
-        const int HP = 16 * p->generic_nt, L = d.num_layers;
-        const int lds_bytes = p->ring_bytes + (HP * (1 + L) + 16 * ((p->generic_nt + 1) / 2) + 4 + HP + 3 * HP) * 4 + 2 * G_ENC_ARGS * (int)sizeof(GEncArg);
+        const int L = d.num_layers;
+        const int lds_bytes = g_lds_bytes(p->ring_bytes, p->generic_nt, L);
         if (int rc = set_lds((const void*)p->kernel_tape, lds_bytes)) return rc;
         const int64_t wg_iters = (a.n + p->wg_samples - 1) / p->wg_samples;
         hipLaunchKernelGGL(p->kernel_tape, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(p->NW * 64), lds_bytes,
@@ -337,8 +353,7 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
         a.d_h = deltas->d_h; a.d_feat = deltas->d_feat; a.d_v = deltas->d_v; a.d_last = deltas->d_last;
         a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
         const MlpPlan* p = m->plan;
-        const int HP = 16 * p->generic_nt;
-        const int lds_bytes = p->ring_bytes + (HP + 3 * HP) * 4;
+        const int lds_bytes = g_bwd_lds_bytes(p->ring_bytes, p->generic_nt);
         if (int rc = set_lds((const void*)p->kernel_bwd, lds_bytes)) return rc;
         const int64_t wg_iters = (n + p->wg_samples - 1) / p->wg_samples;
         hipLaunchKernelGGL(p->kernel_bwd, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(p->NW * 64), lds_bytes,

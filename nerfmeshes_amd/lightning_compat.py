@@ -130,20 +130,31 @@ class TensorBoardLogger:
                  if d.startswith("version_") and d.split("_")[1].isdigit()]
         return max(taken) + 1 if taken else 0
 
-    @property
-    def version(self):
-        """`version_N` with N the next free index.  Under a launcher (one process per GPU) rank 0 picks it and the
-        others take rank 0's answer: every rank scanning the directory for itself races -- the first one through creates
-        `version_N/checkpoints` (PathParser.parse) and the next one then numbers itself N + 1."""
+    def resolve_version(self):
+        """Fix `version_N` for this run; called where EVERY rank passes (PathParser.parse, Trainer.fit).  Under a launcher
+        (one process per GPU) rank 0 picks the next free index and the others take its answer -- every rank scanning the
+        directory for itself races: the first one through creates `version_N/checkpoints` and the next one then numbers
+        itself N + 1.  The one collective of this class lives here; the properties below never communicate."""
         if self._version is None:
-            from . import dist as nd
-            rank, world, _ = nd.init_from_env()          # no-op without a launcher environment
-            if world > 1:
-                box = [self._next_free_version() if rank == 0 else None]
-                torch.distributed.broadcast_object_list(box, src=0)
+            dist = torch.distributed
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                box = [self._next_free_version() if dist.get_rank() == 0 else None]
+                dist.broadcast_object_list(box, src=0)
                 self._version = box[0]
             else:
                 self._version = self._next_free_version()
+        return self._version
+
+    @property
+    def version(self):
+        """`version_N`.  A plain read: in a multi-rank job the version must have been fixed by `resolve_version()` (which
+        every rank calls) -- a property that broadcast would hang the moment only rank 0 read it (`log_hyperparams`)."""
+        if self._version is None:
+            dist = torch.distributed
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise RuntimeError("TensorBoardLogger.version read before resolve_version() in a multi-rank job: call "
+                                   "logger.resolve_version() on every rank first (PathParser.parse and Trainer.fit do)")
+            self._version = self._next_free_version()
         return self._version
 
     @property
@@ -344,6 +355,8 @@ class Trainer:
         model.trainer, model.logger = self, self.logger
         model.to(device)
         self._sync_replicas(model, nd, rank, world)
+        if self.logger is not None and hasattr(self.logger, "resolve_version"):
+            self.logger.resolve_version()        # every rank is here: the logger's only collective (a no-op when PathParser did it)
         model.setup("fit")                       # BaseModel.setup: datasets + min/max steps + validation period
         if self.logger is not None and rank == 0:
             self.logger.log_hyperparams(model.hparams)

@@ -124,6 +124,10 @@ class PathParser:
         if create_logger:
             os.makedirs(Path(self.log_root_dir) / self.log_name, exist_ok=True)
             logger = TensorBoardLogger(self.log_root_dir, self.log_name, version=self.log_version)
+            if hasattr(logger, "resolve_version"):      # the stand-in: one broadcast, here, where every rank passes
+                from . import dist as nd
+                nd.init_from_env()                       # joins the launcher's process group (no-op without one)
+                logger.resolve_version()
             self.log_dir = Path(logger.log_dir)
         if self.log_dir is None:   # config-only parse without a logger: mirror Lightning's first version dir
             self.log_dir = Path(self.log_root_dir) / self.log_name / "version_0"

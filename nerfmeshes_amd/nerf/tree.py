@@ -137,7 +137,10 @@ class TreeSampling:
         order = getattr(self, "tie_order", "auto")
         auto = order == "auto"
         if auto:
-            order = "reference" if getattr(self, "training", False) else "stable"
+            # the reference's own ids (its three unstable sorts restated, NM_TIES_REFERENCE) in training AND in eval since round 5:
+            # "bit-exact for index work" holds by default; 4.0 instead of 1.2 ms per 65 536 x 192 samples, < 3 % of a BuFF view.
+            # `tree.tie_order = "stable"` selects the geometrically consistent order (every id = the voxel its sample lies in).
+            order = "reference"
         if auto and order == "reference" and self.voxels.shape[0] > hip_ops.BUFF_REFERENCE_MAX_VOXELS:
             order = self._fall_back_to_stable(f"{self.voxels.shape[0]} voxels > {hip_ops.BUFF_REFERENCE_MAX_VOXELS}")
         return hip_ops.buff_intersect(self.voxels, origins, dirs, float(near), float(far), int(samples_count), ids=order)

@@ -140,7 +140,7 @@ def test_reads_a_cache_written_by_the_reference(tmp_path):
 
 
 def test_tie_order_auto_falls_back_to_stable_beyond_the_reference_kernels_limit(monkeypatch):
-    """`tree.tie_order = "auto"` while training wants the reference's voxel-id order (nm_buff_intersect_ex, NM_TIES_REFERENCE),
+    """`tree.tie_order = "auto"` wants the reference's voxel-id order (nm_buff_intersect_ex, NM_TIES_REFERENCE),
     whose kernel holds at most 8192 voxels: beyond that "auto" continues in the stable order and says so ONCE instead of
     failing in the middle of a training run; an explicit "reference" is passed through (and would raise in the library)."""
     import warnings
@@ -164,7 +164,11 @@ def test_tie_order_auto_falls_back_to_stable_beyond_the_reference_kernels_limit(
     tree.training = False
     tree.tie_order = "auto"
     tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
-    assert seen[-1] == "stable"                        # evaluation: the geometrically consistent order, whatever the size
+    assert seen[-1] == "stable"                        # still beyond the limit: the fallback, in evaluation as in training
+    tree.voxels = torch.zeros(64, 2, 3)
+    tree.tie_order = "auto"
+    tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
+    assert seen[-1] == "reference"                     # round 5: the reference's own ids by default in evaluation too
     tree.tie_order = "reference"
     tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
     assert seen[-1] == "reference"                     # explicit request: not second-guessed

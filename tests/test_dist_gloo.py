@@ -303,7 +303,13 @@ def _fit_worker(rank, world, port, tmp, deterministic, out):
                 return {"loss": self.net(x).pow(2).mean(), "log": {}}
 
         logger = LC.TensorBoardLogger(tmp, "run")
-        os.makedirs(os.path.join(logger.log_dir, "checkpoints"), exist_ok=True)      # what PathParser.parse does next
+        try:                                              # a bare property read must not communicate: it raises instead
+            logger.version
+            raise AssertionError("version read before resolve_version() must raise in a multi-rank job")
+        except RuntimeError as e:
+            assert "resolve_version" in str(e)
+        logger.resolve_version()                          # what PathParser.parse does, on every rank ...
+        os.makedirs(os.path.join(logger.log_dir, "checkpoints"), exist_ok=True)      # ... before it creates the directory
         model = Toy()
         first = [p.detach().clone() for p in model.parameters()]
         LC.Trainer(logger=logger, max_epochs=1).fit(model)

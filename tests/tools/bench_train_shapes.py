@@ -106,6 +106,12 @@ def main():
             iteration()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / iters * 1e3
+        from nerfmeshes_amd import train_ops
+        train_ops.profile_stages(True)
+        for _ in range(iters):
+            iteration()
+        stages = {k: round(v / iters, 3) for k, v in train_ops.profile_stages(False).items()}
+        stages["rest"] = round(ms - sum(stages.values()), 3)
         fwd, delta, dw = flops_per_sample(kw, viewdirs)
         flops = samples * (fwd + delta + dw)
         variant = model.model_coarse.hip().kernel_variant()[0]
@@ -113,7 +119,11 @@ def main():
                      "rays_per_s": round(rays / ms * 1e3), "kernel_family": "generic class %d" % (variant - 1000) if variant >= 1000 else "tuned",
                      "algorithmic_tflop_per_iteration": round(flops / 1e12, 4),
                      "floor_ms_at_fp32_mfma_peak": round(flops / (PEAK * 1e12) * 1e3, 3),
-                     "frac_of_fp32_mfma_peak_whole_iteration": round(flops / (ms * 1e-3) / 1e12 / PEAK, 3)}
+                     "frac_of_fp32_mfma_peak_whole_iteration": round(flops / (ms * 1e-3) / 1e12 / PEAK, 3),
+                     "stage_ms": stages,
+                     "stage_frac": {"taping_forward": round(samples * fwd / (stages.get("taping_forward", 1e9) * 1e-3) / 1e12 / PEAK, 3),
+                                    "delta": round(samples * delta / (stages.get("delta", 1e9) * 1e-3) / 1e12 / PEAK, 3),
+                                    "weight_gradients": round(samples * dw / (stages.get("weight_gradients", 1e9) * 1e-3) / 1e12 / PEAK, 3)}}
         print(name, json.dumps(out[name]), flush=True)
         del iteration, model
         torch.cuda.empty_cache()
