@@ -408,10 +408,17 @@ __global__ __launch_bounds__(256) void head_reduce_g_kernel(const float* __restr
 
 // ---- host side: the planner ------------------------------------------------------------------------------------------
 typedef void (*DwGKernel)(const DwGArgs);
-#define NM_DWG_ROW(TA)                                                                                                  \
-    { &dw_kernel_g<TA, 1>, &dw_kernel_g<TA, 2>, &dw_kernel_g<TA, 3>, &dw_kernel_g<TA, 4>, &dw_kernel_g<TA, 5>,           \
-      &dw_kernel_g<TA, 6>, &dw_kernel_g<TA, 7>, &dw_kernel_g<TA, 8> }
-static const DwGKernel g_dwg_kernels[4][8] = {NM_DWG_ROW(1), NM_DWG_ROW(2), NM_DWG_ROW(3), NM_DWG_ROW(4)};
+constexpr int DWG_MAX_TA = 6, DWG_MAX_TB = 8, DWG_MAX_TILES = 36;     // tiles per wave: TA x TB <= 36 (144 accumulator registers)
+template <int TA, int TB>
+constexpr DwGKernel dwg_kernel_or_null() {
+    if constexpr (TA * TB <= DWG_MAX_TILES) return &dw_kernel_g<TA, TB>;
+    else return nullptr;
+}
+#define NM_DWG_ROW(TA)                                                                                                          \
+    { dwg_kernel_or_null<TA, 1>(), dwg_kernel_or_null<TA, 2>(), dwg_kernel_or_null<TA, 3>(), dwg_kernel_or_null<TA, 4>(),         \
+      dwg_kernel_or_null<TA, 5>(), dwg_kernel_or_null<TA, 6>(), dwg_kernel_or_null<TA, 7>(), dwg_kernel_or_null<TA, 8>() }
+static const DwGKernel g_dwg_kernels[DWG_MAX_TA][DWG_MAX_TB] = {NM_DWG_ROW(1), NM_DWG_ROW(2), NM_DWG_ROW(3), NM_DWG_ROW(4), NM_DWG_ROW(5),
+                                                                NM_DWG_ROW(6)};
 #undef NM_DWG_ROW
 
 constexpr int DWG_LDS_BYTES = 160 * 1024;
@@ -438,7 +445,9 @@ static inline void operand_image(int rows, int ld, int blk_cols, bool split, boo
 
 // Pick block split, wave arrangement, tiles per wave and rows per chunk for (out x in) from the shape alone (deterministic:
 // the same shape always runs the same summation order).  The model: matrix time of the padded tiles, HBM time of the operand
-// reads (an operand split nb ways on the OTHER side is read nb times), one barrier per chunk.
+// reads (an operand split nb ways on the OTHER side is read nb times), a fixed cost per wave and chunk, one barrier per
+// chunk, the reduction's traffic; checked against exhaustive sweeps on the machine (tests/tools/bench_dw_general.py --sweep,
+// profiles/r05_dw_general.json: within 0 - 10 % of the best geometry on every shape tried).
 static bool plan_dw_g(int out, int lda, int in, int ldb, bool a_x4, bool b_x4, int cus, DwGPlan* best) {
     const int OA = ceil_div(out, 16), OB = ceil_div(in, 16);
     static const int arr[][3] = {{4, 2, 1}, {2, 4, 1}, {8, 1, 1}, {1, 8, 1}, {2, 2, 2}, {4, 1, 2}, {1, 4, 2}, {2, 1, 4}, {1, 2, 4},
@@ -456,7 +465,7 @@ static bool plan_dw_g(int out, int lda, int in, int ldb, bool a_x4, bool b_x4, i
             for (const auto& w : arr) {
                 const int wa = w[0], wb = w[1], wk = w[2];
                 const int ta = ceil_div(OAb, wa), tb = ceil_div(OBb, wb);
-                if (ta > 4 || tb > 8) continue;
+                if (ta > DWG_MAX_TA || tb > DWG_MAX_TB || ta * tb > DWG_MAX_TILES) continue;
                 if ((ta - 1) * wa >= OAb && wa > 1) continue;      // a narrower arrangement covers the same tiles
                 if ((tb - 1) * wb >= OBb && wb > 1) continue;
                 for (int rows = 4 * wk < 16 ? 16 : 4 * wk; rows <= 256; rows *= 2) {
@@ -468,14 +477,17 @@ static bool plan_dw_g(int out, int lda, int in, int ldb, bool a_x4, bool b_x4, i
                     const int pieces_b = ceil_div(nseg * pps, 8);
                     if (4 * (imga + imgb) + DWG_SLACK > DWG_LDS_BYTES) break;
                     if (2 * (pieces_a + pieces_b) > 60) break;     // vmcnt is a 6-bit counter: two chunks in flight
-                    const int kgroups = rows / 4;
-                    // CU cycles per chunk
-                    const double mfma = 64.0 * ta * tb * kgroups / wk;                       // 8 waves' MFMAs on 4 SIMDs, 32 cycles each
-                    const double ldsr = 16.0 * (ta + tb) * kgroups / wk;                     // ds_read_b32: 2 LDS cycles each
+                    // CU cycles per chunk.  A SIMD runs two of the 8 waves; a wave's chunk is kgw k-groups of ta * tb MFMAs
+                    // (32 cycles each) + its operand reads + a fixed part (DMA issue, loop control, the counted wait); the chunk
+                    // cannot beat its operand bytes at the rate one CU draws from HBM; one barrier.  k-splitting (wk) multiplies
+                    // the partials the order-fixed reduction has to read: a per-call cost, weighed at a typical batch of rows.
+                    const double kgw = rows / (4.0 * wk);
+                    const double wave = 32.0 * ta * tb * kgw + 6.0 * (ta + tb) * kgw + 400.0 + 40.0 * (pieces_a + pieces_b);
                     const double hbm = 4.0 * rows * ((nba > 1 ? wa * ta * 16 : lda) + (nbb > 1 ? wb * tb * 16 : ldb)) / 7.5;
-                    const double sync = 500.0 + 40.0 * (pieces_a + pieces_b);
-                    const double wg = (mfma + 0.3 * ldsr > hbm ? mfma + 0.3 * ldsr : hbm) + sync;
-                    const double cost = wg * nba * nbb / rows;
+                    const double chunk = (2.0 * wave > hbm ? 2.0 * wave : hbm) + 300.0;
+                    const double partial_bytes = (double)(cus / (nba * nbb)) * wk * (nba * wa * ta * 16.0) * (nbb * wb * tb * 16.0) * 4.0;
+                    const double reduce = 2.0 * partial_bytes / 2270.0 * cus / 262144.0;       // device cycles -> CU cycles per row
+                    const double cost = chunk * nba * nbb / rows + reduce;
                     if (!found || cost < best->cost * 0.999) {
                         *best = DwGPlan{nba, nbb, wa, wb, wk, ta, tb, rows, 0, lsa, lsb, cost};
                         found = true;
@@ -518,7 +530,7 @@ extern "C" int64_t nm_weight_grad_workspace_bytes_ex(int32_t out_features, int32
 }
 
 // The general form of nm_weight_grad: d_delta (n, >= out_features) with row stride delta_stride, d_act (n, >= in_features) with
-// row stride act_stride (floats), any n >= 1, any widths with ceil(width / 16) <= 4 * 8 * 8 tiles.
+// row stride act_stride (floats), any n >= 1, any widths the planner can tile (up to 8 blocks of 8 x 6 / 8 x 8 tiles per side).
 extern "C" int nm_weight_grad_ex(int device_cus, const float* d_delta, int32_t out_features, int32_t delta_stride,
                                  const float* d_act, int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace,
                                  float* d_dw, int32_t dw_ld, int32_t dw_col0, float* d_dbias, void* stream_) {

@@ -107,10 +107,12 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / iters * 1e3
         from nerfmeshes_amd import train_ops
-        train_ops.profile_stages(True)
-        for _ in range(iters):
+        per_iter = []
+        for _ in range(iters):                 # medians over the iterations: one allocator / launch hiccup must not skew a stage
+            train_ops.profile_stages(True)
             iteration()
-        stages = {k: round(v / iters, 3) for k, v in train_ops.profile_stages(False).items()}
+            per_iter.append(train_ops.profile_stages(False))
+        stages = {k: round(sorted(d.get(k, 0.0) for d in per_iter)[len(per_iter) // 2], 3) for k in per_iter[0]}
         stages["rest"] = round(ms - sum(stages.values()), 3)
         fwd, delta, dw = flops_per_sample(kw, viewdirs)
         flops = samples * (fwd + delta + dw)
