@@ -257,9 +257,10 @@ int nm_mlp_forward_train(nm_mlp* mlp, const float* d_origins, int origins_per_ra
                          float* d_radiance, void* stream);
 
 /* Back-propagation through the network: d_grad_radiance (n,4) = dL/d(sigmoid(rgb), sigma) and the
- * forward's own d_radiance (n,4) -> deltas.  Weight gradients are then plain GEMMs the caller runs with
- * its BLAS: e.g. grad(layers_xyz[i].weight) = deltas.d_h[1+i]^T @ tape.d_h[i] (@ enc_xyz for the skip
- * columns), grad(bias) = column sums (nerfmeshes_amd/hip_ops.py:HipMLP.backward lists all of them). */
+ * forward's own d_radiance (n,4) -> deltas.  The weight gradients are products of those rows with the tape rows:
+ * grad(layers_xyz[i].weight) = deltas.d_h[1+i]^T @ tape.d_h[i] (@ the encoding rows for the skip columns), grad(bias) =
+ * column sums -- nm_weight_grad_ex / nm_head_grad_ex below compute them for every shape (nerfmeshes_amd/train_ops.py:
+ * backward lists all of them; tests/cabi_smoke.c does one from plain C). */
 int nm_mlp_backward(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
                     const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream);
 
