@@ -6,6 +6,7 @@
 
 #include "nm_internal.h"
 #include "mlp_device_g.h"
+#include "nerf_layerwise.h"
 
 namespace nm {
 
@@ -135,6 +136,49 @@ static void pack_head_row_g(std::vector<int32_t>& out, int tensor, int row_offse
 }
 
 struct BlobLayout { size_t off_bias, off_wa, off_wr, off_bwd; uint32_t skip_mask; int chx, chd; };
+
+// ---- layer-wise path (nerf_layerwise.hip): networks beyond the fused families' limits -----------------------------------
+// A plan that launches nothing by itself: launch_mlp_timed / the training entry points route such a handle to the layer-wise
+// evaluator.  nm_mlp_kernel_variant reports 2000.
+static const MlpPlan g_layerwise_plan = {0, 0, 0, 8, 0, 2000, 0, false, nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
+
+// The blob of a layer-wise handle as an index map: per Linear its transpose (in x out: the forward products' A operand), the
+// matrix itself (out x in: the delta chain's), its bias; every piece 256-byte aligned (16-byte DMA pieces need it).
+static void build_index_layerwise(std::vector<int32_t>& index, const nm_mlp_desc& d, LwNet* net) {
+    const int H = d.hidden_size, L = d.num_layers, FX = d.num_encoding_fn_xyz, FD = d.num_encoding_fn_dir;
+    const bool no_view = d.use_viewdirs == 0;
+    const int dx = 6 * FX + (d.include_input_xyz ? 3 : 0), dd = no_view ? 0 : 6 * FD + (d.include_input_dir ? 3 : 0);
+    auto linear = [&](int tw, int tb, int out, int in, int nbias) {
+        LwLinear l;
+        l.out = out; l.in = in;
+        pad_to(index, 64); l.wt = index.size();
+        for (int k = 0; k < in; ++k)
+            for (int o = 0; o < out; ++o) index.push_back((tw << 24) | (o * in + k));
+        pad_to(index, 64); l.w = index.size();
+        pack_range(index, tw, out * in);
+        pad_to(index, 64); l.b = index.size();
+        pack_range(index, tb, nbias);
+        return l;
+    };
+    net->L = L; net->H = H; net->H2 = H / 2; net->dx = dx; net->dd = dd; net->flat = no_view ? 1 : 0;
+    net->fx = FX; net->fd = no_view ? 0 : FD; net->inc_x = d.include_input_xyz ? 1 : 0; net->inc_d = d.include_input_dir ? 1 : 0;
+    net->skip_mask = 0;
+    net->layer1 = linear(T_L1W, T_L1B, H, dx, H);
+    for (int i = 0; i < L - 1; ++i) {
+        const bool skip = is_skip(d, i);
+        if (skip) net->skip_mask |= 1u << i;
+        net->xyz[i] = linear(T_XYZ0 + 2 * i, T_XYZ0 + 2 * i + 1, H, H + (skip ? dx : 0), H);
+    }
+    net->alpha = linear(T_ALPHAW, T_ALPHAB, 1, H, 1);
+    if (no_view) {
+        net->rgb = linear(T_RGBW, T_RGBB, 3, H, 3);              // rows 0..2 of fc_out (nm_mlp_weights)
+    } else {
+        net->feat = linear(T_FEATW, T_FEATB, H, H, H);
+        net->dir = linear(T_DIRW, T_DIRB, H / 2, H + dd, H / 2);
+        net->rgb = linear(T_RGBW, T_RGBB, 3, H / 2, 3);
+    }
+    index.resize(index.size() + 1024, -1);                       // what a piece's rounding may read past the last matrix
+}
 
 // The whole blob of a generic plan as an index map (layout: mlp_device_g.h's kernels): forward stream | biases | fc_alpha |
 // fc_rgb (or fc_out's colour rows) | backward stream (the transposed layers in reverse order, hidden columns only).
@@ -330,13 +374,14 @@ static std::vector<ProfRec> g_prof;
 // the trunk as in mode 1, then all four rows of fc_out (models.py:77-79).
 static int launch_mlp_timed(const nm_mlp* m, const MlpArgs& a, int density_only, hipStream_t stream) {
     if (!density_only && !m->desc.use_viewdirs) density_only = 2;
-    if (!g_prof_on || a.n <= 0) return launch_mlp(m, a, density_only, stream);
+    auto launch = [&]() { return m->lw ? layerwise_forward(const_cast<nm_mlp*>(m), a, density_only, stream) : launch_mlp(m, a, density_only, stream); };
+    if (!g_prof_on || a.n <= 0) return launch();
     ProfRec r;
     NM_HIP_CHECK(hipEventCreate(&r.start));
     NM_HIP_CHECK(hipEventCreate(&r.stop));
     r.flops = (double)a.n * (double)(density_only == 1 ? m->flops_density : m->flops_full);
     NM_HIP_CHECK(hipEventRecord(r.start, stream));
-    const int rc = launch_mlp(m, a, density_only, stream);
+    const int rc = launch();
     NM_HIP_CHECK(hipEventRecord(r.stop, stream));
     g_prof.push_back(r);
     return rc;
@@ -426,29 +471,39 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     // constructor accepts up to hidden_size 512 and 24 k-steps per encoding.  (A network without view directions has no
     // direction encoding: any tuned kernel of that width / xyz encoding runs it.)
     const MlpPlan* plan = (!force_generic && FX <= MAX_FREQ_XYZ && (no_view || FD <= MAX_FREQ_DIR)) ? find_mlp_plan(H, FX, no_view ? 4 : FD) : nullptr;
+    LwNet* lw_net = nullptr;
     if (!plan) {
         plan = find_generic_plan(H);
-        if (!plan) {
-            set_error("hidden_size=" + std::to_string(H) + " exceeds the widest instantiated kernel class (512): the activations of a "
-                      "wider layer do not fit the register file of one wavefront");
-            return 3;
-        }
         const int steps_x = (3 * FX + 1) / 2 + (d.include_input_xyz ? 1 : 0), steps_d = (3 * FD + 1) / 2 + (d.include_input_dir ? 1 : 0);
-        if (steps_x > G_ENC_STEPS || (!no_view && steps_d > G_ENC_STEPS)) {
-            set_error("an encoding of " + std::to_string(FX) + " / " + std::to_string(FD) + " functions spans more than " +
-                      std::to_string(G_ENC_STEPS) + " MFMA k-steps (limit: 15 functions, or 16 without the input itself)");
-            return 3;
-        }
+        const bool long_encoding = steps_x > G_ENC_STEPS || (!no_view && steps_d > G_ENC_STEPS);
         if (precision != NM_PREC_F32) {
             set_error("precision bf16x3 is instantiated for hidden_size 256 with 6 or 10 xyz / 4 direction frequencies only");
             return 3;
+        }
+        if (!plan || long_encoding) {
+            // beyond the fused families -- hidden_size > 512 (the activations of a wider layer do not fit the register file of one
+            // wavefront) or an encoding of more than 24 MFMA k-steps (15 functions) --: the layer-wise path (nerf_layerwise.hip)
+            if (FX > LW_MAX_FREQ || (!no_view && FD > LW_MAX_FREQ)) {
+                set_error("an encoding of " + std::to_string(FX) + " / " + std::to_string(FD) + " functions: the limit is " +
+                          std::to_string(LW_MAX_FREQ) + " per input (frequency 2^31 is past fp32's integer range)");
+                return 3;
+            }
+            if ((int64_t)H * (H + dx) >= (1 << 24)) {
+                set_error("hidden_size=" + std::to_string(H) + ": a weight matrix of more than 2^24 elements exceeds the packer's index map");
+                return 3;
+            }
+            plan = &g_layerwise_plan;
+            lw_net = new LwNet();
+            std::memset(lw_net, 0, sizeof(*lw_net));
         }
     }
     const int NT = H / 16, NTD = H / 32;
 
     std::vector<int32_t> index;
     BlobLayout lay{};
-    if (plan->generic_nt) {
+    if (lw_net) {
+        build_index_layerwise(index, d, lw_net);
+    } else if (plan->generic_nt) {
         lay = build_index_generic(index, d, *plan);
     } else {
     std::vector<StepCols> enc_x, hid, hid_half, hid_skip_enc, dir_steps;
@@ -548,6 +603,11 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     m->device = device;
     m->plan = plan;
     m->precision = precision;
+    m->lw = lw_net;          // freed with the handle (also by the rollback below)
+    if (lw_net) {
+        for (int f = 0; f < FX; ++f) lw_net->bands_x[f] = w->freq_xyz[f];
+        for (int f = 0; f < FD && !no_view; ++f) lw_net->bands_d[f] = w->freq_dir[f];
+    }
     int prev_device = -1;
     (void)hipGetDevice(&prev_device);
     // every early return below (a failed hip call) gives back the half-built handle and the staging buffer and leaves the
@@ -656,6 +716,7 @@ void nm_mlp_destroy(nm_mlp* m) {
     if (m->d_tmp_b3) (void)hipFree(m->d_tmp_b3);
     if (m->d_stream_b3) (void)hipFree(m->d_stream_b3);
     if (m->d_enc_tab) (void)hipFree(m->d_enc_tab);
+    layerwise_destroy(m);
     delete m;
 }
 

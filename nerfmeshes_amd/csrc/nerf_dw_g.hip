@@ -27,6 +27,9 @@
 // Roofline: MFMA for wide layers (2 * out * in FLOP per sample against 4 * (out + in) bytes), HBM for narrow ones (64 x 64:
 // 16 FLOP/B).
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "nm_internal.h"
 #include "mlp_device.h"
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     float bias[TA];
 #pragma unroll
     for (int qa = 0; qa < TA; ++qa) bias[qa] = 0.0f;
-    const bool bias_owner = wb_i == 0 && blockIdx.z == 0;
+    const bool bias_owner = wb_i == 0 && blockIdx.z == 0 && args.partial_bias != nullptr;
 
     // this lane's operands of k-group kg of a chunk: row 4 * (kg * wk + wk_i) + g, columns 16 * (tile) + i
     const int kgw = rows / (4 * args.wk);
@@ -499,6 +502,65 @@ static bool plan_dw_g(int out, int lda, int in, int ldb, bool a_x4, bool b_x4, i
 }
 
 static bool dw_aligned(const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0; }
+
+// ---- the same kernel as a plain GEMM with a SHORT contraction and a WIDE output (layer-wise network evaluation,
+// nerf_layerwise.hip): C (out x in) = A^T B = sum_{r < rows} A[r][o] * B[r][i] with A (rows x out, ld lda), B (rows x in, ld ldb)
+// row-major -- `in` is a batch of samples (up to 2^19), `rows` a layer's input width.  One sample part (grid x = 1: every
+// workgroup walks the whole contraction), the output cut into blocks of up to 256 x 256 (grid y / z); the "partial" IS the
+// result, (out_pad x in_pad) row-major; the caller's epilogue adds the bias and applies the activation.
+DwgGemmGeometry dwg_gemm_geometry(int out, int64_t in) {
+    DwgGemmGeometry g;
+    const int tiles = ceil_div(out, 16);
+    // the block is always 256 samples wide (one 1 KiB DMA piece per row of B): wb * tb = 16 tiles
+    if (tiles <= 4) { g.wa = 1; g.wb = 8; g.ta = tiles; g.tb = 2; }  // heads, narrow layers: all 8 waves side by side over the samples
+    else if (tiles <= 8) { g.wa = 2; g.wb = 4; g.ta = ceil_div(tiles, 2); g.tb = 4; }
+    else if (tiles <= 16) { g.wa = 4; g.wb = 2; g.ta = ceil_div(tiles, 4); g.tb = 8; }
+    else { g.wa = 4; g.wb = 2; g.ta = 4; g.tb = 8; }
+    g.nba = ceil_div(tiles, g.wa * g.ta);
+    const int64_t cols = (int64_t)g.wb * g.tb * 16;
+    g.nbb = (int)((in + cols - 1) / cols);
+    g.out_pad = g.nba * g.wa * g.ta * 16;
+    g.in_pad = (int64_t)g.nbb * cols;
+    return g;
+}
+
+int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64_t ldb, int rows, float* partial, hipStream_t stream) {
+    NM_REQUIRE(A && B && partial && out >= 1 && in >= 1 && rows >= 1 && lda >= out && ldb >= in, "gemm: bad argument");
+    const DwgGemmGeometry g = dwg_gemm_geometry(out, in);
+    NM_REQUIRE(g.nbb <= 65535 && g.in_pad < (1ll << 31) && ldb < (1ll << 31), "gemm: batch too large");
+    NM_REQUIRE(((int64_t)rows + 32) * (ldb > lda ? ldb : lda) * 4 < 0xf0000000ll, "gemm: operand exceeds 32-bit offsets (use a smaller batch)");
+    constexpr int ROWS = 16;
+    DwGArgs a;
+    auto fill = [&](DwOperand& op, const float* base, int64_t ld, int blk_cols, bool split) {
+        op.base = base; op.bytes = (int64_t)rows * ld * 4; op.ld = (int)ld; op.x4 = dw_aligned(base, (int)ld);
+        operand_image(ROWS, (int)ld, blk_cols, split, op.x4, &op.ls, &op.nseg, &op.pps, &op.lstride, &op.img);
+        op.gstride = (int)(ld * 4); op.blk_cols = split ? blk_cols : 0;
+    };
+    fill(a.A, A, lda, g.wa * g.ta * 16, g.nba > 1 || lda > 256);
+    fill(a.B, B, ldb, g.wb * g.tb * 16, true);
+    a.n = rows; a.rows = ROWS; a.wa = g.wa; a.wb = g.wb; a.wk = 1;
+    a.out_pad = g.out_pad; a.in_pad = (int)g.in_pad;
+    a.partial = partial;
+    a.partial_bias = nullptr;
+    const int lds_bytes = 4 * (a.A.img + a.B.img) + DWG_SLACK;
+    NM_REQUIRE(lds_bytes <= DWG_LDS_BYTES, "gemm: LDS budget exceeded");
+    const DwGKernel kernel = g_dwg_kernels[g.ta - 1][g.tb - 1];
+    static std::mutex lock;
+    static std::map<std::pair<int, const void*>, int> have;
+    {
+        int dev = 0;
+        NM_HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> guard(lock);
+        int& cur = have[{dev, (const void*)kernel}];
+        if (cur < lds_bytes) {
+            NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            cur = lds_bytes;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(1, g.nba, g.nbb), dim3(512), lds_bytes, stream, a);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 // the kernels tuned for the shipped configs' shapes (nerf_dw.hip); -1 = "not mine"
 int64_t weight_grad_tuned_workspace_bytes(int32_t out_features, int32_t act_stride, int32_t num_cus);

@@ -22,6 +22,7 @@
 #include "mlp_device_r3.h"
 #endif
 #include "mlp_device_g.h"
+#include "nerf_layerwise.h"
 
 namespace nm {
 
@@ -257,6 +258,15 @@ static unsigned persistent_grid(int64_t wg_iters, int num_cus) {
 // The dynamic-LDS attribute of a kernel is per device; it is raised once per (device, kernel) and when a call needs more --
 // not on every launch -- under a lock (two host threads training two models would otherwise race on it), as the inference
 // launcher does.
+struct DeviceGuardT {        // the handle's device current for the call (as nerf_mlp.hip's DeviceGuard)
+    int prev = -1;
+    explicit DeviceGuardT(int want) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuardT() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static int set_lds(const void* fn, int bytes) {
     NM_REQUIRE(bytes <= 160 * 1024, "LDS budget exceeded");
     static std::mutex lock;
@@ -283,9 +293,18 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
     const nm_mlp_desc& d = m->desc;
     const bool flat = d.use_viewdirs == 0;      // models.py:77-79: the tape is the trunk's (d_h, d_mask_h); d_feat / d_v / d_mask_v are not touched
-    const bool generic = m->plan->generic_nt != 0;     // generic-shape family: activation rows only, no ReLU masks (mlp_device_g.h)
+    const bool generic = m->plan->generic_nt != 0 || m->lw;   // generic-shape family / layer-wise path: activation rows only, no ReLU masks
     NM_REQUIRE(tape->d_h && (generic || tape->d_mask_h) && (flat || (tape->d_feat && tape->d_v && (generic || tape->d_mask_v))), "incomplete tape");
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
+    if (m->lw) {             // beyond the fused families: layer by layer (nerf_layerwise.hip); the tape is rows, no masks
+        MlpArgs a = m->base;
+        a.mode = MODE_RAYS;
+        a.a = d_origins; a.b = d_dirs; a.c = d_t;
+        a.origins_per_ray = origins_per_ray; a.samples = samples;
+        a.n = rays * samples; a.out = d_radiance;
+        DeviceGuardT guard(m->device);
+        return layerwise_forward_train(m, a, tape, static_cast<hipStream_t>(stream));
+    }
     if (generic) {
         MlpArgs a = m->base;
         a.mode = MODE_RAYS;
@@ -341,11 +360,15 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
     NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && deltas && n >= 0, "bad argument");
     const nm_mlp_desc& d = m->desc;
     const bool flat = d.use_viewdirs == 0;
-    const bool generic = m->plan->generic_nt != 0;
+    const bool generic = m->plan->generic_nt != 0 || m->lw;
     NM_REQUIRE(generic ? (tape->d_h && (flat || (tape->d_feat && tape->d_v))) : (tape->d_mask_h && (flat || tape->d_mask_v)), "incomplete tape");
     NM_REQUIRE(deltas->d_h && deltas->d_last && (flat || (deltas->d_feat && deltas->d_v)), "incomplete delta buffers");
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
     if (n == 0) return 0;
+    if (m->lw) {
+        DeviceGuardT guard(m->device);
+        return layerwise_backward(m, n, tape, d_radiance, d_grad_radiance, deltas, static_cast<hipStream_t>(stream));
+    }
     if (generic) {
         MlpBwdArgs a = m->bwd;
         a.radiance = d_radiance; a.grad_out = d_grad_radiance;

@@ -31,8 +31,8 @@ void set_error(const std::string& msg);
 
 // ---- fused MLP ------------------------------------------------------------------------------
 constexpr int KC = 8;          // k-steps (of 4 input features) per LDS weight chunk
-constexpr int MAX_FREQ_XYZ = 16;
-constexpr int MAX_FREQ_DIR = 16;
+constexpr int MAX_FREQ_XYZ = 32;   // frequency bands a handle keeps per encoding (the fused kernels take up to 15 / 16 functions,
+constexpr int MAX_FREQ_DIR = 32;   // the layer-wise path up to 32: nerf_layerwise.h)
 
 enum MlpMode : int { MODE_POINTS = 0, MODE_RAYS = 1, MODE_GRID = 2, MODE_VIEW = 3 };
 
@@ -166,6 +166,12 @@ struct MlpPlan {
     void (*kernel_bwd)(const MlpBwdArgs, const int, const int);      // ... and the delta kernel (null for tuned plans: nerf_train.hip)
 };
 
+// The general weight-gradient kernel (nerf_dw_g.hip) as a plain GEMM C = A^T B with a short contraction and a wide output:
+// the engine of the layer-wise network path (nerf_layerwise.hip).  `partial` receives the (out_pad x in_pad) result.
+struct DwgGemmGeometry { int wa, wb, ta, tb, nba, nbb, out_pad; int64_t in_pad; };
+DwgGemmGeometry dwg_gemm_geometry(int out, int64_t in);
+int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64_t ldb, int rows, float* partial, hipStream_t stream);
+
 // fused MLP over rays generated from a camera pose (mlp_api.hip; used by the render path in ray_ops.hip)
 int nm_mlp_eval_view_internal(nm_mlp* m, const RayGen* gen, const float* d_t, int64_t rays, int32_t samples,
                               float* d_radiance, hipStream_t stream);
@@ -192,4 +198,5 @@ struct nm_mlp {
     int32_t* d_index_b3;
     size_t b3_units;
     void* d_enc_tab;         // generic plans: GEncArg[2][48]
+    void* lw;                // layer-wise path (nerf_layerwise.h: LwNet*): networks beyond the fused families' limits, else null
 };

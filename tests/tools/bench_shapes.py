@@ -48,7 +48,9 @@ GENERIC = [dict(num_layers=8, hidden_size=512), dict(num_layers=8, hidden_size=2
            dict(num_layers=6, hidden_size=48, num_encoding_fn_xyz=6), dict(num_layers=4, hidden_size=32, num_encoding_fn_xyz=4, num_encoding_fn_dir=2, skip_step=2),
            dict(num_layers=8, hidden_size=256, num_encoding_fn_xyz=15, num_encoding_fn_dir=15),
            dict(num_layers=8, hidden_size=256, include_input_xyz=False, include_input_dir=False),
-           dict(num_layers=8, hidden_size=400, use_viewdirs=False)]
+           dict(num_layers=8, hidden_size=400, use_viewdirs=False),
+           # beyond the fused families: the layer-wise path (nerf_layerwise.hip; kernel_variant 2000)
+           dict(num_layers=8, hidden_size=768), dict(num_layers=8, hidden_size=1024), dict(num_layers=8, hidden_size=256, num_encoding_fn_xyz=20)]
 for over in GENERIC:
     kw = dict(dict(skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=True, use_viewdirs=True), **over)
     mlp = hip_ops.HipMLP(S.make_mlp_weights(3, **kw), kw, dev)

@@ -34,6 +34,8 @@ SHAPES = {
     "8x320": (dict(hidden_size=320), 2048, True),
     "4x400 flat": (dict(hidden_size=400, num_layers=4, skip_step=2), 2048, False),
     "8x512": (dict(hidden_size=512), 1024, True),
+    "8x768 (layer-wise path)": (dict(hidden_size=768), 512, True),
+    "8x1024 (layer-wise path)": (dict(hidden_size=1024), 512, True),
 }
 
 
@@ -118,7 +120,7 @@ def main():
         flops = samples * (fwd + delta + dw)
         variant = model.model_coarse.hip().kernel_variant()[0]
         out[name] = {"rays": rays, "samples_per_iteration": samples, "ms_per_iteration": round(ms, 3),
-                     "rays_per_s": round(rays / ms * 1e3), "kernel_family": "generic class %d" % (variant - 1000) if variant >= 1000 else "tuned",
+                     "rays_per_s": round(rays / ms * 1e3), "kernel_family": "layer-wise" if variant == 2000 else ("generic class %d" % (variant - 1000) if variant >= 1000 else "tuned"),
                      "algorithmic_tflop_per_iteration": round(flops / 1e12, 4),
                      "floor_ms_at_fp32_mfma_peak": round(flops / (PEAK * 1e12) * 1e3, 3),
                      "frac_of_fp32_mfma_peak_whole_iteration": round(flops / (ms * 1e-3) / 1e12 / PEAK, 3),
