@@ -35,7 +35,7 @@ extern "C" {
 /* 4 (round 5): + nm_weight_grad_ex / nm_head_grad_ex (+ their workspace functions, nm_weight_grad_plan): weight gradients of
  * every layer shape, row stride and sample count; nm_weight_grad / nm_head_grad forward to them (their shape and n % 16
  * restrictions are gone), nm_encode_samples_strided writes whole rows for any stride.  No signature changed; everything in
- * version 3 is unchanged. */
+ * version 3 is unchanged.  nm_mlp_create accepts hidden sizes above 512 and up to 32 encoding functions (layer-wise path). */
 #define NM_ABI_VERSION 4
 
 const char* nm_last_error(void);
@@ -80,9 +80,12 @@ typedef struct nm_mlp nm_mlp;
  * Every shape FlexibleNeRFModel's constructor accepts (models.py:5-58) is served: the shipped configs' shapes (hidden_size
  * 64 / 128 / 256, 6 or 10 xyz and 4 direction functions) by kernels tuned for exactly them, every other one -- any hidden_size
  * up to 512, 0..15 encoding functions per input (16 without the input itself), include_input_* on or off -- by the
- * generic-shape kernel family (padded to the next width class; nm_mlp_kernel_variant reports 1000 + class).  Only a
- * hidden_size above 512 or an encoding beyond those limits fails, with a message.  Every handle trains (generic-shape
- * handles through the tape-row path: masks may be NULL, nm_mlp_tape); NM_PREC_BF16X3 exists for 256-wide tuned shapes only. */
+ * generic-shape kernel family (padded to the next width class; nm_mlp_kernel_variant reports 1000 + class).  Beyond that -- a
+ * hidden_size above 512 or an encoding of more than 15 functions -- the network is evaluated and trained LAYER BY LAYER on the
+ * library's general MFMA GEMM (nm_mlp_kernel_variant 2000; the handle then owns a grow-only activation workspace that the
+ * first call of a size allocates).  Only more than 32 encoding functions or a weight matrix of more than 2^24 elements fails,
+ * with a message.  Every handle trains (generic-shape and layer-wise handles through the tape-row path: masks may be NULL,
+ * nm_mlp_tape); NM_PREC_BF16X3 exists for 256-wide tuned shapes only. */
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
 
 /* Arithmetic of the GEMMs.  NM_PREC_F32 (default, what nm_mlp_create builds): fp32 MFMA, the reference's fp32 arithmetic
