@@ -58,6 +58,13 @@ struct DwGArgs {
     int32_t out_pad, in_pad; // dimensions of a partial: grid.y * wa * TA * 16, grid.z * wb * TB * 16
     float* partial;          // (gridDim.x * wk, out_pad, in_pad)
     float* partial_bias;     // (gridDim.x * wk, out_pad)
+    // optional fused epilogue (dwg_gemm, one sample part): instead of the partial, out[row][col] = act(acc + bias[row]) (masked
+    // by mask[row][col] > 0) straight from the accumulators -- the layer-wise path's bias / ReLU / sigmoid / ReLU' pass
+    float* epi_out;          // (>= epi_rows x epi_ld) plane, or null
+    const float* epi_bias;   // per output row, or null
+    const float* epi_mask;   // plane of leading dimension epi_ld, or null
+    int64_t epi_ld;
+    int32_t epi_rows, epi_act;     // rows of the real output; 0 none, 1 ReLU, 2 sigmoid
 };
 
 #define NM_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -241,6 +248,33 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     //      per lane, one 16-byte store per tile
     const int64_t part = (int64_t)blockIdx.x * args.wk + wk_i;
     const int row0 = (blockIdx.y * args.wa + wa_i) * TA * 16, col0 = (blockIdx.z * args.wb + wb_i) * TB * 16;
+    if (args.epi_out) {
+#pragma unroll
+        for (int qa = 0; qa < TA; ++qa) {
+            const int row = row0 + 16 * qa + i;
+            if (row >= args.epi_rows) continue;
+            const float bias_r = args.epi_bias ? args.epi_bias[row] : 0.0f;
+            const int64_t at = (int64_t)row * args.epi_ld + col0 + 4 * g;
+#pragma unroll
+            for (int qb = 0; qb < TB; ++qb) {
+                f32x4 v = acc[qa][qb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v[r] + bias_r;
+                    if (args.epi_act == 1) x = fmaxf(x, 0.0f);
+                    else if (args.epi_act == 2) x = 1.0f / (1.0f + expf(-x));
+                    v[r] = x;
+                }
+                if (args.epi_mask) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(args.epi_mask + at + 16 * qb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.0f ? v[r] : 0.0f;
+                }
+                *reinterpret_cast<f32x4*>(args.epi_out + at + 16 * qb) = v;
+            }
+        }
+        return;
+    }
     float* out = args.partial + part * ((int64_t)args.out_pad * args.in_pad);
 #pragma unroll
     for (int qa = 0; qa < TA; ++qa) {
@@ -524,8 +558,9 @@ DwgGemmGeometry dwg_gemm_geometry(int out, int64_t in) {
     return g;
 }
 
-int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64_t ldb, int rows, float* partial, hipStream_t stream) {
-    NM_REQUIRE(A && B && partial && out >= 1 && in >= 1 && rows >= 1 && lda >= out && ldb >= in, "gemm: bad argument");
+int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64_t ldb, int rows, float* partial, hipStream_t stream,
+             const DwgEpilogue* epi) {
+    NM_REQUIRE(A && B && (partial || epi) && out >= 1 && in >= 1 && rows >= 1 && lda >= out && ldb >= in, "gemm: bad argument");
     const DwgGemmGeometry g = dwg_gemm_geometry(out, in);
     NM_REQUIRE(g.nbb <= 65535 && g.in_pad < (1ll << 31) && ldb < (1ll << 31), "gemm: batch too large");
     NM_REQUIRE(((int64_t)rows + 32) * (ldb > lda ? ldb : lda) * 4 < 0xf0000000ll, "gemm: operand exceeds 32-bit offsets (use a smaller batch)");
@@ -542,6 +577,9 @@ int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64
     a.out_pad = g.out_pad; a.in_pad = (int)g.in_pad;
     a.partial = partial;
     a.partial_bias = nullptr;
+    a.epi_out = epi ? epi->out : nullptr; a.epi_bias = epi ? epi->bias : nullptr; a.epi_mask = epi ? epi->mask : nullptr;
+    a.epi_ld = epi ? epi->ld : 0; a.epi_rows = out; a.epi_act = epi ? epi->act : 0;
+    NM_REQUIRE(!epi || (epi->out && epi->ld >= g.in_pad && epi->ld % 4 == 0), "gemm: the epilogue's planes must span the padded batch");
     const int lds_bytes = 4 * (a.A.img + a.B.img) + DWG_SLACK;
     NM_REQUIRE(lds_bytes <= DWG_LDS_BYTES, "gemm: LDS budget exceeded");
     const DwGKernel kernel = g_dwg_kernels[g.ta - 1][g.tb - 1];
@@ -625,6 +663,7 @@ extern "C" int nm_weight_grad_ex(int device_cus, const float* d_delta, int32_t o
     fill(a.A, d_delta, delta_stride, p.wa * p.ta * 16, p.nba > 1, a_x4);
     fill(a.B, d_act, act_stride, p.wb * p.tb * 16, p.nbb > 1, b_x4);
     a.n = n; a.rows = p.rows; a.wa = p.wa; a.wb = p.wb; a.wk = p.wk;
+    a.epi_out = nullptr; a.epi_bias = nullptr; a.epi_mask = nullptr; a.epi_ld = 0; a.epi_rows = 0; a.epi_act = 0;
     a.out_pad = p.nba * p.wa * p.ta * 16; a.in_pad = p.nbb * p.wb * p.tb * 16;
     const int parts = (int)grid_x * p.wk;
     a.partial = static_cast<float*>(d_workspace);

@@ -178,6 +178,13 @@ static int lw_layer(const LwBuffers& b, const LwProduct* prods, int nprods, int 
                     float* dst, int count, hipStream_t stream) {
     const DwgGemmGeometry g = dwg_gemm_geometry(out, count);
     const int64_t stride = (int64_t)g.out_pad * g.in_pad;
+    int live = 0, only = -1;
+    for (int k = 0; k < nprods; ++k)
+        if (prods[k].rows > 0) { ++live; only = k; }
+    if (live == 1) {       // a single product: bias / activation / mask straight from the GEMM's accumulators, no partial plane
+        const DwgEpilogue epi{dst, bias, mask, b.ld, act};
+        return dwg_gemm(prods[only].A, out, prods[only].lda, prods[only].B, count, b.ld, prods[only].rows, nullptr, stream, &epi);
+    }
     int used = 0;
     for (int k = 0; k < nprods; ++k) {
         if (prods[k].rows <= 0) continue;

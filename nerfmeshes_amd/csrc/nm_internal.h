@@ -170,7 +170,9 @@ struct MlpPlan {
 // the engine of the layer-wise network path (nerf_layerwise.hip).  `partial` receives the (out_pad x in_pad) result.
 struct DwgGemmGeometry { int wa, wb, ta, tb, nba, nbb, out_pad; int64_t in_pad; };
 DwgGemmGeometry dwg_gemm_geometry(int out, int64_t in);
-int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64_t ldb, int rows, float* partial, hipStream_t stream);
+struct DwgEpilogue { float* out; const float* bias; const float* mask; int64_t ld; int act; };   // act: 0 none, 1 ReLU, 2 sigmoid
+int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64_t ldb, int rows, float* partial, hipStream_t stream,
+             const DwgEpilogue* epilogue = nullptr);
 
 // fused MLP over rays generated from a camera pose (mlp_api.hip; used by the render path in ray_ops.hip)
 int nm_mlp_eval_view_internal(nm_mlp* m, const RayGen* gen, const float* d_t, int64_t rays, int32_t samples,
