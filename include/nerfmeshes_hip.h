@@ -85,11 +85,11 @@ typedef struct nm_mlp nm_mlp;
  * library's general MFMA GEMM (nm_mlp_kernel_variant 2000; the handle then owns a grow-only activation workspace that the
  * first call of a size allocates).  Only more than 32 encoding functions or a weight matrix of more than 2^24 elements fails,
  * with a message.  Every handle trains (generic-shape and layer-wise handles through the tape-row path: masks may be NULL,
- * nm_mlp_tape); NM_PREC_BF16X3 exists for 256-wide tuned shapes only. */
+ * nm_mlp_tape); NM_PREC_BF16X3 exists for the tuned (shipped) shapes only. */
 int nm_mlp_create(const nm_mlp_desc* desc, const nm_mlp_weights* h_weights, int device, nm_mlp** out);
 
 /* Arithmetic of the GEMMs.  NM_PREC_F32 (default, what nm_mlp_create builds): fp32 MFMA, the reference's fp32 arithmetic
- * up to summation order.  NM_PREC_BF16X3 (opt-in; 256-wide networks): every product is emulated by six bf16 MFMA
+ * up to summation order.  NM_PREC_BF16X3 (opt-in; the shipped widths 64 / 128 / 256 with 6 or 10 xyz and 4 direction functions): every product is emulated by six bf16 MFMA
  * products of a three-way split of both operands with fp32 accumulation -- fp32-class error (dropped terms <= 2^-24 of
  * a product) at ~2.3x the throughput, but not bit-comparable with the fp32 path; inference entry points only
  * (nm_mlp_forward_train / nm_mlp_backward refuse such a handle). */

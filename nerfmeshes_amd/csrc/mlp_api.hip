@@ -477,7 +477,7 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
         const int steps_x = (3 * FX + 1) / 2 + (d.include_input_xyz ? 1 : 0), steps_d = (3 * FD + 1) / 2 + (d.include_input_dir ? 1 : 0);
         const bool long_encoding = steps_x > G_ENC_STEPS || (!no_view && steps_d > G_ENC_STEPS);
         if (precision != NM_PREC_F32) {
-            set_error("precision bf16x3 is instantiated for hidden_size 256 with 6 or 10 xyz / 4 direction frequencies only");
+            set_error("precision bf16x3 is instantiated for hidden_size 64 / 128 / 256 with 6 or 10 xyz / 4 direction frequencies only");
             return 3;
         }
         if (!plan || long_encoding) {
@@ -576,7 +576,7 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     std::vector<int32_t> index_b3;
     if (precision == NM_PREC_BF16X3) {
         if (!has_b3_kernel(H, FX, FD)) {
-            set_error("precision bf16x3 is instantiated for hidden_size 256 with 6 or 10 xyz / 4 direction frequencies only");
+            set_error("precision bf16x3 is instantiated for hidden_size 64 / 128 / 256 with 6 or 10 xyz / 4 direction frequencies only");
             return 3;
         }
         std::vector<SlotCols> bx, bh, bskip, bdir;

@@ -58,10 +58,14 @@ struct B3Next { const char* s0; int b0; const char* s1; int b1; };
 // One stage: acc[NT] += W_stage * B, B = KB1 k-blocks of b1 followed by KB2 of b2.  Units are streamed k-block-major
 // (all NT tiles of k-block 0, then k-block 1, ...); `carry` holds the A planes of the next two units across chunk and
 // stage boundaries (same scheme as gemm_stage3).
-template <int NT, int KB1, int KB2, int NW>
+// CU: units per chunk (B3_CHUNK_UNITS = 16 for the 256-wide networks; 8 / 3 for the 128- / 64-wide ones, whose stages would
+// not span two chunks of 16 units: round 5)
+template <int NT, int KB1, int KB2, int NW, int CU = B3_CHUNK_UNITS>
 __device__ __forceinline__ void gemm_stage_b3(f32x4 (&acc)[NT], const Split3 (&b1)[KB1], const Split3 (&b2)[(KB2 > 0 ? KB2 : 1)],
                                               const char* gw, const B3Next nx, char* lds, int& slot, u32x4 (&carry)[2][3],
                                               int wave, int lane) {
+    constexpr int B3_CHUNK_UNITS = CU;                 // shadows the namespace constants inside this function
+    constexpr int B3_SLOT = CU * B3_UNIT;
     constexpr int UNITS = (KB1 + KB2) * NT;
     constexpr int NCH = (UNITS + B3_CHUNK_UNITS - 1) / B3_CHUNK_UNITS;
     static_assert(NCH >= 2, "every stage must span at least two chunks");
@@ -156,8 +160,10 @@ __device__ __forceinline__ float b3_convert(const f32x4 (&acc)[NT], Split3 (&out
     return part;
 }
 
-template <int H, int FX, int FD, int NW>
+template <int H, int FX, int FD, int NW, int CU = B3_CHUNK_UNITS>
 __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, const int num_layers, const int density_only) {
+    constexpr int B3_CHUNK_UNITS = CU;
+    constexpr int B3_SLOT = CU * B3_UNIT;
     constexpr int NT = H / 16, KB = H / 32, NTD = H / 32, KBX = 2, KBD = 1;
     static_assert(6 * FX + 3 <= 64 && 6 * FD + 3 <= 32 && FX <= 16 && FD <= 16, "encoding slots");
     static_assert(NT * KBX >= 2 * B3_CHUNK_UNITS && NTD * (KB + KBD) >= 2 * B3_CHUNK_UNITS, "stages must span two chunks");
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
             Split3 encx[KBX];
 #pragma unroll
             for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, opaque(g), encx[m]);
-            gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, next_of(gw + U_ENC * B3_UNIT, U_HID, true), lds, slot, carry, wave, lane);
+            gemm_stage_b3<NT, KBX, 0, NW, CU>(acc, encx, none, gw, next_of(gw + U_ENC * B3_UNIT, U_HID, true), lds, slot, carry, wave, lane);
         }
         gw += U_ENC * B3_UNIT;
         b3_convert<NT, false>(acc, in, lds_walpha + g * (H / 4), false);
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
                 if (skip) nx = next_of(after, U_ENC, true);
                 else if (is_feat) nx = next_of(after, U_DIR, true);
                 else if (last_density) nx = wrap;
-                gemm_stage_b3<NT, KB, 0, NW>(acc, in, none, gw, nx, lds, slot, carry, wave, lane);
+                gemm_stage_b3<NT, KB, 0, NW, CU>(acc, in, none, gw, nx, lds, slot, carry, wave, lane);
                 gw = after;
             }
             if (skip) {
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
                 Split3 encx[KBX];
 #pragma unroll
                 for (int m = 0; m < KBX; ++m) b3_encode_block<FX>(p, lds_bands, m, opaque(g), encx[m]);
-                gemm_stage_b3<NT, KBX, 0, NW>(acc, encx, none, gw, nx, lds, slot, carry, wave, lane);
+                gemm_stage_b3<NT, KBX, 0, NW, CU>(acc, encx, none, gw, nx, lds, slot, carry, wave, lane);
                 gw = after;
             }
             // fc_alpha reads the output of layers_xyz[L-2] (models.py:71): its GEMV rides on this conversion
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_b3(const MlpArgs args, 
         load_bias<NTD>(accd, lds_bias + H * (1 + num_layers), g);
         Split3 encd[KBD];
         b3_encode_block<FD>(d, lds_bands + 16, 0, opaque(g), encd[0]);
-        gemm_stage_b3<NTD, KB, KBD, NW>(accd, in, encd, gw, wrap, lds, slot, carry, wave, lane);
+        gemm_stage_b3<NTD, KB, KBD, NW, CU>(accd, in, encd, gw, wrap, lds, slot, carry, wave, lane);
         float v[4 * NTD];
         acc_to_operand<NTD, true>(accd, v);
         float rgb[3];

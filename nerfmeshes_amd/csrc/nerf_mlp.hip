@@ -124,15 +124,22 @@ struct B3Plan {
     int H, FX, FD;
     void (*kernel)(const MlpArgs, const int, const int);
     void (*kernel_w)(const MlpArgs, const int, const int);      // ablation library: two column tiles per wave (mlp_device_b3w.h)
+    int chunk_units;                                            // units per ring slot (a stage must span two chunks)
 };
 static const B3Plan g_b3_plans[] = {
 #ifdef NM_ABLATIONS
-    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>, &mlp_kernel_b3w<256, 10, 4, 4>},
-    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>, &mlp_kernel_b3w<256, 6, 4, 4>},
+    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>, &mlp_kernel_b3w<256, 10, 4, 4>, B3_CHUNK_UNITS},
+    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>, &mlp_kernel_b3w<256, 6, 4, 4>, B3_CHUNK_UNITS},
 #else
-    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>, nullptr},
-    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>, nullptr},
+    {256, 10, 4, &mlp_kernel_b3<256, 10, 4, 8>, nullptr, B3_CHUNK_UNITS},
+    {256, 6, 4, &mlp_kernel_b3<256, 6, 4, 8>, nullptr, B3_CHUNK_UNITS},
 #endif
+    // round 5: the narrower shipped shapes (the fern configs' 8x128, config 1's 4x64): smaller chunks so that every stage still
+    // spans two of them; the same kernel otherwise
+    {128, 10, 4, &mlp_kernel_b3<128, 10, 4, 8, 8>, nullptr, 8},
+    {128, 6, 4, &mlp_kernel_b3<128, 6, 4, 8, 8>, nullptr, 8},
+    {64, 10, 4, &mlp_kernel_b3<64, 10, 4, 8, 3>, nullptr, 3},
+    {64, 6, 4, &mlp_kernel_b3<64, 6, 4, 8, 3>, nullptr, 3},
 };
 static const B3Plan* find_b3_plan(int H, int FX, int FD) {
     for (const B3Plan& p : g_b3_plans)
@@ -194,7 +201,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     if (m->precision == NM_PREC_BF16X3) {
         const B3Plan* b = find_b3_plan(H, m->desc.num_encoding_fn_xyz, m->desc.num_encoding_fn_dir);
         NM_REQUIRE(b && m->d_stream_b3, "no bf16x3 kernel for this network");
-        const int lds_bytes = 3 * B3_SLOT + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2 + 32) * 4 + 255) & ~255);   // + the two band tables
+        const int lds_bytes = 3 * b->chunk_units * B3_UNIT + (((H * (1 + L) + H / 2 + 4 + H + 3 * H / 2 + 32) * 4 + 255) & ~255);   // + the two band tables
         NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (bf16x3 ring + bias cache): too many layers");
         auto b3_kernel = b->kernel;
         unsigned b3_threads = 512;

@@ -45,7 +45,7 @@ class HipMLP:
         FlexibleNeRFModel.state_dict(); desc: dict of constructor hyper-parameters.
         precision: "f32" (default: fp32 MFMA, the reference's arithmetic) or the opt-in "bf16x3" (every product emulated
         by six bf16 MFMA products of three-way operand splits, fp32 accumulation: fp32-class error, ~2x the throughput,
-        inference only, 256-wide networks).  force_generic: bind to the generic-shape kernel family even where a tuned
+        inference only, the shipped 64- / 128- / 256-wide shapes).  force_generic: bind to the generic-shape kernel family even where a tuned
         kernel exists for the shape (NM_KERNEL_GENERIC: a cross-check, same results bit for bit)."""
         lib = _lib.load()
         if precision not in PRECISIONS:

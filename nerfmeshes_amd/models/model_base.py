@@ -51,7 +51,7 @@ class BaseModel(_Base):
     def set_precision(self, precision):
         """Arithmetic of the inference kernels of every network of this model: "f32" (default; the reference's fp32) or
         the opt-in "bf16x3" (hip_ops.HipMLP: fp32 products emulated on the bf16 matrix pipe, fp32-class error, ~1.8x the
-        throughput; 256-wide networks; a network without such a kernel says so when it is first used).  Training and the
+        throughput; the shipped 64- / 128- / 256-wide shapes; a network without such a kernel says so when it is first used).  Training and the
         mesh grid of `mesh_nerf` always run in fp32."""
         from ..hip_ops import PRECISIONS
         if precision not in PRECISIONS:
