@@ -93,8 +93,12 @@ struct DwStream {
     uint32_t goff, loff;     // lane p: byte offset of its piece p inside a chunk in HBM / inside the LDS image
 };
 
-template <int TA, int TB>
+// VEC (TA, TB multiples of 4; both LDS row strides multiples of 4 floats): a lane fetches 4 consecutive features of a
+// 64-feature block with ONE ds_read_b128 -- register q is then the operand of "tile q" whose index i stands for feature 4 i + q,
+// the tuned kernel's mapping: 3 reads instead of 12 per 32 MFMAs, conflict-free for 64-float-multiple strides.
+template <int TA, int TB, bool VEC = false>
 __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
+    static_assert(!VEC || (TA % 4 == 0 && TB % 4 == 0), "VEC: whole 64-feature blocks per wave");
     constexpr int NW = 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -182,15 +186,31 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     // this lane's operands of k-group kg of a chunk: row 4 * (kg * wk + wk_i) + g, columns 16 * (tile) + i
     const int kgw = rows / (4 * args.wk);
     const int step_a = 4 * args.wk * args.A.ls * 4, step_b = 4 * args.wk * args.B.ls * 4;
-    const int lane_a = ((4 * wk_i + g) * args.A.ls + wa_i * TA * 16 + i) * 4;
-    const int lane_b = args.A.img + ((4 * wk_i + g) * args.B.ls + wb_i * TB * 16 + i) * 4;
+    const int lane_col = VEC ? 4 * i : i;
+    const int lane_a = ((4 * wk_i + g) * args.A.ls + wa_i * TA * 16 + lane_col) * 4;
+    const int lane_b = args.A.img + ((4 * wk_i + g) * args.B.ls + wb_i * TB * 16 + lane_col) * 4;
     auto load_ops = [&](int slot, int kg, float (&a)[TA], float (&b)[TB]) {
         const char* pa = lds + slot * slot_bytes + kg * step_a + lane_a;
         const char* pb = lds + slot * slot_bytes + kg * step_b + lane_b;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int qa = 0; qa < TA; ++qa) a[qa] = *reinterpret_cast<const float*>(pa + qa * 64);
+            for (int blk = 0; blk < TA / 4; ++blk) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pa + blk * 256);
 #pragma unroll
-        for (int qb = 0; qb < TB; ++qb) b[qb] = *reinterpret_cast<const float*>(pb + qb * 64);
+                for (int q = 0; q < 4; ++q) a[4 * blk + q] = v[q];
+            }
+#pragma unroll
+            for (int blk = 0; blk < TB / 4; ++blk) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pb + blk * 256);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[4 * blk + q] = v[q];
+            }
+        } else {
+#pragma unroll
+            for (int qa = 0; qa < TA; ++qa) a[qa] = *reinterpret_cast<const float*>(pa + qa * 64);
+#pragma unroll
+            for (int qb = 0; qb < TB; ++qb) b[qb] = *reinterpret_cast<const float*>(pb + qb * 64);
+        }
     };
     // one k-group: the operands of the NEXT one are put in flight first (pinned: hipcc otherwise sinks the reads to their use)
     auto kstep = [&](const float (&a)[TA], const float (&b)[TB], float (&an)[TA], float (&bn)[TB], int nslot, int nkg) {
@@ -205,7 +225,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
         for (int qa = 0; qa < TA; ++qa)
 #pragma unroll
             for (int qb = 0; qb < TB; ++qb)
-                acc[qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[qb], a[qa], acc[qa][qb], 0, 0, 0);
+                acc[qa][qb] = VEC ? __builtin_amdgcn_mfma_f32_16x16x4f32(a[qa], b[qb], acc[qa][qb], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x4f32(b[qb], a[qa], acc[qa][qb], 0, 0, 0);
     };
 
     dma(c_lo, 0);
@@ -248,48 +269,61 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     //      per lane, one 16-byte store per tile
     const int64_t part = (int64_t)blockIdx.x * args.wk + wk_i;
     const int row0 = (blockIdx.y * args.wa + wa_i) * TA * 16, col0 = (blockIdx.z * args.wb + wb_i) * TB * 16;
-    if (args.epi_out) {
+    // element (row, 4 consecutive columns) of the output a lane holds for (qa, group of 4 registers / tiles):
+    //   plain: tile (qa, qb), registers r = 0..3  -> row 16 qa + i,          columns 16 qb + 4 g + (0..3)
+    //   VEC:   tiles (qa, 4 blk + 0..3), register r -> row 16 (qa / 4 * 4) + 4 (4 g + r) + qa % 4,  columns 64 blk + 4 i + (0..3)
+    auto emit = [&](auto&& sink) {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int qa = 0; qa < TA; ++qa) {
-            const int row = row0 + 16 * qa + i;
-            if (row >= args.epi_rows) continue;
-            const float bias_r = args.epi_bias ? args.epi_bias[row] : 0.0f;
-            const int64_t at = (int64_t)row * args.epi_ld + col0 + 4 * g;
-#pragma unroll
-            for (int qb = 0; qb < TB; ++qb) {
-                f32x4 v = acc[qa][qb];
+            for (int qa = 0; qa < TA; ++qa)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = v[r] + bias_r;
-                    if (args.epi_act == 1) x = fmaxf(x, 0.0f);
-                    else if (args.epi_act == 2) x = 1.0f / (1.0f + expf(-x));
-                    v[r] = x;
-                }
-                if (args.epi_mask) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(args.epi_mask + at + 16 * qb);
+                    const int row = row0 + 64 * (qa / 4) + 4 * (4 * g + r) + (qa % 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.0f ? v[r] : 0.0f;
+                    for (int blk = 0; blk < TB / 4; ++blk) {
+                        const f32x4 v = {acc[qa][4 * blk][r], acc[qa][4 * blk + 1][r], acc[qa][4 * blk + 2][r], acc[qa][4 * blk + 3][r]};
+                        sink(row, col0 + 64 * blk + 4 * i, v);
+                    }
                 }
-                *reinterpret_cast<f32x4*>(args.epi_out + at + 16 * qb) = v;
-            }
+        } else {
+#pragma unroll
+            for (int qa = 0; qa < TA; ++qa)
+#pragma unroll
+                for (int qb = 0; qb < TB; ++qb) sink(row0 + 16 * qa + i, col0 + 16 * qb + 4 * g, acc[qa][qb]);
         }
+    };
+    if (args.epi_out) {
+        emit([&](int row, int col, f32x4 v) {
+            if (row >= args.epi_rows) return;
+            const float bias_r = args.epi_bias ? args.epi_bias[row] : 0.0f;
+            const int64_t at = (int64_t)row * args.epi_ld + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r] + bias_r;
+                if (args.epi_act == 1) x = fmaxf(x, 0.0f);
+                else if (args.epi_act == 2) x = 1.0f / (1.0f + expf(-x));
+                v[r] = x;
+            }
+            if (args.epi_mask) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(args.epi_mask + at);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.0f ? v[r] : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(args.epi_out + at) = v;
+        });
         return;
     }
     float* out = args.partial + part * ((int64_t)args.out_pad * args.in_pad);
-#pragma unroll
-    for (int qa = 0; qa < TA; ++qa) {
-        float* prow = out + (int64_t)(row0 + 16 * qa + i) * args.in_pad + col0 + 4 * g;
-#pragma unroll
-        for (int qb = 0; qb < TB; ++qb) *reinterpret_cast<f32x4*>(prow + 16 * qb) = acc[qa][qb];
-    }
+    emit([&](int row, int col, f32x4 v) { *reinterpret_cast<f32x4*>(out + (int64_t)row * args.in_pad + col) = v; });
     if (bias_owner) {
-        // lane (g, i) holds the sum over its rows (= g mod 4 of its k-groups) of feature 16 ta + i: fold the 4 lane groups
+        // lane (g, i) holds the sum over its rows (= g mod 4 of its k-groups) of one feature per qa: fold the 4 lane groups
 #pragma unroll
         for (int qa = 0; qa < TA; ++qa) {
             float v = bias[qa];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (g == 0) args.partial_bias[part * args.out_pad + row0 + 16 * qa + i] = v;
+            const int feature = VEC ? 64 * (qa / 4) + 4 * i + (qa % 4) : 16 * qa + i;
+            if (g == 0) args.partial_bias[part * args.out_pad + row0 + feature] = v;
         }
     }
 }
@@ -451,6 +485,13 @@ constexpr DwGKernel dwg_kernel_or_null() {
     if constexpr (TA * TB <= DWG_MAX_TILES) return &dw_kernel_g<TA, TB>;
     else return nullptr;
 }
+// the ds_read_b128 variants (whole 64-feature blocks per wave): picked when both operands' LDS rows are 16-byte aligned
+static DwGKernel dwg_vec_kernel(int ta, int tb) {
+    if (ta == 4 && tb == 8) return &dw_kernel_g<4, 8, true>;
+    if (ta == 4 && tb == 4) return &dw_kernel_g<4, 4, true>;
+    return nullptr;
+}
+static bool dwg_vec_ok(const DwGArgs& a) { return a.A.x4 && a.B.x4 && a.A.ls % 4 == 0 && a.B.ls % 4 == 0 && !getenv("NM_DW_NO_VEC"); }
 #define NM_DWG_ROW(TA)                                                                                                          \
     { dwg_kernel_or_null<TA, 1>(), dwg_kernel_or_null<TA, 2>(), dwg_kernel_or_null<TA, 3>(), dwg_kernel_or_null<TA, 4>(),         \
       dwg_kernel_or_null<TA, 5>(), dwg_kernel_or_null<TA, 6>(), dwg_kernel_or_null<TA, 7>(), dwg_kernel_or_null<TA, 8>() }
@@ -582,7 +623,9 @@ int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64
     NM_REQUIRE(!epi || (epi->out && epi->ld >= g.in_pad && epi->ld % 4 == 0), "gemm: the epilogue's planes must span the padded batch");
     const int lds_bytes = 4 * (a.A.img + a.B.img) + DWG_SLACK;
     NM_REQUIRE(lds_bytes <= DWG_LDS_BYTES, "gemm: LDS budget exceeded");
-    const DwGKernel kernel = g_dwg_kernels[g.ta - 1][g.tb - 1];
+    DwGKernel kernel = g_dwg_kernels[g.ta - 1][g.tb - 1];
+    if (DwGKernel vec = dwg_vec_kernel(g.ta, g.tb))
+        if (dwg_vec_ok(a)) kernel = vec;
     static std::mutex lock;
     static std::map<std::pair<int, const void*>, int> have;
     {
@@ -670,7 +713,9 @@ extern "C" int nm_weight_grad_ex(int device_cus, const float* d_delta, int32_t o
     a.partial_bias = a.partial + (int64_t)parts * a.out_pad * a.in_pad;
     const int lds_bytes = 4 * (a.A.img + a.B.img) + DWG_SLACK;
     NM_REQUIRE(lds_bytes <= DWG_LDS_BYTES, "weight_grad: LDS budget exceeded");
-    const DwGKernel kernel = g_dwg_kernels[p.ta - 1][p.tb - 1];
+    DwGKernel kernel = g_dwg_kernels[p.ta - 1][p.tb - 1];
+    if (DwGKernel vec = dwg_vec_kernel(p.ta, p.tb))
+        if (dwg_vec_ok(a)) kernel = vec;
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid_x, p.nba, p.nbb), dim3(512), lds_bytes, stream, a);
     const int64_t elems = (int64_t)out_features * in_features;
