@@ -34,6 +34,25 @@ def _dev32(t, device=None, name="tensor"):
     return t.detach().to(torch.float32).contiguous()
 
 
+_small_cache = {}
+
+
+def _dev32_small(t, device):
+    """`_dev32` for the few-element HOST tensors that are the same call after call -- the ray bounds the reference keeps on
+    the CPU (eval_nerf.py:65, mesh_nerf.py:179, every training batch): device copies cached by value.  A pageable H2D copy
+    per call is a host-blocking hipMemcpy that first drains the stream: at the top of every training iteration / render
+    chunk it left the GPU idle for the CPU's launch latency."""
+    if isinstance(t, torch.Tensor) and not t.is_cuda and t.numel() <= 4:
+        key = (str(device), tuple(float(x) for x in t.reshape(-1).tolist()))
+        hit = _small_cache.get(key)
+        if hit is None:
+            if len(_small_cache) > 256:
+                _small_cache.clear()
+            hit = _small_cache[key] = t.detach().to(device=device, dtype=torch.float32).contiguous()
+        return hit
+    return _dev32(t, device)
+
+
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
@@ -159,7 +178,7 @@ def ray_bundle(c2w, height, width, focal, first=0, count=None, device="cuda"):
 def coarse_intervals(u, near, far, rays, lindisp=False):
     lib = _lib.load()
     u = _dev32(u)
-    near, far = _dev32(near, u.device).reshape(-1), _dev32(far, u.device).reshape(-1)
+    near, far = _dev32_small(near, u.device).reshape(-1), _dev32_small(far, u.device).reshape(-1)
     per_ray = int(near.numel() == rays and rays > 1)
     t = torch.empty(rays, u.numel(), dtype=torch.float32, device=u.device)
     check(lib.nm_coarse_intervals(_ptr(u), _ptr(near), _ptr(far), per_ray, int(lindisp), rays, u.numel(), _ptr(t),
@@ -331,7 +350,10 @@ def buff_intersect(voxels, origins, dirs, near, far, samples, ids="stable"):
     dev = voxels.device
     origins, dirs = _dev32(origins, dev, "origins").reshape(-1, 3), _dev32(dirs, dev, "dirs").reshape(-1, 3)
     rays = dirs.shape[0]
-    u = torch.linspace(0, 1.0, samples).to(dev)                   # tree.py:318
+    key = ("linspace", str(dev), int(samples))                    # tree.py:318; one H2D per (device, count), not per call
+    u = _small_cache.get(key)
+    if u is None:
+        u = _small_cache[key] = torch.linspace(0, 1.0, samples).to(dev)
     z = torch.empty(rays, samples, dtype=torch.float32, device=dev)
     idx = torch.empty(rays, samples, dtype=torch.int64, device=dev)
     mask = torch.empty(rays, dtype=torch.uint8, device=dev)
