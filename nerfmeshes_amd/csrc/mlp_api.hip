@@ -2,6 +2,9 @@
 // handle lifetime, and the three entry points that launch nerf_mlp.hip's kernel.
 #include <array>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "nm_internal.h"
@@ -12,6 +15,21 @@ namespace nm {
 
 static thread_local std::string g_error;
 void set_error(const std::string& msg) { g_error = msg; }
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    NM_REQUIRE(bytes <= 160 * 1024, "LDS budget exceeded");
+    static std::mutex lock;
+    static std::map<std::pair<int, const void*>, int> have;
+    int dev = 0;
+    NM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> guard(lock);
+    int& cur = have[{dev, kernel}];
+    if (cur < bytes) {
+        NM_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        cur = bytes;
+    }
+    return 0;
+}
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD);
 const MlpPlan* find_generic_plan(int H);

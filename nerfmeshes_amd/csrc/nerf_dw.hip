@@ -349,7 +349,7 @@ int weight_grad_tuned(int device_cus, const float* d_delta, int32_t out_features
     a.partial_bias = a.partial + (int64_t)parts * out_features * act_stride;
     const int lds_bytes = 4 * DW_ROWS * (out_features + act_stride) * 4;
     NM_REQUIRE(lds_bytes <= 160 * 1024, "weight_grad: LDS budget exceeded");
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)plan->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (int rc = ensure_dynamic_lds((const void*)plan->kernel, lds_bytes)) return rc;
     hipLaunchKernelGGL(plan->kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
     const int64_t elems = (int64_t)out_features * in_features;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((elems + out_features + 255) / 256)), dim3(256), 0, stream,

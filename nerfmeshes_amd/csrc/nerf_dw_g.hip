@@ -626,18 +626,7 @@ int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64
     DwGKernel kernel = g_dwg_kernels[g.ta - 1][g.tb - 1];
     if (DwGKernel vec = dwg_vec_kernel(g.ta, g.tb))
         if (dwg_vec_ok(a)) kernel = vec;
-    static std::mutex lock;
-    static std::map<std::pair<int, const void*>, int> have;
-    {
-        int dev = 0;
-        NM_HIP_CHECK(hipGetDevice(&dev));
-        std::lock_guard<std::mutex> guard(lock);
-        int& cur = have[{dev, (const void*)kernel}];
-        if (cur < lds_bytes) {
-            NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            cur = lds_bytes;
-        }
-    }
+    if (int rc = ensure_dynamic_lds((const void*)kernel, lds_bytes)) return rc;
     hipLaunchKernelGGL(kernel, dim3(1, g.nba, g.nbb), dim3(512), lds_bytes, stream, a);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -716,7 +705,7 @@ extern "C" int nm_weight_grad_ex(int device_cus, const float* d_delta, int32_t o
     DwGKernel kernel = g_dwg_kernels[p.ta - 1][p.tb - 1];
     if (DwGKernel vec = dwg_vec_kernel(p.ta, p.tb))
         if (dwg_vec_ok(a)) kernel = vec;
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (int rc = ensure_dynamic_lds((const void*)kernel, lds_bytes)) return rc;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid_x, p.nba, p.nbb), dim3(512), lds_bytes, stream, a);
     const int64_t elems = (int64_t)out_features * in_features;
     hipLaunchKernelGGL(dw_reduce_g_kernel, dim3((unsigned)((elems + out_features + 255) / 256)), dim3(256), 0, stream, a.partial,

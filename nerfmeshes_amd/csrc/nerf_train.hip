@@ -255,9 +255,6 @@ static unsigned persistent_grid(int64_t wg_iters, int num_cus) {
     return (unsigned)grid;
 }
 
-// The dynamic-LDS attribute of a kernel is per device; it is raised once per (device, kernel) and when a call needs more --
-// not on every launch -- under a lock (two host threads training two models would otherwise race on it), as the inference
-// launcher does.
 struct DeviceGuardT {        // the handle's device current for the call (as nerf_mlp.hip's DeviceGuard)
     int prev = -1;
     explicit DeviceGuardT(int want) {
@@ -267,20 +264,7 @@ struct DeviceGuardT {        // the handle's device current for the call (as ner
     ~DeviceGuardT() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-static int set_lds(const void* fn, int bytes) {
-    NM_REQUIRE(bytes <= 160 * 1024, "LDS budget exceeded");
-    static std::mutex lock;
-    static std::map<std::pair<int, const void*>, int> have;
-    int dev = 0;
-    NM_HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> guard(lock);
-    int& cur = have[{dev, fn}];
-    if (cur < bytes) {
-        NM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        cur = bytes;
-    }
-    return 0;
-}
+static int set_lds(const void* fn, int bytes) { return ensure_dynamic_lds(fn, bytes); }
 
 }  // namespace nm
 

@@ -166,6 +166,10 @@ struct MlpPlan {
     void (*kernel_bwd)(const MlpBwdArgs, const int, const int);      // ... and the delta kernel (null for tuned plans: nerf_train.hip)
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised once per (device, kernel) and whenever a launch needs more --
+// not on every launch --, under a lock (the attribute is per device; two host threads would otherwise race on it).
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // The general weight-gradient kernel (nerf_dw_g.hip) as a plain GEMM C = A^T B with a short contraction and a wide output:
 // the engine of the layer-wise network path (nerf_layerwise.hip).  `partial` receives the (out_pad x in_pad) result.
 struct DwgGemmGeometry { int wa, wb, ta, tb, nba, nbb, out_pad; int64_t in_pad; };
