@@ -316,6 +316,22 @@ int nm_weight_grad_ex(int num_cus, const float* d_delta, int32_t out_features, i
                       int32_t dw_col0, float* d_dbias, void* stream);
 int nm_weight_grad_plan(int32_t out_features, int32_t delta_stride, int32_t in_features, int32_t act_stride,
                         int32_t aligned16, int32_t num_cus, int32_t* plan8);
+
+/* Several products of ONE shape, stride pair and row count in one launch + one reduction -- the same-shape layers of a network
+ * (models.py:63-70: layers_xyz[*] and fc_feat are all hidden x hidden).  A job gets 1 / jobs of the CUs and jobs times the
+ * samples per workgroup: the same matrix work, but jobs times fewer per-workgroup partials to write and to reduce (eight
+ * 256 x 256 layers: 64 MB instead of 512 MB) and 2 launches instead of 2 * jobs.  At most 16 jobs; the workspace of ONE
+ * product (nm_weight_grad_workspace_bytes_ex) suffices.  Deterministic; the summation grouping differs from jobs separate
+ * calls (fewer, longer sample parts). */
+typedef struct nm_weight_grad_job {
+    const float* d_delta;    /* (n, out_features), row stride delta_stride */
+    const float* d_act;      /* (n, in_features), row stride act_stride    */
+    float* d_dw;             /* d_dw[o * dw_ld + dw_col0 + c]               */
+    int32_t dw_ld, dw_col0;
+    float* d_dbias;          /* (out_features,) or NULL                     */
+} nm_weight_grad_job;
+int nm_weight_grad_batch(int num_cus, int32_t jobs, const nm_weight_grad_job* job, int32_t out_features, int32_t delta_stride,
+                         int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace, void* stream);
 int64_t nm_head_grad_workspace_bytes_ex(int32_t in_features);
 int nm_head_grad_ex(const float* d_dlast, const float* d_act, int32_t in_features, int32_t act_stride, int64_t n,
                     void* d_workspace, float* d_dw, float* d_dbias, void* stream);

@@ -42,6 +42,11 @@ class MlpDeltas(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_last")]
 
 
+class WeightGradJob(C.Structure):
+    _fields_ = [("d_delta", c_void_p), ("d_act", c_void_p), ("d_dw", c_void_p), ("dw_ld", C.c_int32), ("dw_col0", C.c_int32),
+                ("d_dbias", c_void_p)]
+
+
 class BundleGrads(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("d_rgb_map", "d_acc_map", "d_depth_map", "d_weights")]
 
@@ -110,6 +115,8 @@ SIGNATURES = {
     "nm_weight_grad_workspace_bytes_ex": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "nm_weight_grad_ex": (C.c_int, [C.c_int, c_void_p, C.c_int32, C.c_int32, c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_p,
                                     c_void_p, C.c_int32, C.c_int32, c_void_p, c_void_p]),
+    "nm_weight_grad_batch": (C.c_int, [C.c_int, C.c_int32, C.POINTER(WeightGradJob), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                       c_void_p, c_void_p]),
     "nm_weight_grad_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "nm_head_grad_workspace_bytes_ex": (C.c_int64, [C.c_int32]),
     "nm_head_grad_ex": (C.c_int, [c_void_p, c_void_p, C.c_int32, C.c_int32, C.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -36,10 +36,23 @@ struct DwArgs {
     float* partial_bias;     // (parts, AB * 64)
 };
 
+// Several products of ONE shape in one launch (round 5: the L same-shape layers of a network): workgroup x serves job
+// x / per_job, sample part x % per_job.  With J jobs a job gets 1 / J of the CUs and J times the samples per workgroup: the
+// same matrix work, but J times fewer partials to write and to reduce (8 x 256^2 layers: 64 MB instead of 512 MB per network)
+// and one launch + one reduction instead of J of each.
+constexpr int DW_MAX_JOBS = 16;
+struct DwBatch {
+    DwArgs job[DW_MAX_JOBS];
+    int32_t jobs, per_job;
+};
+
 constexpr int DW_ROWS = 16;  // samples per chunk (4 k-groups of 4)
 
 template <int AB, int BB>
-__global__ __launch_bounds__(512, 2) void dw_kernel(const DwArgs args) {
+__global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
+    const int job_i = blockIdx.x / batch.per_job;
+    const int part_i = blockIdx.x - job_i * batch.per_job;
+    const DwArgs args = batch.job[job_i];
     constexpr int NW = 8;
     constexpr int AW = AB * 64, BW = BB * 64;
     constexpr int A_BYTES = DW_ROWS * AW * 4, B_BYTES = DW_ROWS * BW * 4, SLOT = A_BYTES + B_BYTES;
@@ -58,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwArgs args) {
     const int kpart = NBLK >= NW ? 0 : wave / NBLK;
     const int ablk = id0 / BB, bblk0 = id0 % BB;
 
-    const int64_t c_lo = args.chunks * blockIdx.x / gridDim.x, c_hi = args.chunks * (blockIdx.x + 1) / gridDim.x;
+    const int64_t c_lo = args.chunks * part_i / batch.per_job, c_hi = args.chunks * (part_i + 1) / batch.per_job;
     f32x4 acc[BPW][4][4];
 #pragma unroll
     for (int p = 0; p < BPW; ++p)
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwArgs args) {
 
     // ---- write this workgroup's partial (feature permutation undone: tile (qa, qb) row i' = 4g + r, column j' = i
     //      is dW[64 ablk + 4 i' + qa][64 bblk + 4 j' + qb])
-    const int64_t part = (int64_t)blockIdx.x * KSPLIT + kpart;
+    const int64_t part = (int64_t)part_i * KSPLIT + kpart;
     float* out = args.partial + part * (int64_t)(AW * BW);
 #pragma unroll
     for (int p = 0; p < BPW; ++p)
@@ -173,10 +186,12 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwArgs args) {
 
 // order-fixed reduction of the partials: out[o][c] = sum_p partial[p][o][c] for c < cols (padding columns dropped); the
 // threads past rows * cols reduce the bias partials.  The additions run in index order p = 0, 1, 2, ... (deterministic);
-// the loads of 16 partials are issued together so the loop is bandwidth- rather than latency-bound.
-__global__ void dw_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_bias, int parts,
-                                 int rows, int ld, int cols, float* __restrict__ out, int out_ld, int out_col0,
-                                 float* __restrict__ out_bias) {
+// the loads of 16 partials are issued together so the loop is bandwidth- rather than latency-bound.  One launch serves a
+// batch of jobs (blockIdx.y = job).
+struct DwReduceJob { const float* partial; const float* partial_bias; float* out; float* out_bias; int32_t out_ld, out_col0; };
+struct DwReduceBatch { DwReduceJob job[DW_MAX_JOBS]; };
+__global__ void dw_reduce_batch_kernel(const DwReduceBatch rb, int parts, int rows, int ld, int cols) {
+    const DwReduceJob j = rb.job[blockIdx.y];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t elems = (int64_t)rows * cols;
     const float* p;
@@ -184,14 +199,14 @@ __global__ void dw_reduce_kernel(const float* __restrict__ partial, const float*
     float* dst;
     if (t < elems) {
         const int o = (int)(t / cols), c = (int)(t - (int64_t)o * cols);
-        p = partial + (int64_t)o * ld + c;
+        p = j.partial + (int64_t)o * ld + c;
         stride = (int64_t)rows * ld;
-        dst = out + (int64_t)o * out_ld + out_col0 + c;
-    } else if (out_bias && t < elems + rows) {
+        dst = j.out + (int64_t)o * j.out_ld + j.out_col0 + c;
+    } else if (j.out_bias && t < elems + rows) {
         const int o = (int)(t - elems);
-        p = partial_bias + o;
+        p = j.partial_bias + o;
         stride = rows;
-        dst = out_bias + o;
+        dst = j.out_bias + o;
     } else {
         return;
     }
@@ -207,7 +222,6 @@ __global__ void dw_reduce_kernel(const float* __restrict__ partial, const float*
     for (; k < parts; ++k) s += p[k * stride];
     *dst = s;
 }
-
 
 // ---- the 4-row heads --------------------------------------------------------------------------------------------
 // fc_alpha (1 row) and fc_rgb (3 rows) share the delta dlast (n, 4): out[r][k] = sum_n dlast[n][r] * act[n][k] for
@@ -303,7 +317,7 @@ constexpr int HEAD_MAX_PARTS = 512;
 
 struct DwPlan {
     int ab, bb, ksplit;
-    void (*kernel)(const DwArgs);
+    void (*kernel)(const DwBatch);
 };
 static const DwPlan g_dw_plans[] = {
     {4, 4, 1, &dw_kernel<4, 4>}, {4, 1, 2, &dw_kernel<4, 1>}, {2, 4, 1, &dw_kernel<2, 4>}, {2, 1, 4, &dw_kernel<2, 1>},
@@ -328,12 +342,12 @@ int64_t weight_grad_tuned_workspace_bytes(int32_t out_features, int32_t act_stri
     return 0;
 }
 
-// The kernel above for the shipped configs' six (out, stride) pairs, n a multiple of 16, delta rows of stride out_features.
-// Returns -1 when it does not serve the call (nm_weight_grad_ex then takes the general kernel, nerf_dw_g.hip).
-int weight_grad_tuned(int device_cus, const float* d_delta, int32_t out_features, const float* d_act, int32_t act_stride,
-                      int32_t in_features, int64_t n, void* d_workspace, float* d_dw, int32_t dw_ld, int32_t dw_col0,
-                      float* d_dbias, hipStream_t stream) {
-    if (n % DW_ROWS || out_features % 64 || act_stride % 64) return -1;
+// The kernel above for the shipped configs' six (out, stride) pairs, n a multiple of 16, delta rows of stride out_features:
+// `jobs` products of that one shape and row count in one launch.  Returns -1 when it does not serve the call
+// (nm_weight_grad_ex / nm_weight_grad_batch then take the general kernel, nerf_dw_g.hip).
+int weight_grad_tuned(int device_cus, int jobs, const nm_weight_grad_job* job, int32_t out_features, int32_t act_stride,
+                      int32_t in_features, int64_t n, void* d_workspace, hipStream_t stream) {
+    if (n % DW_ROWS || out_features % 64 || act_stride % 64 || jobs < 1 || jobs > DW_MAX_JOBS) return -1;
     const int ab = out_features / 64, bb = act_stride / 64;
     const DwPlan* plan = nullptr;
     for (const DwPlan& p : g_dw_plans)
@@ -341,19 +355,26 @@ int weight_grad_tuned(int device_cus, const float* d_delta, int32_t out_features
     if (!plan) return -1;
     const int64_t chunks = n / DW_ROWS;
     const int cus = device_cus > 0 ? device_cus : 256;
-    const int grid = (int)(chunks < cus ? chunks : cus);
-    const int parts = grid * plan->ksplit;
-    DwArgs a;
-    a.a = d_delta; a.b = d_act; a.chunks = chunks;
-    a.partial = static_cast<float*>(d_workspace);
-    a.partial_bias = a.partial + (int64_t)parts * out_features * act_stride;
+    int64_t per_job = cus / jobs;
+    per_job = per_job < 1 ? 1 : (per_job > chunks ? chunks : per_job);
+    const int parts = (int)per_job * plan->ksplit;
+    const int64_t job_floats = (int64_t)parts * ((int64_t)out_features * act_stride + out_features);
+    DwBatch batch;
+    DwReduceBatch rb;
+    batch.jobs = jobs; batch.per_job = (int)per_job;
+    for (int j = 0; j < jobs; ++j) {
+        DwArgs& a = batch.job[j];
+        a.a = job[j].d_delta; a.b = job[j].d_act; a.chunks = chunks;
+        a.partial = static_cast<float*>(d_workspace) + j * job_floats;
+        a.partial_bias = a.partial + (int64_t)parts * out_features * act_stride;
+        rb.job[j] = DwReduceJob{a.partial, a.partial_bias, job[j].d_dw, job[j].d_dbias, job[j].dw_ld, job[j].dw_col0};
+    }
     const int lds_bytes = 4 * DW_ROWS * (out_features + act_stride) * 4;
-    NM_REQUIRE(lds_bytes <= 160 * 1024, "weight_grad: LDS budget exceeded");
     if (int rc = ensure_dynamic_lds((const void*)plan->kernel, lds_bytes)) return rc;
-    hipLaunchKernelGGL(plan->kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
+    hipLaunchKernelGGL(plan->kernel, dim3((unsigned)(per_job * jobs)), dim3(512), lds_bytes, stream, batch);
     const int64_t elems = (int64_t)out_features * in_features;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((elems + out_features + 255) / 256)), dim3(256), 0, stream,
-                       a.partial, a.partial_bias, parts, out_features, act_stride, in_features, d_dw, dw_ld, dw_col0, d_dbias);
+    hipLaunchKernelGGL(dw_reduce_batch_kernel, dim3((unsigned)((elems + out_features + 255) / 256), jobs), dim3(256), 0, stream, rb, parts,
+                       out_features, act_stride, in_features);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -67,6 +67,16 @@ struct DwGArgs {
     int32_t epi_rows, epi_act;     // rows of the real output; 0 none, 1 ReLU, 2 sigmoid
 };
 
+// a batch of products of ONE shape, stride set and row count (nm_weight_grad_batch): everything in `common` but the four
+// per-job pointers.  Workgroup x serves job x / per_job, sample part x % per_job (see DwBatch in nerf_dw.hip for the why).
+constexpr int DWG_MAX_JOBS = 16;
+struct DwGJob { const float* a; const float* b; float* partial; float* partial_bias; };
+struct DwGBatch {
+    DwGArgs common;
+    DwGJob job[DWG_MAX_JOBS];
+    int32_t jobs, per_job;
+};
+
 #define NM_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt(int pieces) {     // wave-uniform run-time count (the instruction takes an immediate)
     switch (pieces) {
@@ -97,8 +107,12 @@ struct DwStream {
 // 64-feature block with ONE ds_read_b128 -- register q is then the operand of "tile q" whose index i stands for feature 4 i + q,
 // the tuned kernel's mapping: 3 reads instead of 12 per 32 MFMAs, conflict-free for 64-float-multiple strides.
 template <int TA, int TB, bool VEC = false>
-__global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
+__global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGBatch batch) {
     static_assert(!VEC || (TA % 4 == 0 && TB % 4 == 0), "VEC: whole 64-feature blocks per wave");
+    const DwGArgs& args = batch.common;
+    const int job_i = blockIdx.x / batch.per_job;
+    const int part_i = blockIdx.x - job_i * batch.per_job;
+    const DwGJob job = batch.job[job_i];
     constexpr int NW = 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -109,17 +123,17 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     const int wa_i = rem / args.wb, wb_i = rem - wa_i * args.wb;
     const int rows = args.rows;
     const int64_t chunks = (args.n + rows - 1) / rows;
-    const int64_t c_lo = chunks * blockIdx.x / gridDim.x, c_hi = chunks * (blockIdx.x + 1) / gridDim.x;
+    const int64_t c_lo = chunks * part_i / batch.per_job, c_hi = chunks * (part_i + 1) / batch.per_job;
     const int slot_bytes = args.A.img + args.B.img;
 
     // descriptors rebased to this workgroup's first row and column block: offsets stay below 2^32, num_records is what is
     // left of the operand from there (the tail rows of the last chunk and everything past the operand read as zeros)
-    auto open = [&](const DwOperand& op, int blk) {
+    auto open = [&](const DwOperand& op, const float* base_ptr, int blk) {
         DwStream s;
         const int64_t skip = (c_lo * rows * op.ld + (int64_t)blk * op.blk_cols) * 4;
         int64_t left = op.bytes - skip;
         left = left < 0 ? 0 : (left > 0xfffffff0ll ? 0xfffffff0ll : left);
-        char* base = const_cast<char*>(reinterpret_cast<const char*>(op.base) + skip);
+        char* base = const_cast<char*>(reinterpret_cast<const char*>(base_ptr) + skip);
         s.safe = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)(uint32_t)left, 0x00020000);
         s.fast = __builtin_amdgcn_make_buffer_rsrc(base, (short)(op.x4 ? 16 : 4), 0x7fffffff, 1 << 23);
         const int total = op.nseg * op.pps;
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
         s.loff = (uint32_t)seg * (uint32_t)op.lstride + (uint32_t)(k * unit);
         return s;
     };
-    const DwStream sa = open(args.A, blockIdx.y), sb = open(args.B, blockIdx.z);
+    const DwStream sa = open(args.A, job.a, blockIdx.y), sb = open(args.B, job.b, blockIdx.z);
     const int my_pieces = sa.count + sb.count;
     const uint32_t lane16 = lane * 16, lane4 = lane * 4;
 
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     float bias[TA];
 #pragma unroll
     for (int qa = 0; qa < TA; ++qa) bias[qa] = 0.0f;
-    const bool bias_owner = wb_i == 0 && blockIdx.z == 0 && args.partial_bias != nullptr;
+    const bool bias_owner = wb_i == 0 && blockIdx.z == 0 && job.partial_bias != nullptr;
 
     // this lane's operands of k-group kg of a chunk: row 4 * (kg * wk + wk_i) + g, columns 16 * (tile) + i
     const int kgw = rows / (4 * args.wk);
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
     // ---- this workgroup's partial.  The MFMA's row operand is the ACTIVATION tile, its column operand the delta tile, so
     //      tile (qa, qb) register r of lane (g, i) is dW[16 ta + i][16 tb + 4 g + r]: four consecutive floats of a row of dW
     //      per lane, one 16-byte store per tile
-    const int64_t part = (int64_t)blockIdx.x * args.wk + wk_i;
+    const int64_t part = (int64_t)part_i * args.wk + wk_i;
     const int row0 = (blockIdx.y * args.wa + wa_i) * TA * 16, col0 = (blockIdx.z * args.wb + wb_i) * TB * 16;
     // element (row, 4 consecutive columns) of the output a lane holds for (qa, group of 4 registers / tiles):
     //   plain: tile (qa, qb), registers r = 0..3  -> row 16 qa + i,          columns 16 qb + 4 g + (0..3)
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
         });
         return;
     }
-    float* out = args.partial + part * ((int64_t)args.out_pad * args.in_pad);
+    float* out = job.partial + part * ((int64_t)args.out_pad * args.in_pad);
     emit([&](int row, int col, f32x4 v) { *reinterpret_cast<f32x4*>(out + (int64_t)row * args.in_pad + col) = v; });
     if (bias_owner) {
         // lane (g, i) holds the sum over its rows (= g mod 4 of its k-groups) of one feature per qa: fold the 4 lane groups
@@ -323,15 +337,17 @@ __global__ __launch_bounds__(512, 2) void dw_kernel_g(const DwGArgs args) {
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             const int feature = VEC ? 64 * (qa / 4) + 4 * i + (qa % 4) : 16 * qa + i;
-            if (g == 0) args.partial_bias[part * args.out_pad + row0 + feature] = v;
+            if (g == 0) job.partial_bias[part * args.out_pad + row0 + feature] = v;
         }
     }
 }
 
-// order-fixed reduction of the partials (parts in index order, 16 loads in flight); threads past rows * cols do the biases
-__global__ void dw_reduce_g_kernel(const float* __restrict__ partial, const float* __restrict__ partial_bias, int parts,
-                                   int64_t part_stride, int bias_stride, int rows, int ld, int cols, float* __restrict__ out,
-                                   int out_ld, int out_col0, float* __restrict__ out_bias) {
+// order-fixed reduction of the partials (parts in index order, 16 loads in flight); threads past rows * cols do the biases;
+// blockIdx.y = job of a batch
+struct DwGReduceJob { const float* partial; const float* partial_bias; float* out; float* out_bias; int32_t out_ld, out_col0; };
+struct DwGReduceBatch { DwGReduceJob job[DWG_MAX_JOBS]; };
+__global__ void dw_reduce_g_kernel(const DwGReduceBatch rb, int parts, int64_t part_stride, int bias_stride, int rows, int ld, int cols) {
+    const DwGReduceJob j = rb.job[blockIdx.y];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t elems = (int64_t)rows * cols;
     const float* p;
@@ -339,14 +355,14 @@ __global__ void dw_reduce_g_kernel(const float* __restrict__ partial, const floa
     float* dst;
     if (t < elems) {
         const int o = (int)(t / cols), c = (int)(t - (int64_t)o * cols);
-        p = partial + (int64_t)o * ld + c;
+        p = j.partial + (int64_t)o * ld + c;
         stride = part_stride;
-        dst = out + (int64_t)o * out_ld + out_col0 + c;
-    } else if (out_bias && t < elems + rows) {
+        dst = j.out + (int64_t)o * j.out_ld + j.out_col0 + c;
+    } else if (j.out_bias && t < elems + rows) {
         const int o = (int)(t - elems);
-        p = partial_bias + o;
+        p = j.partial_bias + o;
         stride = bias_stride;
-        dst = out_bias + o;
+        dst = j.out_bias + o;
     } else {
         return;
     }
@@ -478,7 +494,7 @@ __global__ __launch_bounds__(256) void head_reduce_g_kernel(const float* __restr
 }
 
 // ---- host side: the planner ------------------------------------------------------------------------------------------
-typedef void (*DwGKernel)(const DwGArgs);
+typedef void (*DwGKernel)(const DwGBatch);
 constexpr int DWG_MAX_TA = 6, DWG_MAX_TB = 8, DWG_MAX_TILES = 36;     // tiles per wave: TA x TB <= 36 (144 accumulator registers)
 template <int TA, int TB>
 constexpr DwGKernel dwg_kernel_or_null() {
@@ -627,16 +643,18 @@ int dwg_gemm(const float* A, int out, int lda, const float* B, int64_t in, int64
     if (DwGKernel vec = dwg_vec_kernel(g.ta, g.tb))
         if (dwg_vec_ok(a)) kernel = vec;
     if (int rc = ensure_dynamic_lds((const void*)kernel, lds_bytes)) return rc;
-    hipLaunchKernelGGL(kernel, dim3(1, g.nba, g.nbb), dim3(512), lds_bytes, stream, a);
+    DwGBatch batch;
+    batch.common = a; batch.jobs = 1; batch.per_job = 1;
+    batch.job[0] = DwGJob{A, B, partial, nullptr};
+    hipLaunchKernelGGL(kernel, dim3(1, g.nba, g.nbb), dim3(512), lds_bytes, stream, batch);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 // the kernels tuned for the shipped configs' shapes (nerf_dw.hip); -1 = "not mine"
 int64_t weight_grad_tuned_workspace_bytes(int32_t out_features, int32_t act_stride, int32_t num_cus);
-int weight_grad_tuned(int device_cus, const float* d_delta, int32_t out_features, const float* d_act, int32_t act_stride,
-                      int32_t in_features, int64_t n, void* d_workspace, float* d_dw, int32_t dw_ld, int32_t dw_col0,
-                      float* d_dbias, hipStream_t stream);
+int weight_grad_tuned(int device_cus, int jobs, const nm_weight_grad_job* job, int32_t out_features, int32_t act_stride,
+                      int32_t in_features, int64_t n, void* d_workspace, hipStream_t stream);
 int head_grad_tuned(const float* d_dlast, const float* d_act, int32_t in_features, int64_t n, void* d_workspace, float* d_dw,
                     float* d_dbias, hipStream_t stream);
 static bool general_only() { const char* e = getenv("NM_DW_GENERAL"); return e && *e && *e != '0'; }   // A/B hook of the tools
@@ -663,56 +681,80 @@ extern "C" int64_t nm_weight_grad_workspace_bytes_ex(int32_t out_features, int32
 
 // The general form of nm_weight_grad: d_delta (n, >= out_features) with row stride delta_stride, d_act (n, >= in_features) with
 // row stride act_stride (floats), any n >= 1, any widths the planner can tile (up to 8 blocks of 8 x 6 / 8 x 8 tiles per side).
-extern "C" int nm_weight_grad_ex(int device_cus, const float* d_delta, int32_t out_features, int32_t delta_stride,
-                                 const float* d_act, int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace,
-                                 float* d_dw, int32_t dw_ld, int32_t dw_col0, float* d_dbias, void* stream_) {
-    NM_REQUIRE(d_delta && d_act && d_workspace && d_dw && n > 0, "bad argument");
+// `jobs` products of ONE shape, stride pair and row count in one launch + one reduction (the same-shape layers of a
+// network): a job gets 1 / jobs of the CUs and jobs times the samples per workgroup -- the same matrix work, jobs times fewer
+// partials to write and reduce.  The tuned kernel when it serves the shape, the general one otherwise.
+extern "C" int nm_weight_grad_batch(int device_cus, int32_t jobs, const nm_weight_grad_job* job, int32_t out_features,
+                                    int32_t delta_stride, int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace,
+                                    void* stream_) {
+    NM_REQUIRE(job && jobs >= 1 && jobs <= DWG_MAX_JOBS && d_workspace && n > 0, "bad argument");
     NM_REQUIRE(out_features >= 1 && in_features >= 1 && delta_stride >= out_features && act_stride >= in_features,
                "weight_grad: a row stride is smaller than its feature count");
-    NM_REQUIRE((reinterpret_cast<uintptr_t>(d_delta) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_act) & 3) == 0, "weight_grad: unaligned operand");
+    bool a_x4 = true, b_x4 = true;
+    for (int j = 0; j < jobs; ++j) {
+        NM_REQUIRE(job[j].d_delta && job[j].d_act && job[j].d_dw, "weight_grad: a job lacks an operand or its output");
+        NM_REQUIRE((reinterpret_cast<uintptr_t>(job[j].d_delta) & 3) == 0 && (reinterpret_cast<uintptr_t>(job[j].d_act) & 3) == 0, "weight_grad: unaligned operand");
+        a_x4 = a_x4 && dw_aligned(job[j].d_delta, delta_stride);
+        b_x4 = b_x4 && dw_aligned(job[j].d_act, act_stride);
+    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (delta_stride == out_features && !general_only()) {
-        const int rc = weight_grad_tuned(device_cus, d_delta, out_features, d_act, act_stride, in_features, n, d_workspace, d_dw,
-                                         dw_ld, dw_col0, d_dbias, stream);
+        const int rc = weight_grad_tuned(device_cus, jobs, job, out_features, act_stride, in_features, n, d_workspace, stream);
         if (rc >= 0) return rc;
     }
     const int cus = device_cus > 0 ? device_cus : 256;
-    const bool a_x4 = dw_aligned(d_delta, delta_stride), b_x4 = dw_aligned(d_act, act_stride);
     DwGPlan p;
     NM_REQUIRE(plan_dw_g(out_features, delta_stride, in_features, act_stride, a_x4, b_x4, cus, &p),
                "weight_grad: no tiling for this (out, in) shape (rows wider than the LDS ring holds)");
     const int64_t chunks = (n + p.rows - 1) / p.rows;
-    int64_t grid_x = cus / (p.nba * p.nbb);
-    grid_x = grid_x < 1 ? 1 : (grid_x > chunks ? chunks : grid_x);
-    NM_REQUIRE((chunks / grid_x + 2) * p.rows * (int64_t)(delta_stride > act_stride ? delta_stride : act_stride) * 4 < 0xf0000000ll,
+    int64_t per_job = cus / (p.nba * p.nbb * jobs);
+    per_job = per_job < 1 ? 1 : (per_job > chunks ? chunks : per_job);
+    NM_REQUIRE((chunks / per_job + 2) * p.rows * (int64_t)(delta_stride > act_stride ? delta_stride : act_stride) * 4 < 0xf0000000ll,
                "weight_grad: a workgroup's sample range exceeds 32-bit offsets");
-    DwGArgs a;
-    auto fill = [&](DwOperand& op, const float* base, int ld, int blk_cols, bool split, bool x4) {
-        op.base = base; op.bytes = n * (int64_t)ld * 4; op.ld = ld; op.x4 = x4;
+    DwGBatch batch;
+    DwGArgs& a = batch.common;
+    auto fill = [&](DwOperand& op, int ld, int blk_cols, bool split, bool x4) {
+        op.base = nullptr; op.bytes = n * (int64_t)ld * 4; op.ld = ld; op.x4 = x4;
         operand_image(p.rows, ld, blk_cols, split, x4, &op.ls, &op.nseg, &op.pps, &op.lstride, &op.img);
         op.gstride = ld * 4; op.blk_cols = split ? blk_cols : 0;
     };
-    fill(a.A, d_delta, delta_stride, p.wa * p.ta * 16, p.nba > 1, a_x4);
-    fill(a.B, d_act, act_stride, p.wb * p.tb * 16, p.nbb > 1, b_x4);
+    fill(a.A, delta_stride, p.wa * p.ta * 16, p.nba > 1, a_x4);
+    fill(a.B, act_stride, p.wb * p.tb * 16, p.nbb > 1, b_x4);
     a.n = n; a.rows = p.rows; a.wa = p.wa; a.wb = p.wb; a.wk = p.wk;
     a.epi_out = nullptr; a.epi_bias = nullptr; a.epi_mask = nullptr; a.epi_ld = 0; a.epi_rows = 0; a.epi_act = 0;
     a.out_pad = p.nba * p.wa * p.ta * 16; a.in_pad = p.nbb * p.wb * p.tb * 16;
-    const int parts = (int)grid_x * p.wk;
-    a.partial = static_cast<float*>(d_workspace);
-    a.partial_bias = a.partial + (int64_t)parts * a.out_pad * a.in_pad;
+    a.partial = nullptr; a.partial_bias = nullptr;
+    const int parts = (int)per_job * p.wk;
+    const int64_t job_floats = (int64_t)parts * ((int64_t)a.out_pad * a.in_pad + a.out_pad);
+    batch.jobs = jobs; batch.per_job = (int)per_job;
+    DwGReduceBatch rb;
+    for (int j = 0; j < jobs; ++j) {
+        float* partial = static_cast<float*>(d_workspace) + j * job_floats;
+        float* partial_bias = partial + (int64_t)parts * a.out_pad * a.in_pad;
+        batch.job[j] = DwGJob{job[j].d_delta, job[j].d_act, partial, partial_bias};
+        rb.job[j] = DwGReduceJob{partial, partial_bias, job[j].d_dw, job[j].d_dbias, job[j].dw_ld, job[j].dw_col0};
+    }
     const int lds_bytes = 4 * (a.A.img + a.B.img) + DWG_SLACK;
     NM_REQUIRE(lds_bytes <= DWG_LDS_BYTES, "weight_grad: LDS budget exceeded");
     DwGKernel kernel = g_dwg_kernels[p.ta - 1][p.tb - 1];
     if (DwGKernel vec = dwg_vec_kernel(p.ta, p.tb))
         if (dwg_vec_ok(a)) kernel = vec;
     if (int rc = ensure_dynamic_lds((const void*)kernel, lds_bytes)) return rc;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid_x, p.nba, p.nbb), dim3(512), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(per_job * jobs), p.nba, p.nbb), dim3(512), lds_bytes, stream, batch);
     const int64_t elems = (int64_t)out_features * in_features;
-    hipLaunchKernelGGL(dw_reduce_g_kernel, dim3((unsigned)((elems + out_features + 255) / 256)), dim3(256), 0, stream, a.partial,
-                       a.partial_bias, parts, (int64_t)a.out_pad * a.in_pad, a.out_pad, out_features, a.in_pad, in_features, d_dw,
-                       dw_ld, dw_col0, d_dbias);
+    hipLaunchKernelGGL(dw_reduce_g_kernel, dim3((unsigned)((elems + out_features + 255) / 256), jobs), dim3(256), 0, stream, rb, parts,
+                       (int64_t)a.out_pad * a.in_pad, a.out_pad, out_features, a.in_pad, in_features);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// one product = a batch of one
+extern "C" int nm_weight_grad_ex(int device_cus, const float* d_delta, int32_t out_features, int32_t delta_stride,
+                                 const float* d_act, int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace,
+                                 float* d_dw, int32_t dw_ld, int32_t dw_col0, float* d_dbias, void* stream_) {
+    NM_REQUIRE(d_delta && d_act && d_workspace && d_dw && n > 0, "bad argument");
+    const nm_weight_grad_job job = {d_delta, d_act, d_dw, dw_ld, dw_col0, d_dbias};
+    return nm_weight_grad_batch(device_cus, 1, &job, out_features, delta_stride, in_features, act_stride, n, d_workspace, stream_);
 }
 
 // what the planner chose for a shape (tools / tests): [nba, nbb, wa, wb, wk, ta, tb, rows]

@@ -171,38 +171,61 @@ struct EncodeArgs {
     int32_t stride_x, stride_d;   // floats per output row (>= the encoding width; the tail of a row is left untouched)
 };
 
-// PositionalEncoding rows for the weight-gradient kernels: WHOLE rows of the given strides (zero padding included), ONE
-// OUTPUT ELEMENT PER THREAD so that a wavefront writes 256 contiguous bytes (a row-per-thread kernel issues 4-byte stores a
-// row apart: 0.63 ms for 393 216 samples; this one is bandwidth-bound).  sincosf is evaluated on the same product as
-// encode<>() and one of its two results kept, so the values are bit-identical to the forward kernel's.
-// Thread e serves column e % smax of sample e / smax in both encodings (smax = the larger stride; 64 for the tuned shapes).
-__global__ __launch_bounds__(256) void encode_samples_rows_kernel(const EncodeArgs args, const int smax) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = smax == 64 ? e >> 6 : e / smax;
-    const int j = (int)(e - i * smax);
-    if (i >= args.n) return;
-    const int64_t ray = i / args.samples;
-    const float t = args.t[i];
-    const float* o = args.origins + (args.origins_per_ray ? 3 * ray : 0);
-    float p[3], d[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        d[k] = args.dirs[3 * ray + k];
-        const float dt = d[k] * t;
-        p[k] = o[k] + dt;
+// PositionalEncoding rows for the weight-gradient kernels: WHOLE rows of the given strides (zero padding included).  A thread
+// serves one work item of one sample of one encoding (blockIdx.y: 0 = xyz, 1 = direction): item w < 3 F is ARGUMENT w -- one
+// sincosf, both results written (sin at column base + w, cos at base + 3 F + w: neighbouring threads write neighbouring
+// floats) --, the items behind are the remaining columns one by one (the input itself, the zero padding).  Index arithmetic in
+// 32 bits whenever the launch allows it (a 64-bit division is ~100 instructions; the first version spent more time dividing
+// than encoding).  sincosf is evaluated on the same product as encode<>(): the values are bit-identical to the forward kernel's.
+__global__ __launch_bounds__(256) void encode_samples_rows_kernel(const EncodeArgs args, const int narrow) {
+    const bool dir = blockIdx.y == 1;
+    float* out = dir ? args.enc_d : args.enc_x;
+    if (!out) return;
+    const int F = dir ? args.fd : args.fx, include = dir ? args.include_d : args.include_x, stride = dir ? args.stride_d : args.stride_x;
+    const int items = stride - 3 * F;                       // 3 F arguments + (stride - 6 F) plain columns
+    const float* bands = dir ? args.bands_dir : args.bands_xyz;
+    const int base = include ? 3 : 0;
+    const int64_t total = args.n * items;
+    // a grid-stride loop over the work items: a few thousand workgroups that stay, not one per 256 items (the dispatcher, not
+    // the memory system, bounded the one-shot form: 10^5 workgroups of a few instructions each)
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    int64_t i, ray;
+    int w;
+    if (narrow) {                                           // n * items < 2^31
+        const unsigned iu = (unsigned)e / (unsigned)items;
+        w = (int)((unsigned)e - iu * (unsigned)items);
+        i = iu;
+        ray = iu / (unsigned)args.samples;
+    } else {
+        i = e / items;
+        w = (int)(e - i * items);
+        ray = i / args.samples;
     }
-    auto element = [&](const float (&x)[3], int F, int include, const float* bands) -> float {
-        const int base = include ? 3 : 0;
-        if (j < base) return x[j];
-        const int a = j - base;
-        if (a >= 6 * F) return 0.0f;                       // zero padding up to the stride
-        const int arg = a < 3 * F ? a : a - 3 * F;
+    float x[3];
+    if (dir) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = args.dirs[3 * ray + k];
+    } else {
+        const float t = args.t[i];
+        const float* o = args.origins + (args.origins_per_ray ? 3 * ray : 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float dt = args.dirs[3 * ray + k] * t;
+            x[k] = o[k] + dt;
+        }
+    }
+    float* row = out + i * stride;
+    if (w < 3 * F) {
         float sv, cv;
-        sincosf(x[arg / F] * bands[arg % F], &sv, &cv);
-        return a < 3 * F ? sv : cv;
-    };
-    if (args.enc_x && j < args.stride_x) args.enc_x[i * args.stride_x + j] = element(p, args.fx, args.include_x, args.bands_xyz);
-    if (args.enc_d && j < args.stride_d) args.enc_d[i * args.stride_d + j] = element(d, args.fd, args.include_d, args.bands_dir);
+        sincosf(x[w / F] * bands[w % F], &sv, &cv);
+        row[base + w] = sv;
+        row[base + 3 * F + w] = cv;
+    } else {
+        const int c = w - 3 * F;                             // the c-th column that is not a sine / cosine
+        if (c < base) row[c] = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+        else row[6 * F + c] = 0.0f;
+    }
+    }
 }
 
 // ---- plan tables -------------------------------------------------------------------------------------------
@@ -407,11 +430,14 @@ int nm_encode_samples_strided(nm_mlp* m, const float* d_origins, int origins_per
     a.enc_x = d_enc_xyz; a.enc_d = d_enc_dir;
     a.stride_x = stride_xyz; a.stride_d = stride_dir;
     if (a.n == 0) return 0;
-    // whole rows, one element per thread (zero padding up to the stride included)
-    const int smax = (d_enc_xyz ? stride_xyz : 0) > (d_enc_dir ? stride_dir : 0) ? stride_xyz : stride_dir;
-    if (smax <= 0) return 0;
-    hipLaunchKernelGGL(encode_samples_rows_kernel, dim3((unsigned)((a.n * smax + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a, smax);
+    // whole rows (zero padding up to the stride included); grid y: the two encodings
+    const int items_x = d_enc_xyz ? stride_xyz - 3 * a.fx : 0, items_d = d_enc_dir ? stride_dir - 3 * a.fd : 0;
+    const int items = items_x > items_d ? items_x : items_d;
+    if (items <= 0) return 0;
+    const int narrow = a.n * items + 256 < (1ll << 31) ? 1 : 0;
+    const int64_t blocks = (a.n * items + 255) / 256, cap = (int64_t)(m->num_cus > 0 ? m->num_cus : 256) * 8;
+    hipLaunchKernelGGL(encode_samples_rows_kernel, dim3((unsigned)(blocks < cap ? blocks : cap), d_enc_dir ? 2 : 1), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a, narrow);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }

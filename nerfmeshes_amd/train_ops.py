@@ -20,7 +20,7 @@ import ctypes as C
 import torch
 
 from . import _lib, hip_ops
-from ._lib import BundleGrads, MlpDeltas, MlpTape, MlpWeights, check
+from ._lib import BundleGrads, MlpDeltas, MlpTape, MlpWeights, WeightGradJob, check
 from .hip_ops import _dev32, _ptr, _stream
 
 
@@ -175,6 +175,27 @@ def _weight_grad(mlp, delta, act, in_features, out=None, col0=0, bias=True):
     return out, db
 
 
+def _weight_grad_batch(mlp, jobs):
+    """Several dW products in as few launches as possible: `jobs` = [(delta, act, in_features, out, col0, bias tensor | None)];
+    products of one shape, stride pair and row count go through nm_weight_grad_batch together (one launch + one reduction,
+    1 / len of the partials each: the L same-shape layers of a network), in groups of at most 16."""
+    lib = _lib.load()
+    cus = int(lib.nm_mlp_num_cus(mlp.handle))
+    groups = {}
+    for job in jobs:
+        delta, act, in_features = job[0], job[1], job[2]
+        assert delta.stride(1) == 1 and act.stride(1) == 1 and act.shape[0] == delta.shape[0]
+        groups.setdefault((delta.shape[1], delta.stride(0), in_features, act.stride(0), delta.shape[0]), []).append(job)
+    for (o, lda, in_features, ldb, n), group in groups.items():
+        ws = _workspace(mlp, "dw", int(lib.nm_weight_grad_workspace_bytes_ex(o, lda, in_features, ldb, cus)))
+        for s0 in range(0, len(group), 16):
+            part = group[s0:s0 + 16]
+            arr = (WeightGradJob * len(part))(*[WeightGradJob(_ptr(d), _ptr(a), _ptr(out), out.shape[1], col0, _ptr(db))
+                                                 for d, a, _, out, col0, db in part])
+            with _stage("weight_gradients"):
+                check(lib.nm_weight_grad_batch(cus, len(part), arr, o, lda, in_features, ldb, n, _ptr(ws), _stream()), "nm_weight_grad_batch")
+
+
 def _head_grad(mlp, dlast, act, bias=False):
     """(4, K) = dlast^T @ act for the heads that share dlast (n, 4) (+ its column sums): nm_head_grad_ex, HBM-bound VALU
     kernel with the order-fixed partial reduction; any activation width."""
@@ -219,17 +240,36 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     with _stage("encodings"):
         check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
                                             samples, _ptr(enc_x), sx, _ptr(enc_d), sd, _stream()), "nm_encode_samples_strided")
-    g = {}
-    g["layer1.weight"], g["layer1.bias"] = _weight_grad(mlp, dh[0], enc_x, dx)
+    # every dW product of the backward as a job (delta, act, in_features, out, col0, bias): the same-shape ones -- the hidden x hidden
+    # layers, the two encoding products -- each go out as ONE launch (nm_weight_grad_batch)
+    g, jobs = {}, []
+
+    def product(name, delta, act, in_features, out=None, col0=0, bias=True):
+        o = delta.shape[1]
+        if out is None:
+            out = torch.empty(o, in_features, **f32)
+        db = torch.empty(o, **f32) if bias else None
+        jobs.append((delta, act, in_features, out, col0, db))
+        if bias:
+            g[name + ".bias"] = db
+        g[name + ".weight"] = out
+
+    product("layer1", dh[0], enc_x, dx)
     for i in range(L - 1):
         delta = dh[1 + i]
-        if is_skip(i):
+        if is_skip(i):                                                                  # cat(x, xyz): models.py:64-65
             gw = torch.empty(H, H + dx, **f32)
-            _, gb = _weight_grad(mlp, delta, h[i], H, out=gw, col0=0)
-            _weight_grad(mlp, delta, enc_x, dx, out=gw, col0=H, bias=False)
+            product(f"layers_xyz.{i}", delta, h[i], H, out=gw, col0=0)
+            product(f"layers_xyz.{i}", delta, enc_x, dx, out=gw, col0=H, bias=False)
         else:
-            gw, gb = _weight_grad(mlp, delta, h[i], H)
-        g[f"layers_xyz.{i}.weight"], g[f"layers_xyz.{i}.bias"] = gw, gb
+            product(f"layers_xyz.{i}", delta, h[i], H)
+    if not flat:
+        product("fc_feat", dfeat, h[L - 1], H)
+        gw = torch.empty(H // 2, H + dd, **f32)                                        # cat(feat, view): models.py:72
+        product("layers_dir.0", dv, feat, H, out=gw, col0=0)
+        if dd:
+            product("layers_dir.0", dv, enc_d, dd, out=gw, col0=H, bias=False)
+    _weight_grad_batch(mlp, jobs)
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
     if flat:
@@ -237,12 +277,6 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         # exactly dlast^T @ h[L-1] and dlast's column sums (models.py:77-79)
         g["fc_out.weight"], g["fc_out.bias"] = _head_grad(mlp, dlast, h[L - 1], bias=True)
         return g
-    g["fc_feat.weight"], g["fc_feat.bias"] = _weight_grad(mlp, dfeat, h[L - 1], H)
-    gw = torch.empty(H // 2, H + dd, **f32)                                            # cat(feat, view): models.py:72
-    _, g["layers_dir.0.bias"] = _weight_grad(mlp, dv, feat, H, out=gw, col0=0)
-    if dd:
-        _weight_grad(mlp, dv, enc_d, dd, out=gw, col0=H, bias=False)
-    g["layers_dir.0.weight"] = gw
     (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, h[L - 1], bias=True), _head_grad(mlp, dlast, v)
     g["fc_alpha.weight"], g["fc_alpha.bias"] = gh[3:4], last_sums[3:4]
     g["fc_rgb.weight"], g["fc_rgb.bias"] = gv[:3], last_sums[:3]

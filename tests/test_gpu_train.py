@@ -555,3 +555,40 @@ def test_general_head_grad_kernel_vs_fp64(n, k, ld, monkeypatch):
     assert float((dw.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5)
     assert float((db.double().cpu() - dlast.double().sum(0)).abs().max()) <= 2e-6 * float(dlast.abs().sum(0).max() + 1)
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "not deterministic"
+
+
+@pytest.mark.parametrize("out_f,in_f,jobs,n,general", [(256, 256, 8, 4096, False), (256, 256, 8, 4096, True), (128, 128, 3, 1040, False),
+                                                       (100, 100, 5, 583, True), (320, 320, 16, 2000, True), (64, 39, 2, 37, True)])
+def test_weight_grad_batch_vs_fp64(out_f, in_f, jobs, n, general, monkeypatch):
+    """nm_weight_grad_batch: the same-shape layers of a network in ONE launch + one reduction (a job gets 1 / jobs of the CUs) --
+    every job against delta^T @ act in fp64, tuned and general kernel, ragged row counts, a shared output with column windows."""
+    from nerfmeshes_amd import hip_ops, train_ops as T
+    if general:
+        monkeypatch.setenv("NM_DW_GENERAL", "1")
+    kw = dict(num_layers=4, hidden_size=128, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    mlp = hip_ops.HipMLP({k: torch.as_tensor(v) for k, v in S.make_mlp_weights(3, **kw).items()}, kw, "cuda")
+    g = torch.Generator().manual_seed(n + out_f + jobs)
+    ldb = (in_f + 3) & ~3
+    deltas = [torch.randn(n, out_f, generator=g) * (torch.rand(n, 1, generator=g) < 0.7) for _ in range(jobs)]
+    acts = [torch.relu(torch.randn(n, in_f, generator=g)) for _ in range(jobs)]
+    wide = torch.full((out_f, in_f + 7), 5.0, device="cuda")
+    todo, outs = [], []
+    for j in range(jobs):
+        buf = torch.full((n, ldb), float("nan"), device="cuda")
+        buf[:, :in_f] = acts[j].cuda()
+        out = wide if j == 0 else torch.empty(out_f, in_f, device="cuda")
+        db = torch.empty(out_f, device="cuda") if j % 2 == 0 else None
+        todo.append((deltas[j].cuda().contiguous(), buf[:, :in_f], in_f, out, 7 if j == 0 else 0, db))
+        outs.append((out[:, 7:] if j == 0 else out, db))
+    T._weight_grad_batch(mlp, todo)
+    first = [(o.clone(), None if b is None else b.clone()) for o, b in outs]
+    T._weight_grad_batch(mlp, todo)
+    for j, ((o, b), (o1, b1)) in enumerate(zip(outs, first)):
+        ref = deltas[j].double().t() @ acts[j].double()
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((o.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n / 1000) ** 0.5), j
+        assert torch.equal(o, o1), "not deterministic"
+        if b is not None:
+            assert float((b.double().cpu() - deltas[j].double().sum(0)).abs().max()) <= 2e-6 * float(deltas[j].abs().sum(0).max() + 1)
+            assert torch.equal(b, b1)
+    assert bool((wide[:, :7] == 5.0).all()), "wrote outside its column window"
