@@ -527,6 +527,16 @@ struct DwGPlan {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// DMA element of an operand: 16 bytes when base and stride allow -- except for a NARROW column block of a split operand, whose
+// rows round up to whole pieces in LDS: an 80-float block is 1 KiB per row with 16-byte pieces, 512 B with 4-byte ones (what
+// lets a 400-wide product take five 80-row blocks inside the LDS budget)
+static inline bool pick_x4(bool aligned, bool split, int blk_cols) {
+    if (!aligned) return false;
+    if (!split) return true;
+    const int bytes = blk_cols * 4;
+    return ((bytes + 1023) / 1024) * 1024 <= ((bytes + 255) / 256) * 256;
+}
+
 // image bytes of `rows` rows of an operand: contiguous run (unsplit) or one run per row (split), rounded to whole pieces
 static inline void operand_image(int rows, int ld, int blk_cols, bool split, bool x4, int* ls, int* nseg, int* pps, int* lstride, int* img) {
     const int unit = x4 ? 1024 : 256;
@@ -565,9 +575,9 @@ static bool plan_dw_g(int out, int lda, int in, int ldb, bool a_x4, bool b_x4, i
                 for (int rows = 4 * wk < 16 ? 16 : 4 * wk; rows <= 256; rows *= 2) {
                     if (forced && !(nba == force[0] && nbb == force[1] && wa == force[2] && wb == force[3] && wk == force[4] && rows == force[5])) continue;
                     int lsa, lsb, nseg, pps, lstride, imga, imgb;
-                    operand_image(rows, lda, wa * ta * 16, nba > 1, a_x4, &lsa, &nseg, &pps, &lstride, &imga);
+                    operand_image(rows, lda, wa * ta * 16, nba > 1, pick_x4(a_x4, nba > 1, wa * ta * 16), &lsa, &nseg, &pps, &lstride, &imga);
                     const int pieces_a = ceil_div(nseg * pps, 8);
-                    operand_image(rows, ldb, wb * tb * 16, nbb > 1, b_x4, &lsb, &nseg, &pps, &lstride, &imgb);
+                    operand_image(rows, ldb, wb * tb * 16, nbb > 1, pick_x4(b_x4, nbb > 1, wb * tb * 16), &lsb, &nseg, &pps, &lstride, &imgb);
                     const int pieces_b = ceil_div(nseg * pps, 8);
                     if (4 * (imga + imgb) + DWG_SLACK > DWG_LDS_BYTES) break;
                     if (2 * (pieces_a + pieces_b) > 60) break;     // vmcnt is a 6-bit counter: two chunks in flight
@@ -718,8 +728,8 @@ extern "C" int nm_weight_grad_batch(int device_cus, int32_t jobs, const nm_weigh
         operand_image(p.rows, ld, blk_cols, split, x4, &op.ls, &op.nseg, &op.pps, &op.lstride, &op.img);
         op.gstride = ld * 4; op.blk_cols = split ? blk_cols : 0;
     };
-    fill(a.A, delta_stride, p.wa * p.ta * 16, p.nba > 1, a_x4);
-    fill(a.B, act_stride, p.wb * p.tb * 16, p.nbb > 1, b_x4);
+    fill(a.A, delta_stride, p.wa * p.ta * 16, p.nba > 1, pick_x4(a_x4, p.nba > 1, p.wa * p.ta * 16));
+    fill(a.B, act_stride, p.wb * p.tb * 16, p.nbb > 1, pick_x4(b_x4, p.nbb > 1, p.wb * p.tb * 16));
     a.n = n; a.rows = p.rows; a.wa = p.wa; a.wb = p.wb; a.wk = p.wk;
     a.epi_out = nullptr; a.epi_bias = nullptr; a.epi_mask = nullptr; a.epi_ld = 0; a.epi_rows = 0; a.epi_act = 0;
     a.out_pad = p.nba * p.wa * p.ta * 16; a.in_pad = p.nbb * p.wb * p.tb * 16;
