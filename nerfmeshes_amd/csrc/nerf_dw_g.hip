@@ -21,8 +21,15 @@
 //     only, so whatever a tile reads beyond the real width (the next row's values, stale LDS) lands in accumulators of
 //     dW entries >= out / >= in that the reduction never reads.  Rows: the buffer descriptor's num_records is the exact end
 //     of the operand, so the rows of the last chunk beyond n arrive as zeros (out-of-range buffer loads return 0, also into LDS).
-//   * operands come out of LDS with ds_read_b32 at (row, 16 t + i): conflict-free whatever the stride's alignment; a
-//     wave reads TA + TB values per TA * TB MFMAs.
+//     The exact-extent (raw, VGPR-addressed) descriptor serves the LAST chunk only; interior chunks go through the
+//     ADD_TID form, which reads no address VGPR -- and makes no range check at all (probed: tests/tools/probes/).
+//   * operands come out of LDS with ds_read_b32 at (row, 16 t + i): correct whatever the stride's alignment (at most 2-way
+//     bank conflicts); a wave reads TA + TB values per TA * TB MFMAs.  The 4 x 8 / 4 x 4 geometries also exist with the
+//     tuned kernel's ds_read_b128 mapping (VEC) for 16-byte-aligned LDS rows.
+//   * several products of one shape run as ONE launch (DwGBatch: workgroup x -> job x / per_job): the L same-shape layers
+//     of a network share the CUs, each with 1 / L of the partials (nm_weight_grad_batch).
+//   * the same kernel is the GEMM of the layer-wise network path (dwg_gemm: a short contraction, a wide output, one sample
+//     part, bias / activation / mask applied to the accumulators on the way out: nerf_layerwise.hip).
 //
 // Roofline: MFMA for wide layers (2 * out * in FLOP per sample against 4 * (out + in) bytes), HBM for narrow ones (64 x 64:
 // 16 FLOP/B).
