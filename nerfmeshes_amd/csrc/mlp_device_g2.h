@@ -74,8 +74,8 @@ __device__ __forceinline__ void rgb_head_g2(const float (&v)[KD], const float* l
     }
 }
 
-template <int NT, int NW, int KCH>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_kernel_g2(const MlpArgs args, const int num_layers, const int density_only) {
+template <int NT, int NW, int KCH, int WPS = 2>
+__global__ __launch_bounds__(NW * 64, WPS) void mlp_kernel_g2(const MlpArgs args, const int num_layers, const int density_only) {
     constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
     constexpr int KH = 4 * NT, KD = 4 * NTD;
     constexpr int NB = (NT + 3) / 4, NBD = (NTD + 3) / 4;

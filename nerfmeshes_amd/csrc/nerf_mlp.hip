@@ -111,6 +111,11 @@ static const std::vector<MlpPlan>& all_plans() {
         generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_e(v);
 #ifdef NM_ABLATIONS
         // experiment (NM_MLP_VARIANT=200 + NM_KERNEL_GENERIC): two 16-sample column tiles per wave (mlp_device_g2.h)
+        // (round 5: also the classes of 2 and 3 tiles -- VERDICT r4 item 7 -- compiled for four waves per SIMD (200) and two (201))
+        v.push_back(MlpPlan{32, -1, -1, 8, 8, 200, 2 * 8 * 1024, true, &mlp_kernel_g2<2, 8, 8, 4>, 8 * 32, 1, nullptr, 2, nullptr, nullptr});
+        v.push_back(MlpPlan{48, -1, -1, 8, 8, 200, 2 * 8 * 1024, true, &mlp_kernel_g2<3, 8, 8, 4>, 8 * 32, 1, nullptr, 3, nullptr, nullptr});
+        v.push_back(MlpPlan{32, -1, -1, 8, 8, 201, 2 * 8 * 1024, true, &mlp_kernel_g2<2, 8, 8, 2>, 8 * 32, 1, nullptr, 2, nullptr, nullptr});
+        v.push_back(MlpPlan{48, -1, -1, 8, 8, 201, 2 * 8 * 1024, true, &mlp_kernel_g2<3, 8, 8, 2>, 8 * 32, 1, nullptr, 3, nullptr, nullptr});
         v.push_back(MlpPlan{64, -1, -1, 8, 8, 200, 2 * 8 * 1024, true, &mlp_kernel_g2<4, 8, 8>, 8 * 32, 1, nullptr, 4, nullptr, nullptr});
         v.push_back(MlpPlan{128, -1, -1, 8, 8, 200, 2 * 8 * 2 * 1024, true, &mlp_kernel_g2<8, 8, 8>, 8 * 32, 1, nullptr, 8, nullptr, nullptr});
 #endif
@@ -168,7 +173,7 @@ const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
 const MlpPlan* find_generic_plan(int H) {
     int want = 0;
 #ifdef NM_ABLATIONS
-    if (const char* v = getenv("NM_MLP_VARIANT")) want = atoi(v) == 200 ? 200 : 0;
+    if (const char* v = getenv("NM_MLP_VARIANT")) want = (atoi(v) == 200 || atoi(v) == 201) ? atoi(v) : 0;
 #endif
     for (const MlpPlan& p : all_plans())
         if (p.generic_nt && p.variant == want && p.H >= H) return &p;

@@ -29,12 +29,19 @@ def time_it(mlp):
 
 
 res = {}
-for layers, hidden, fx, skip in ((8, 128, 10, 4), (6, 128, 6, 2), (8, 64, 10, 4), (4, 64, 6, 4)):
-    kw = dict(num_layers=layers, hidden_size=hidden, skip_step=skip, num_encoding_fn_xyz=fx, num_encoding_fn_dir=4)
+# --narrow (round 5): the width classes of 2 and 3 tiles, which have no tuned kernel -- one tile against two
+NARROW = "--narrow" in sys.argv
+SHAPES = ((4, 32, 4, 2, 2), (6, 48, 6, 4, 4), (8, 48, 10, 4, 4), (8, 32, 10, 4, 4)) if NARROW else \
+    ((8, 128, 10, 4, 4), (6, 128, 6, 2, 4), (8, 64, 10, 4, 4), (4, 64, 6, 4, 4))
+LEGS = (("tuned", None, False), ("generic_one_tile_per_wave", None, True), ("generic_two_tiles_per_wave", "200", True))
+if NARROW:
+    LEGS = (LEGS[1], ("generic_two_tiles_per_wave_4_waves_per_simd", "200", True), ("generic_two_tiles_per_wave_2_waves_per_simd", "201", True))
+for layers, hidden, fx, skip, fd in SHAPES:
+    kw = dict(num_layers=layers, hidden_size=hidden, skip_step=skip, num_encoding_fn_xyz=fx, num_encoding_fn_dir=fd)
     w = S.make_mlp_weights(3, **kw)
     row = {}
     outs = {}
-    for name, env, force in (("tuned", None, False), ("generic_one_tile_per_wave", None, True), ("generic_two_tiles_per_wave", "200", True)):
+    for name, env, force in LEGS:
         if env is None:
             os.environ.pop("NM_MLP_VARIANT", None)
         else:
@@ -43,8 +50,9 @@ for layers, hidden, fx, skip in ((8, 128, 10, 4), (6, 128, 6, 2), (8, 64, 10, 4)
         ms, outs[name] = time_it(mlp)
         tf = n * mlp.flops_per_sample() / (ms * 1e-3) / 1e12
         row[name] = {"ms": ms, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK, "kernel_variant": mlp.kernel_variant()[0]}
-    row["bit_identical"] = bool(torch.equal(outs["tuned"], outs["generic_one_tile_per_wave"]) and torch.equal(outs["tuned"], outs["generic_two_tiles_per_wave"]))
-    key = f"{layers}x{hidden} F={fx}/4 skip {skip}"
+    first = next(iter(outs.values()))
+    row["bit_identical"] = bool(all(torch.equal(first, o) for o in outs.values()))
+    key = f"{layers}x{hidden} F={fx}/{fd} skip {skip}"
     res[key] = row
     print(key, {k: round(v["frac_of_fp32_mfma_peak"], 3) for k, v in row.items() if isinstance(v, dict)}, "bit-identical:", row["bit_identical"], file=sys.stderr)
 os.environ.pop("NM_MLP_VARIANT", None)
