@@ -32,7 +32,7 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
 }
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD);
-const MlpPlan* find_generic_plan(int H);
+const MlpPlan* find_generic_plan(int H, int L);
 bool has_b3_kernel(int H, int FX, int FD);
 int mlp_plan_info(const MlpPlan* p, int* nw);
 int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream);
@@ -491,7 +491,7 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     const MlpPlan* plan = (!force_generic && FX <= MAX_FREQ_XYZ && (no_view || FD <= MAX_FREQ_DIR)) ? find_mlp_plan(H, FX, no_view ? 4 : FD) : nullptr;
     LwNet* lw_net = nullptr;
     if (!plan) {
-        plan = find_generic_plan(H);
+        plan = find_generic_plan(H, L);
         const int steps_x = (3 * FX + 1) / 2 + (d.include_input_xyz ? 1 : 0), steps_d = (3 * FD + 1) / 2 + (d.include_input_dir ? 1 : 0);
         const bool long_encoding = steps_x > G_ENC_STEPS || (!no_view && steps_d > G_ENC_STEPS);
         if (precision != NM_PREC_F32) {
@@ -499,8 +499,9 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
             return 3;
         }
         if (!plan || long_encoding) {
-            // beyond the fused families -- hidden_size > 512 (the activations of a wider layer do not fit the register file of one
-            // wavefront) or an encoding of more than 24 MFMA k-steps (15 functions) --: the layer-wise path (nerf_layerwise.hip)
+            // beyond the fused families -- hidden_size > 512 (half of a wider layer's activations does not fit the register file of
+            // one wavefront), an encoding of more than 24 MFMA k-steps (15 functions), or so many layers that their biases no longer
+            // fit the LDS next to the weight ring --: the layer-wise path (nerf_layerwise.hip)
             if (FX > LW_MAX_FREQ || (!no_view && FD > LW_MAX_FREQ)) {
                 set_error("an encoding of " + std::to_string(FX) + " / " + std::to_string(FD) + " functions: the limit is " +
                           std::to_string(LW_MAX_FREQ) + " per input (frequency 2^31 is past fp32's integer range)");

@@ -348,4 +348,160 @@ __global__ __launch_bounds__(2 * GS_PAIRS * 64, 2) void mlp_kernel_gs(const MlpA
     else gs_forward<NT, KCH, TAPE, 0>(args, num_layers, density_only, lds, lds_bias, nbias, lds_walpha, lds_wrgb, lds_tab, wave, lane);
 }
 
+// ---- delta propagation (mlp_backward_kernel_g of mlp_device_g.h) on the same split: the transposed layers in reverse order, each
+// wave of a pair producing its half of a delta's tiles, gating them with ITS tiles of the taped activation and storing ITS part of
+// every delta row; the other half of the delta reaches the next stage through the exchange slots as in the forward kernel.
+template <int NT, int HF, int N, int N4>
+__device__ __forceinline__ void gs_relu_gate(const f32x4 (&acc)[N], const float* base, int width, int64_t sample, float (&own)[N4], int g) {
+    static_assert(N == GsHalf<NT, HF>::N && N4 == 4 * N, "this wave's tiles");
+    const float* row = base + sample * width;
+    const bool vec = (width & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int k0 = 16 * (GsHalf<NT, HF>::T0 + i) + 4 * g;
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (vec && k0 + 3 < width) a = *reinterpret_cast<const f32x4*>(row + k0);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = k0 + r < width ? row[k0 + r] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) own[4 * i + r] = a[r] > 0.0f ? acc[i][r] : 0.0f;
+    }
+}
+
+template <int NT, int KCH, int HF>
+__device__ __forceinline__ void gs_backward(const MlpBwdArgs& args, const int num_layers, const int flat, char* lds,
+                                            const float* lds_walpha, const float* lds_wrgb, const int wave, const int lane) {
+    constexpr int HP = 16 * NT, NTD = (NT + 1) / 2;
+    constexpr int KH = 4 * NT, KD = 4 * NTD;
+    constexpr int STEP = ((NT + 3) / 4) * 1024, SLOT = KCH * STEP;
+    constexpr int FIRST = KCH * STEP;                           // first chunk of any stage (every stage lands on the trunk tiles)
+    using T = GsHalf<NT, HF>;
+    using D = GsHalf<NTD, HF>;
+    const int pair = wave >> 1;
+    char* xch = lds + 2 * SLOT + pair * 4096;
+    const int g = lane >> 4, col = lane & 15;
+    const int L = num_layers, H = args.g_h, HD = args.g_hd;
+
+    const int64_t wg_iters = (args.n + GS_PAIRS * 16 - 1) / (GS_PAIRS * 16);
+    int par = 0;
+    for (int64_t it = blockIdx.x; it < wg_iters; it += gridDim.x) {
+        const bool has_next = it + gridDim.x < wg_iters;
+        const int wrap_bytes = has_next ? FIRST : 0;
+        const int64_t sample = (it * GS_PAIRS + pair) * 16 + col;
+        const bool valid = sample < args.n;
+        const int64_t sidx = valid ? sample : args.n - 1;
+        // ---- head: sigmoid' (models.py:75 / :78)
+        const f32x4 go = *reinterpret_cast<const f32x4*>(args.grad_out + 4 * sidx);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(args.radiance + 4 * sidx);
+        float drgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) drgb[ch] = go[ch] * (y[ch] * (1.0f - y[ch]));
+        const float dsigma = go[3];
+        if (HF == 0 && valid && g == 0) *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = f32x4{drgb[0], drgb[1], drgb[2], dsigma};
+        f32x4 acc[T::N];
+        float own[4 * T::N];
+        const char* gw = args.wstream;
+        const float* wa = lds_walpha + g * (HP / 4);
+        if (flat) {
+            // ---- fc_out^T on the VALU: delta at the trunk's output from the four head deltas (rows in fc_alpha's operand layout)
+#pragma unroll
+            for (int i = 0; i < T::N; ++i) {
+                const int nt = T::T0 + i;
+                f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
+                f32x4 a = {w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    w4 = *reinterpret_cast<const f32x4*>(lds_wrgb + ch * HP + g * (HP / 4) + 4 * nt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = fmaf(w4[r], drgb[ch], a[r]);
+                }
+                acc[i] = a;
+            }
+        } else {
+            // ---- fc_rgb^T on the VALU, gated by the view layer's ReLU: this wave's tiles of the delta at layers_dir.0's pre-activation
+            float dv[4 * D::N];
+            {
+                const float* row = args.tape_v + sidx * HD;
+                const bool vec = (HD & 3) == 0;
+#pragma unroll
+                for (int i = 0; i < D::N; ++i) {
+                    const int k0 = 16 * (D::T0 + i) + 4 * g;
+                    f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (vec && k0 + 3 < HD) av = *reinterpret_cast<const f32x4*>(row + k0);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) av[r] = k0 + r < HD ? row[k0 + r] : 0.0f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = 4 * (D::T0 + i) + r;
+                        float a = lds_wrgb[(0 * 4 + g) * KD + s] * drgb[0];
+                        a = fmaf(lds_wrgb[(1 * 4 + g) * KD + s], drgb[1], a);
+                        a = fmaf(lds_wrgb[(2 * 4 + g) * KD + s], drgb[2], a);
+                        dv[4 * i + r] = av[r] > 0.0f ? a : 0.0f;
+                    }
+                }
+            }
+            gs_store_rows<NTD, HF>(args.d_v, HD, sample, valid, dv, g);
+            // ---- layers_dir.0^T (hidden columns): -> delta at relu(fc_feat) -> gated -> delta at fc_feat's output
+#pragma unroll
+            for (int i = 0; i < T::N; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            gs_publish_first<NTD, HF>(dv, xch, lane);
+            __syncthreads();
+            gs_stage_hidden<NTD, NT, HF, KCH>(acc, dv, xch, gw, gw + KD * STEP, FIRST, lds, SLOT, par, wave, lane);
+            gw += KD * STEP;
+            gs_relu_gate<NT, HF>(acc, args.tape_feat, H, sidx, own, g);
+            gs_store_rows<NT, HF>(args.d_feat, H, sample, valid, own, g);
+            // ---- fc_feat^T + fc_alpha^T: delta at the output of layers_xyz[L-2]
+#pragma unroll
+            for (int i = 0; i < T::N; ++i) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * (T::T0 + i));
+                acc[i] = f32x4{w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+            }
+            gs_publish_first<NT, HF>(own, xch, lane);
+            __syncthreads();
+            gs_stage_hidden<NT, NT, HF, KCH>(acc, own, xch, gw, gw + KH * STEP, FIRST, lds, SLOT, par, wave, lane);
+            gw += KH * STEP;
+        }
+        gs_relu_gate<NT, HF>(acc, args.tape_h + (int64_t)(L - 1) * args.n * H, H, sidx, own, g);
+        gs_store_rows<NT, HF>(args.d_h + (int64_t)(L - 1) * args.n * H, H, sample, valid, own, g);
+        // ---- layers_xyz[i]^T, i = L-2 .. 0: delta at the input of layers_xyz[i] (gated by the ReLU of layers_xyz[i-1]; layer1 has none)
+#pragma unroll 1
+        for (int i = L - 2; i >= 0; --i) {
+#pragma unroll
+            for (int t = 0; t < T::N; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const char* after = gw + KH * STEP;
+            gs_publish_first<NT, HF>(own, xch, lane);
+            __syncthreads();
+            gs_stage_hidden<NT, NT, HF, KCH>(acc, own, xch, gw, i == 0 ? args.wstream : after, i == 0 ? wrap_bytes : FIRST, lds, SLOT, par,
+                                             wave, lane);
+            gw = after;
+            if (i > 0) gs_relu_gate<NT, HF>(acc, args.tape_h + (int64_t)i * args.n * H, H, sidx, own, g);
+            else gs_acc_to_own<T::N, false>(acc, own);
+            gs_store_rows<NT, HF>(args.d_h + (int64_t)i * args.n * H, H, sample, valid, own, g);
+        }
+    }
+}
+
+template <int NT, int KCH>
+__global__ __launch_bounds__(2 * GS_PAIRS * 64, 2) void mlp_backward_kernel_gs(const MlpBwdArgs args, const int num_layers, const int flat) {
+    constexpr int NW = 2 * GS_PAIRS;
+    constexpr int HP = 16 * NT, HPD = 16 * ((NT + 1) / 2);
+    constexpr int STEP = ((NT + 3) / 4) * 1024, SLOT = KCH * STEP;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_walpha = reinterpret_cast<float*>(lds + 2 * SLOT + GS_EXTRA_BYTES);   // [4][HP / 4]
+    float* lds_wrgb = lds_walpha + HP;                                               // [3][4][HPD / 4], or (flat) [3][4][HP / 4]
+    for (int i = threadIdx.x; i < HP; i += NW * 64) lds_walpha[i] = args.walpha[i];
+    for (int i = threadIdx.x; i < (flat ? 3 * HP : 3 * HPD); i += NW * 64) lds_wrgb[i] = args.wrgb[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wg_iters = (args.n + GS_PAIRS * 16 - 1) / (GS_PAIRS * 16);
+    if ((int64_t)blockIdx.x < wg_iters) stream_to_lds<NW>(args.wstream, lds, KCH * STEP, wave, lane);
+    __syncthreads();
+    if (wave & 1) gs_backward<NT, KCH, 1>(args, num_layers, flat, lds, lds_walpha, lds_wrgb, wave, lane);
+    else gs_backward<NT, KCH, 0>(args, num_layers, flat, lds, lds_walpha, lds_wrgb, wave, lane);
+}
+
 }  // namespace nm

@@ -104,14 +104,13 @@ void generic_plans_b(std::vector<MlpPlan>&);
 void generic_plans_c(std::vector<MlpPlan>&);
 void generic_plans_d(std::vector<MlpPlan>&);
 void generic_plans_e(std::vector<MlpPlan>&);
-void generic_plans_s(std::vector<MlpPlan>&, int variant);
+void generic_plans_s(std::vector<MlpPlan>&);
 
 static const std::vector<MlpPlan>& all_plans() {
     static const std::vector<MlpPlan> plans = [] {
         std::vector<MlpPlan> v(std::begin(g_tuned_plans), std::end(g_tuned_plans));
-        generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_e(v);
+        generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_s(v); generic_plans_e(v);
 #ifdef NM_ABLATIONS
-        generic_plans_s(v, 300);      // experiment (NM_MLP_VARIANT=300): output tiles split over a pair of waves (mlp_device_gs.h)
         // experiment (NM_MLP_VARIANT=200 + NM_KERNEL_GENERIC): two 16-sample column tiles per wave (mlp_device_g2.h)
         // (round 5: also the classes of 2 and 3 tiles -- VERDICT r4 item 7 -- compiled for four waves per SIMD (200) and two (201))
         v.push_back(MlpPlan{32, -1, -1, 8, 8, 200, 2 * 8 * 1024, true, &mlp_kernel_g2<2, 8, 8, 4>, 8 * 32, 1, nullptr, 2, nullptr, nullptr});
@@ -172,13 +171,15 @@ const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
     return fallback;
 }
 
-const MlpPlan* find_generic_plan(int H) {
+// the narrowest class of the generic family that holds hidden_size H and whose LDS image (weight ring + every bias of an L-layer
+// network + heads + tables) fits a CU; null if there is none (the caller then takes the layer-wise path)
+const MlpPlan* find_generic_plan(int H, int L) {
     int want = 0;
 #ifdef NM_ABLATIONS
-    if (const char* v = getenv("NM_MLP_VARIANT")) want = (atoi(v) == 200 || atoi(v) == 201 || atoi(v) == 300) ? atoi(v) : 0;
+    if (const char* v = getenv("NM_MLP_VARIANT")) want = (atoi(v) == 200 || atoi(v) == 201 || atoi(v) == 310) ? atoi(v) : 0;
 #endif
     for (const MlpPlan& p : all_plans())
-        if (p.generic_nt && p.variant == want && p.H >= H) return &p;
+        if (p.generic_nt && p.variant == want && p.H >= H && g_lds_bytes(p.ring_bytes, p.generic_nt, L) <= 160 * 1024) return &p;
     return nullptr;
 }
 

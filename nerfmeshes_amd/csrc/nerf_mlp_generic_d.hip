@@ -1,4 +1,4 @@
-// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part d: width classes NT = 22, 24, 26 (hidden_size <= 16 NT).
+// Generic-shape instantiations of the fused MLP (mlp_device_g.h), part d: width classes NT = 22, 24 (hidden_size <= 16 NT).
 // One translation unit per group of classes so that the build compiles them side by side (nerfmeshes_amd/build.py).
 #include <vector>
 
@@ -19,7 +19,6 @@ static MlpPlan generic_plan() {
 void generic_plans_d(std::vector<MlpPlan>& out) {
     out.push_back(generic_plan<22>());
     out.push_back(generic_plan<24>());
-    out.push_back(generic_plan<26>());
 }
 
 }  // namespace nm

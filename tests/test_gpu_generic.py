@@ -47,7 +47,7 @@ OFF_MENU = [
     dict(hidden_size=272, num_layers=4),                                                              # 17 tiles -> class 18
     dict(hidden_size=320, num_layers=5, num_encoding_fn_xyz=6),
     dict(hidden_size=384, num_layers=4, num_encoding_fn_dir=0),                                       # direction = the raw vector only; class 24: two waves per SIMD, the skip layer re-encodes
-    dict(hidden_size=448, num_layers=3, num_encoding_fn_xyz=0),                                       # xyz = the raw point only; a 4-wave class (512 registers)
+    dict(hidden_size=448, num_layers=3, num_encoding_fn_xyz=0),                                       # xyz = the raw point only; a class of 26 -- 32 tiles: output tiles split over a pair of waves
     dict(hidden_size=128, num_encoding_fn_dir=0, include_input_dir=False),                            # no direction columns at all
     dict(hidden_size=64, num_layers=2, num_encoding_fn_xyz=3, log_sampling_xyz=False, log_sampling_dir=False),
     dict(hidden_size=16, num_layers=2, num_encoding_fn_xyz=2, num_encoding_fn_dir=1),                 # one tile
@@ -161,7 +161,10 @@ TRAIN_SHAPES = [
     dict(num_layers=2, hidden_size=2, num_encoding_fn_xyz=1, num_encoding_fn_dir=1),                      # the narrowest network with a view layer
     dict(num_layers=4, hidden_size=320, num_encoding_fn_xyz=6),                                           # class 20: the widest that holds the encoding in registers at two waves per SIMD
     dict(num_layers=5, hidden_size=384, skip_step=2, num_encoding_fn_xyz=6),                              # class 24: re-encoding skip layers, spilled registers outside the k-step loops
-    dict(num_layers=3, hidden_size=448, num_encoding_fn_xyz=4),                                           # a 4-wave class (512 registers)
+    dict(num_layers=3, hidden_size=448, num_encoding_fn_xyz=4),                                           # a split class (mlp_device_gs.h): the pair of waves exchanges activation / delta halves
+    dict(num_layers=4, hidden_size=512, skip_step=2, num_encoding_fn_xyz=6),                              # the widest fused class, a skip layer
+    dict(num_layers=4, hidden_size=400, skip_step=2, num_encoding_fn_xyz=5, use_viewdirs=False),          # class 26: 13 + 13 tiles, fc_out's four chains handed between the waves
+    dict(num_layers=3, hidden_size=390, num_encoding_fn_xyz=3, num_encoding_fn_dir=2),                   # class 26 with a view layer of 13 tiles (7 + 6)
     dict(num_layers=5, hidden_size=80, skip_step=2, include_input_xyz=False, include_input_dir=False),
     dict(num_layers=8, hidden_size=256, num_encoding_fn_xyz=8),                                           # menu width: the hand-written dW kernels take the rows
     dict(num_layers=4, hidden_size=144, num_encoding_fn_xyz=9, use_viewdirs=False),
@@ -278,3 +281,26 @@ def test_limits_of_the_family_are_errors_with_a_reason(ops):
     got = ops.HipMLP(w, desc, "cuda").sample_points(pts.cuda(), pts.cuda()).cpu()
     ref = O.mlp_forward(w, spec, pts, pts)
     assert float((got[:, :3] - ref[:, :3]).abs().max()) < 1e-3      # 2^15 x: the argument itself carries 2^-9 of absolute error
+
+
+def test_the_deepest_network_of_the_widest_fused_class_fits_the_lds(ops):
+    """The fused kernels keep every bias of the network in LDS next to the weight ring (and, for the split classes, the exchange
+    slots): at the ABI's 32 layers and 512 padded columns that is 163 600 of the 163 840 bytes of a CU -- it must launch, on the
+    fused class, and agree with the oracle.  (The plan lookup checks the budget and would hand a network that does not fit to the
+    layer-wise path: nerf_mlp.hip find_generic_plan.)"""
+    g = torch.Generator().manual_seed(9)
+    pts = (torch.rand(700, 3, generator=g) * 2 - 1) * 2.0
+    dirs = torch.nn.functional.normalize(torch.randn(700, 3, generator=g), dim=-1)
+    spec, desc = _desc(dict(num_layers=32, hidden_size=500, skip_step=5, num_encoding_fn_xyz=4, num_encoding_fn_dir=2))
+    w = S.make_mlp_weights(4, **desc)
+    for k in [k for k in w if k.endswith(".weight") and k.startswith("layers_xyz")]:
+        w[k] = (w[k] * np.float32(1.6)).astype(np.float32)      # keep the signal alive through 31 ReLU layers
+    mlp = ops.HipMLP(w, desc, "cuda")
+    assert mlp.kernel_variant()[0] == 1032
+    ref = O.mlp_forward(w, spec, pts, dirs)
+    got = mlp.sample_points(pts.cuda(), dirs.cuda())
+    assert float(ref[:, :3].std()) > 1e-4, "the test network must not have died"
+    _close(got[:, :3], ref[:, :3], 2e-5, "rgb")
+    _close(got[:, 3], ref[:, 3], 2e-5 * (float(ref[:, 3].abs().max()) + 1.0), "sigma")
+    assert torch.equal(mlp.grid_query(pts[:50, 0], pts[:50, 1], pts[:9, 2], density_only=True),
+                       mlp.grid_query(pts[:50, 0], pts[:50, 1], pts[:9, 2], density_only=False)[:, 3])

@@ -1,6 +1,6 @@
 """Round 5: the width classes of 26 -- 32 tiles (hidden_size 385 -- 512) with a layer's output tiles split over a
 pair of waves (mlp_device_gs.h: 8-wave workgroups, two waves per SIMD) against the one-wave-per-SIMD kernels of the same classes.
-A/B in ONE process on the ablation library (NM_MLP_VARIANT=300 selects the split kernels): bit-identity of the full evaluation, the
+A/B in ONE process on the ablation library (NM_MLP_VARIANT=310 selects the old kernels, which only that library holds): bit-identity of the full evaluation, the
 density-only grid query and a use_viewdirs = 0 network is checked, then both are timed on 2^21 points.  Prints one JSON object.
 
     python tests/tools/bench_split.py [--n 2097152]
@@ -34,15 +34,19 @@ def time_it(fn):
 
 
 res = {}
+LEGS = [("one_wave_per_simd", "310"), ("split_two_waves_per_simd", None)]
+ONLY = [int(x) for x in sys.argv[sys.argv.index("--hidden") + 1].split(",")] if "--hidden" in sys.argv else None
 SHAPES = (dict(num_layers=8, hidden_size=512), dict(num_layers=8, hidden_size=480), dict(num_layers=8, hidden_size=448),
           dict(num_layers=8, hidden_size=400), dict(num_layers=4, hidden_size=400, skip_step=2, use_viewdirs=False),
           dict(num_layers=8, hidden_size=500, num_encoding_fn_xyz=15, num_encoding_fn_dir=0, include_input_dir=False))
 for over in SHAPES:
+    if ONLY is not None and over["hidden_size"] not in ONLY:
+        continue
     kw = dict(num_layers=8, hidden_size=256, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
     kw.update(over)
     w = S.make_mlp_weights(3, **kw)
     row, outs = {}, {}
-    for name, env in (("one_wave_per_simd", None), ("split_two_waves_per_simd", "300")):
+    for name, env in LEGS:
         if env is None:
             os.environ.pop("NM_MLP_VARIANT", None)
         else:
@@ -56,10 +60,9 @@ for over in SHAPES:
         row[name] = {"ms": ms, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK, "density_grid_frac": tf_d / PEAK,
                      "kernel_variant": mlp.kernel_variant()}
         del mlp
-    a, b = outs["one_wave_per_simd"], outs["split_two_waves_per_simd"]
-    row["bit_identical"] = bool(all(torch.equal(x, y) for x, y in zip(a, b)))
-    row["finite"] = bool(all(torch.isfinite(x).all() for x in b))
-    row["max_abs_diff"] = max(float((x - y).abs().max()) for x, y in zip(a, b))
+    a = outs["one_wave_per_simd"]
+    row["bit_identical"] = bool(all(torch.equal(x, y) for name, b in outs.items() for x, y in zip(a, b)))
+    row["max_abs_diff"] = max(float((x - y).abs().max()) for name, b in outs.items() for x, y in zip(a, b))
     key = " ".join(f"{k}={v}" for k, v in over.items())
     res[key] = row
     print(key, {k: (round(v["frac_of_fp32_mfma_peak"], 3), round(v["density_grid_frac"], 3)) for k, v in row.items() if isinstance(v, dict)},

@@ -5,7 +5,7 @@ noise, MSE(coarse) + MSE(fine), loss.backward(), Adam): ms per iteration and the
 single shape runs a few iterations and exits (the target of `rocprofv3 --kernel-trace`: the trace must show no rocBLAS /
 Cijk_* / at::native GEMM or reduction kernel between the forward and the optimizer).
 
-    python tests/tools/bench_train_shapes.py [--iters 10] [--trace-one 8x320]
+    python tests/tools/bench_train_shapes.py [--iters 10] [--only 8x512,4x400] [--trace-one 8x320]
 """
 import json
 import os
@@ -33,6 +33,7 @@ SHAPES = {
     "8x256 ragged (583 rays)": (dict(), 583, True),
     "8x320": (dict(hidden_size=320), 2048, True),
     "4x400 flat": (dict(hidden_size=400, num_layers=4, skip_step=2), 2048, False),
+    "8x448": (dict(hidden_size=448), 1024, True),
     "8x512": (dict(hidden_size=512), 1024, True),
     "8x768 (layer-wise path)": (dict(hidden_size=768), 512, True),
     "8x1024 (layer-wise path)": (dict(hidden_size=1024), 512, True),
@@ -98,7 +99,10 @@ def main():
         torch.cuda.synchronize()
         return
     out = {}
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
     for name in SHAPES:
+        if only is not None and not any(name.startswith(o) for o in only):
+            continue
         iteration, kw, viewdirs, rays, samples, model = build(name, dev)
         for _ in range(3):
             iteration()
