@@ -22,7 +22,8 @@
 // up to NT = 20; classes 21 -- 24 re-encode the position at the skip layer instead of holding it and still spill a few dozen
 // registers at the stage boundaries, outside the k-step loops -- measured 0.89 -- 0.91 of the peak against 0.80 with one wave per SIMD (the partner
 // wave hides a wave's LDS and barrier latency; round 4, profiles/r04_mlp_shapes.json).  Beyond 24 tiles the two arrays alone
-// exceed 256: 4-wave workgroups, one wave per SIMD, on the 512-register budget.
+// exceed 256: those classes run on mlp_device_gs.h (a layer's output tiles split over a pair of waves; round 5).  The NW = 4
+// instantiations of THIS kernel for them -- one wave per SIMD on the 512-register budget -- remain in the ablation library only.
 #pragma once
 #include "mlp_device.h"
 

@@ -9,8 +9,8 @@ namespace nm {
 
 template <int NT>
 static MlpPlan generic_plan() {
-    constexpr int NW = NT <= 24 ? 8 : 4;      // classes beyond 24 tiles: one wave per SIMD on the 512-register budget
-    constexpr int KCH = NT <= 24 ? 8 : 4;     // ring slots of at most 48 KiB
+    static_assert(NT <= 24, "wider classes: nerf_mlp_generic_s.hip");
+    constexpr int NW = 8, KCH = 8;            // two waves per SIMD; ring slots of at most 48 KiB
     constexpr int SLOT = KCH * ((NT + 3) / 4) * 1024;
     return MlpPlan{16 * NT, -1, -1, NW, KCH, 0, 2 * SLOT, true, &mlp_kernel_g<NT, NW, KCH>, NW * 16, 1,
                    &mlp_kernel_g<NT, NW, KCH>, NT, &mlp_kernel_g<NT, NW, KCH, true>, &mlp_backward_kernel_g<NT, NW, KCH>};

@@ -16,6 +16,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+if "--ablation-variant" in sys.argv:      # A/B against kernels only the ablation library holds (e.g. 310: the one-wave-per-SIMD wide classes)
+    from nerfmeshes_amd import _lib, build as hip_build
+    _lib.LIB_PATH = hip_build.ABLATION_LIB_PATH
+    if sys.argv[sys.argv.index("--ablation-variant") + 1] != "0":
+        os.environ["NM_MLP_VARIANT"] = sys.argv[sys.argv.index("--ablation-variant") + 1]
 from nerfmeshes_amd import models, synthetic as S  # noqa: E402
 from nerfmeshes_amd.nerf import CfgNode  # noqa: E402
 
@@ -136,7 +141,8 @@ def main():
         del iteration, model
         torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump({"peak_tflops": PEAK, "iters": iters, "shapes": out}, open(os.path.join(ROOT, "gpurun_out", "train_shapes.json"), "w"), indent=1)
+    tag = ("_variant_" + sys.argv[sys.argv.index("--ablation-variant") + 1]) if "--ablation-variant" in sys.argv else ""
+    json.dump({"peak_tflops": PEAK, "iters": iters, "shapes": out}, open(os.path.join(ROOT, "gpurun_out", f"train_shapes{tag}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
