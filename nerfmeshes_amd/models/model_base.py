@@ -122,7 +122,8 @@ class BaseModel(_Base):
         return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda step: gamma ** (step / step_size))
 
     def configure_optimizers(self):
-        optimizer = getattr(torch.optim, self.cfg.optimizer.type)(self.parameters(), lr=self.cfg.optimizer.lr)
+        from .. import train_ops
+        optimizer = train_ops.make_optimizer(self.cfg.optimizer.type, self.parameters(), self.cfg.optimizer.lr)
         if hasattr(torch.optim.lr_scheduler, self.cfg.scheduler.type):
             scheduler = getattr(torch.optim.lr_scheduler, self.cfg.scheduler.type)(optimizer, **self.cfg.scheduler.options)
         else:

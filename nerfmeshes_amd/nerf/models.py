@@ -42,7 +42,8 @@ class FlexibleNeRFModel(torch.nn.Module):
 
     def hip(self, precision=None):
         """Packed device copy of the current parameters: built once per device, then re-packed on the GPU
-        (nm_mlp_refresh, one gather kernel) whenever a parameter changed -- e.g. after every optimizer step.
+        (nm_mlp_refresh, one gather kernel) whenever a parameter changed -- autograd's version counters moved, or ANY optimizer
+        stepped / a captured iteration was replayed since (train_ops.generation(): fused optimizers and graph replays move no counter).
         `precision` overrides `self.precision` for this handle (mesh_nerf's density grid asks for "f32" whatever the
         module is set to)."""
         params = list(self.parameters()) + list(self.buffers())
@@ -50,7 +51,7 @@ class FlexibleNeRFModel(torch.nn.Module):
         if dev.type != "cuda":
             raise hip_ops._lib.HipLibraryError(
                 "FlexibleNeRFModel lives on %s: move it to the MI355X (.to('cuda')); there is no CPU path" % dev)
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (train_ops.generation(),) + tuple((p.data_ptr(), p._version) for p in params)
         precision = "f32" if self.needs_grad() else (precision or getattr(self, "precision", "f32"))
         if self._hip is None or self._hip.device != dev or self._hip.precision != precision:
             self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev, precision=precision)

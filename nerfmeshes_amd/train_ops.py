@@ -308,6 +308,75 @@ def mlp_rays(module, origins, dirs, t):
     return _MLPRays.apply(mlp, names, origins, dirs, t, *[params[k] for k in names])
 
 
+# ---- "the parameters may have changed": what FlexibleNeRFModel.hip() keys its device re-pack on, besides autograd's version
+# counters.  An optimizer step does not always move those -- torch's FUSED optimizers update the tensors through one multi-tensor
+# kernel without bumping them, and a replayed hipGraph runs no Python at all -- so every optimizer step (a global post-step hook,
+# any optimizer, any module) and every GraphedStep replay advances this generation; the next hip() of any module then re-packs
+# (one gather kernel, ~8 us).  Edits through `p.data` still need FlexibleNeRFModel.refresh().
+_GENERATION = [0]
+
+
+def parameters_changed(*_args, **_kw):
+    _GENERATION[0] += 1
+
+
+def generation():
+    return _GENERATION[0]
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(parameters_changed)
+
+
+def make_optimizer(kind, params, lr, **kw):
+    """torch.optim.<kind>(params, lr=lr) as the reference builds it (model_base.py:159-162) -- in torch's FUSED implementation
+    when the class has one and every parameter lives on the GPU: one kernel per step instead of seven multi-tensor launches, the
+    same update formula.  Nothing for an 8x256 pair (14.06 vs 14.08 ms per iteration), 4 -- 13 % of an iteration of BASELINE config
+    1's 4x64 network (1.27 -- 1.30 -> 1.13 -- 1.22 ms: profiles/r05_train_graph_and_adam.json).  (A fused step moves no autograd
+    version counter: FlexibleNeRFModel.hip() re-packs on `generation()` above.)"""
+    import inspect
+    cls = getattr(torch.optim, kind)
+    params = list(params)
+    flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
+    if "fused" in inspect.signature(cls.__init__).parameters and "fused" not in kw and "foreach" not in kw and flat and \
+            all(p.is_cuda and torch.is_floating_point(p) for p in flat):
+        kw["fused"] = True
+    return cls(params, lr=lr, **kw)
+
+
+class GraphedStep:
+    """One optimizer iteration of FIXED shapes captured into a hipGraph once, then replayed: for the small networks, whose
+    iteration is about forty launches of a few tens of microseconds, the launch gaps are a third of the wall time (BASELINE config
+    1's 4x64 network on 8192 rays x 32 samples: 1.27 ms eagerly, 1.52 with the capturable Adam a capture needs, 0.89 replayed --
+    9.2 M rays/s; an 8x256 pair gains nothing, its CPU already runs ahead of 2 -- 4 ms kernels: profiles/r05_train_graph_and_adam.json).  The library's training kernels capture as they are: every buffer
+    they use comes from the caller, no call allocates, copies from the host or synchronises once the handles are warm.
+
+        step = GraphedStep(iteration)     # iteration(): optimizer.zero_grad(set_to_none=True); forward on STATIC input tensors;
+        for batch in loader:              #              loss.backward(); optimizer.step()  -- optimizer built with capturable=True
+            static_rays.copy_(batch); step()
+
+    `warmup` eager iterations run first on a side stream (they ARE optimizer steps: allocator, handle re-pack and the cached ray
+    bounds must be warm before the capture); the capture itself records the iteration without running it.  The parameters after
+    k replays equal those after k eager iterations bit for bit (tests/test_gpu_train.py)."""
+
+    def __init__(self, iteration, warmup=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            iteration()
+
+    def __call__(self):
+        self.graph.replay()
+        parameters_changed()       # the step inside the graph ran without Python: FlexibleNeRFModel.hip() must re-pack on its next use
+
+
 def perturb_intervals(t, rnd):
     t, rnd = _dev32(t), _dev32(rnd)
     out = torch.empty_like(t)

@@ -273,14 +273,17 @@ def test_end_to_end_loss_gradients_vs_oracle_autograd():
             assert _rel(p.grad, grads[name][k]) < 5e-4, (name, k, _rel(p.grad, grads[name][k]))
 
 
-def test_adam_steps_reduce_the_loss_and_eval_follows_the_new_weights():
+@pytest.mark.parametrize("adam", [dict(), dict(fused=True), dict(foreach=False)], ids=["multi-tensor", "fused", "single-tensor"])
+def test_adam_steps_reduce_the_loss_and_eval_follows_the_new_weights(adam):
     """A few optimizer steps on one ray batch: the loss falls, and the inference path (nm_render_rays) sees the
-    updated parameters (device re-pack) -- it equals a model rebuilt from the new state_dict."""
+    updated parameters (device re-pack) -- it equals a model rebuilt from the new state_dict.  Every implementation of the
+    optimizer: torch's fused Adam updates the tensors without moving autograd's version counters, which the re-pack used to key on
+    alone (the model then trained on its initial weights for ever; round 5: train_ops.generation())."""
     kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
     hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw)
     model = _model(hp, seed=3)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, **adam)
     o, d, _ = _rays(512, 2, 4)
     target = (0.5 + 0.5 * torch.sin(7.0 * d)).cuda()
     batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
@@ -302,6 +305,64 @@ def test_adam_steps_reduce_the_loss_and_eval_follows_the_new_weights():
     with torch.no_grad():
         want = fresh.query(batch).rgb_map
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("kw", [dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
+                                dict(num_layers=3, hidden_size=100, skip_step=2, num_encoding_fn_xyz=5, num_encoding_fn_dir=2)],
+                         ids=["tuned-4x64", "generic-3x100"])
+def test_training_iteration_replays_from_a_hipgraph(kw):
+    """train_ops.GraphedStep: the whole iteration (forward in train mode, both losses, backward through the HIP kernels, Adam)
+    captured once and replayed -- nothing in the library allocates, copies from the host or synchronises once the handles are
+    warm.  Deterministic configuration: the parameters after 3 warm-up steps + 4 replays equal those after 7 eager steps bit for
+    bit; with perturb + noise every replay draws fresh randoms (torch's generator is part of the graph)."""
+    from nerfmeshes_amd import train_ops
+    o, d, _ = _rays(512, 2, 4)
+    target = (0.5 + 0.5 * torch.sin(7.0 * d)).cuda()
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+
+    def setup(stochastic):
+        hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.3 if stochastic else 0.0, train_perturb=stochastic, **kw)
+        model = _model(hp, seed=3)
+        model.train()
+        opt = train_ops.make_optimizer("Adam", model.parameters(), 5e-3, capturable=True)
+        assert opt.defaults["fused"] and opt.defaults["capturable"]
+        loss_out = torch.zeros((), device="cuda")
+
+        def iteration():
+            opt.zero_grad(set_to_none=True)
+            c, f = model(batch)
+            loss = torch.nn.functional.mse_loss(c.rgb_map, target) + torch.nn.functional.mse_loss(f.rgb_map, target)
+            loss.backward()
+            opt.step()
+            loss_out.copy_(loss.detach())
+        return model, iteration, loss_out
+
+    eager, it_e, loss_e = setup(False)
+    start = [p.detach().clone() for p in eager.parameters()]
+    it_e()
+    first = float(loss_e)
+    for _ in range(6):
+        it_e()
+    assert float(loss_e) < 0.9 * first and not any(torch.equal(a, b) for a, b in zip(start, eager.parameters())), "the eager run must have trained"
+    graphed, it_g, loss_g = setup(False)
+    step = train_ops.GraphedStep(it_g, warmup=3)
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    assert float(loss_g) == float(loss_e)
+    for (k, a), b in zip(eager.named_parameters(), graphed.parameters()):
+        assert torch.equal(a, b), k
+    # the inference path after replays sees the step the graph made last (no Python ran in it: GraphedStep tells the modules)
+    graphed.eval(), eager.eval()
+    with torch.no_grad():
+        assert torch.equal(graphed.query(batch).rgb_map, eager.query(batch).rgb_map)
+    _, it_s, loss_s = setup(True)
+    step = train_ops.GraphedStep(it_s)
+    seen = []
+    for _ in range(4):
+        step()
+        seen.append(float(loss_s))
+    assert len(set(seen)) == 4 and all(np.isfinite(seen)), seen
 
 
 def test_perturb_and_noise_are_seeded_by_torch():
