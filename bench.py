@@ -780,7 +780,55 @@ def tiny_probe(dev, cpu_legs=True):
                            "sample": f"{dc.shape[0]} rays of the view (stride 10), chunks of 2048, {dt:.2f} s"}
     out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     out["parity"] = parity.psnr_parity(rgb[idx].cpu(), ref, chunk=2048)
+    try:
+        out["train"] = tiny_train_probe(dev)
+    except Exception as e:      # a figure of a figure: never at the expense of the rest of the object
+        out["train"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def tiny_train_probe(dev, rays=8192, iters=40):
+    """Config 1's training iteration (4x64, 32 coarse samples, no fine network; perturb + noise, MSE, backward through the HIP
+    kernels, Adam) -- about forty launches of a few tens of microseconds: launched eagerly, and replayed from one captured hipGraph
+    (train_ops.GraphedStep; the same kernels: tests/test_gpu_train.py::test_training_iteration_replays_from_a_hipgraph)."""
+    from nerfmeshes_amd import models, train_ops
+    from nerfmeshes_amd.nerf import CfgNode
+    hp = S.hparams(train_perturb=True, train_noise_std=0.2, hidden_size=64, num_layers=4, skip_step=2, num_encoding_fn_xyz=6,
+                   num_encoding_fn_dir=4, num_coarse=32, num_fine=0, use_fine=False)
+    g = torch.Generator().manual_seed(1)
+    dirs = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1).to(dev)
+    batch = (torch.tensor([[0.0, 0.0, 4.0]], device=dev), dirs, torch.tensor([NEAR, FAR]))
+    target = torch.rand(rays, 3, generator=g).to(dev)
+
+    def build(**adam):
+        torch.manual_seed(0)
+        model = models.NeRFModel(CfgNode(hp)).to(dev)
+        model.train()
+        opt = train_ops.make_optimizer("Adam", model.parameters(), 5e-4, **adam)
+
+        def iteration():
+            opt.zero_grad(set_to_none=True)
+            out = model(batch)
+            c = out[0] if isinstance(out, tuple) else out
+            torch.nn.functional.mse_loss(c.rgb_map, target).backward()
+            opt.step()
+        return iteration
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    eager = timed(build())
+    replay = timed(train_ops.GraphedStep(build(capturable=True)))
+    return {"workload": f"config 1 training iteration: 4x64, {rays} rays x 32 samples, perturb + noise, fused Adam",
+            "ms_per_iteration_eager": eager, "ms_per_iteration_graph_replay": replay, "rays_per_s_graph_replay": rays / replay * 1e3,
+            "note": "launch-bound: one captured hipGraph replaces ~40 launches per iteration (train_ops.GraphedStep)"}
 
 
 class _Emergency:

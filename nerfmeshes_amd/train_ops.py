@@ -17,6 +17,7 @@ torch is plumbing (device memory, autograd bookkeeping, the optimizer); there is
 """
 import ctypes as C
 
+import os
 import torch
 
 from . import _lib, hip_ops
