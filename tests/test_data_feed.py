@@ -172,3 +172,21 @@ def test_tie_order_auto_falls_back_to_stable_beyond_the_reference_kernels_limit(
     tree.tie_order = "reference"
     tree.batch_ray_voxel_intersect(o, d, 2.0, 6.0, 8)
     assert seen[-1] == "reference"                     # explicit request: not second-guessed
+
+
+def test_every_optimizer_step_advances_the_parameter_generation():
+    """FlexibleNeRFModel.hip() re-packs its device copy when autograd's version counters moved OR train_ops.generation() did: the
+    latter advances on every optimizer step of any optimizer (a global post-step hook) -- torch's fused optimizers update tensors
+    without touching the counters -- and on every GraphedStep replay."""
+    import torch
+    from nerfmeshes_amd import train_ops
+    lin = torch.nn.Linear(3, 2)
+    for opt in (torch.optim.SGD(lin.parameters(), lr=0.1), torch.optim.Adam(lin.parameters(), lr=0.1, foreach=False),
+                train_ops.make_optimizer("Adam", lin.parameters(), 0.1)):
+        before = train_ops.generation()
+        lin(torch.ones(1, 3)).sum().backward()
+        opt.step()
+        assert train_ops.generation() == before + 1
+    assert "fused" not in train_ops.make_optimizer("Adam", lin.parameters(), 0.1).defaults or \
+        not train_ops.make_optimizer("Adam", lin.parameters(), 0.1).defaults["fused"], "host parameters: torch's default implementation"
+    assert train_ops.make_optimizer("SGD", lin.parameters(), 0.1, momentum=0.9).defaults["momentum"] == 0.9
