@@ -177,7 +177,7 @@ template <int NT, int KCH, bool TAPE, int HF>
 __device__ __forceinline__ void gs_forward(const MlpArgs& args, const int num_layers, const int density_only, char* lds,
                                            const float* lds_bias, const int nbias, const float* lds_walpha, const float* lds_wrgb,
                                            const GEncArg* lds_tab, const int wave, const int lane) {
-    constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
+    constexpr int HP = 16 * NT, NTD = (NT + 1) / 2;
     constexpr int KH = 4 * NT, KD = 4 * NTD;
     constexpr int NB = (NT + 3) / 4, NBD = (NTD + 3) / 4;
     constexpr int STEP = NB * 1024, STEPD = NBD * 1024;
