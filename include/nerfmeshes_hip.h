@@ -79,9 +79,9 @@ typedef struct nm_mlp nm_mlp;
 /* Packs the weights into the MFMA operand stream and uploads them to `device`.
  * Every shape FlexibleNeRFModel's constructor accepts (models.py:5-58) is served: the shipped configs' shapes (hidden_size
  * 64 / 128 / 256, 6 or 10 xyz and 4 direction functions) by kernels tuned for exactly them, every other one -- any hidden_size
- * up to 512, 0..15 encoding functions per input (16 without the input itself), include_input_* on or off -- by the
+ * up to 512, 0..31 encoding functions per input (32 without the input itself), include_input_* on or off -- by the
  * generic-shape kernel family (padded to the next width class; nm_mlp_kernel_variant reports 1000 + class).  Beyond that -- a
- * hidden_size above 512 or an encoding of more than 15 functions -- the network is evaluated and trained LAYER BY LAYER on the
+ * hidden_size above 512 or an encoding of more than 48 MFMA k-steps -- the network is evaluated and trained LAYER BY LAYER on the
  * library's general MFMA GEMM (nm_mlp_kernel_variant 2000; the handle then owns a grow-only activation workspace that the
  * first call of a size allocates).  Only more than 32 encoding functions or a weight matrix of more than 2^24 elements fails,
  * with a message.  Every handle trains (generic-shape and layer-wise handles through the tape-row path: masks may be NULL,

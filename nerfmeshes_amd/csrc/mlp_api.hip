@@ -32,7 +32,7 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
 }
 
 const MlpPlan* find_mlp_plan(int H, int FX, int FD);
-const MlpPlan* find_generic_plan(int H, int L);
+const MlpPlan* find_generic_plan(int H, int L, bool long_encoding);
 bool has_b3_kernel(int H, int FX, int FD);
 int mlp_plan_info(const MlpPlan* p, int* nw);
 int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream_t stream);
@@ -262,8 +262,8 @@ static BlobLayout build_index_generic(std::vector<int32_t>& index, const nm_mlp_
 }
 
 // the per-argument table of one encoding (GEncArg: band, coordinate)
-static void fill_enc_table(float* tab /* [G_ENC_ARGS][2] */, int F, const float* bands) {
-    for (int a = 0; a < 48; ++a) {
+static void fill_enc_table(float* tab /* [parts * G_ENC_ARGS][2] */, int parts, int F, const float* bands) {
+    for (int a = 0; a < parts * G_ENC_ARGS; ++a) {
         const bool real = F > 0 && a < 3 * F;
         const int32_t coord = real ? a / F : 0;
         tab[2 * a] = real ? bands[a % F] : 0.0f;
@@ -491,16 +491,17 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     const MlpPlan* plan = (!force_generic && FX <= MAX_FREQ_XYZ && (no_view || FD <= MAX_FREQ_DIR)) ? find_mlp_plan(H, FX, no_view ? 4 : FD) : nullptr;
     LwNet* lw_net = nullptr;
     if (!plan) {
-        plan = find_generic_plan(H, L);
         const int steps_x = (3 * FX + 1) / 2 + (d.include_input_xyz ? 1 : 0), steps_d = (3 * FD + 1) / 2 + (d.include_input_dir ? 1 : 0);
-        const bool long_encoding = steps_x > G_ENC_STEPS || (!no_view && steps_d > G_ENC_STEPS);
+        const int steps = (!no_view && steps_d > steps_x) ? steps_d : steps_x;
+        const bool long_encoding = steps > G_ENC_PARTS * G_ENC_STEPS;      // beyond what the fused kernels take even in two parts
+        plan = find_generic_plan(H, L, steps > G_ENC_STEPS);
         if (precision != NM_PREC_F32) {
             set_error("precision bf16x3 is instantiated for hidden_size 64 / 128 / 256 with 6 or 10 xyz / 4 direction frequencies only");
             return 3;
         }
         if (!plan || long_encoding) {
             // beyond the fused families -- hidden_size > 512 (half of a wider layer's activations does not fit the register file of
-            // one wavefront), an encoding of more than 24 MFMA k-steps (15 functions), or so many layers that their biases no longer
+            // one wavefront), an encoding of more than 48 MFMA k-steps (31 functions), or so many layers that their biases no longer
             // fit the LDS next to the weight ring --: the layer-wise path (nerf_layerwise.hip)
             if (FX > LW_MAX_FREQ || (!no_view && FD > LW_MAX_FREQ)) {
                 set_error("an encoding of " + std::to_string(FX) + " / " + std::to_string(FD) + " functions: the limit is " +
@@ -665,11 +666,13 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     for (int f = 0; f < FD && f < MAX_FREQ_DIR && !no_view; ++f) a.bands_dir[f] = w->freq_dir[f];
     a.skip_mask = lay.skip_mask;
     if (plan->generic_nt) {      // the encodings' run-time description (mlp_device_g.h)
-        float tab[2 * 2 * G_ENC_ARGS];
-        fill_enc_table(tab, FX, w->freq_xyz);
-        fill_enc_table(tab + 2 * G_ENC_ARGS, no_view ? 0 : FD, w->freq_dir);
-        NM_HIP_CHECK(hipMalloc(&m->d_enc_tab, sizeof(tab)));
-        NM_HIP_CHECK(hipMemcpy(m->d_enc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        const int parts = plan->variant == G_LONG_VARIANT ? G_ENC_PARTS : 1;     // [xyz, dir][parts][G_ENC_ARGS] (band, coordinate)
+        float tab[2 * 2 * G_ENC_PARTS * G_ENC_ARGS];
+        fill_enc_table(tab, parts, FX, w->freq_xyz);
+        fill_enc_table(tab + 2 * parts * G_ENC_ARGS, parts, no_view ? 0 : FD, w->freq_dir);
+        const size_t tab_bytes = sizeof(float) * 2 * 2 * parts * G_ENC_ARGS;
+        NM_HIP_CHECK(hipMalloc(&m->d_enc_tab, tab_bytes));
+        NM_HIP_CHECK(hipMemcpy(m->d_enc_tab, tab, tab_bytes, hipMemcpyHostToDevice));
         a.g_tab = m->d_enc_tab;
         a.g_nsx = (3 * FX + 1) / 2; a.g_idx = d.include_input_xyz ? 1 : 0; a.g_chx = lay.chx;
         a.g_nsd = no_view ? 0 : (3 * FD + 1) / 2; a.g_idd = (!no_view && d.include_input_dir) ? 1 : 0; a.g_chd = lay.chd;

@@ -7,7 +7,8 @@
 //     pads rows / columns / biases beyond the real width with zeros: relu(0 * x + 0) = 0 feeds zero columns, so the padded
 //     network computes exactly the real one.  The view layer (hidden_size // 2 rows) is padded to NTD = ceil(NT / 2) tiles.
 //     A-operand blocks are 4 tiles (one ds_read_b128 per lane); a trailing block of NT % 4 tiles skips its unused MFMAs.
-//   * num_encoding_fn_* / include_input_* -> encodings live in G_ENC_STEPS = 24 registers per lane; how many k-steps are
+//   * num_encoding_fn_* / include_input_* -> encodings live in G_ENC_STEPS = 24 registers per lane (longer ones -- more than 15
+//     functions, up to 31 -- in two parts, the second evaluated into the same registers when its chunks come up); how many k-steps are
 //     real, which argument (coordinate, frequency band) each lane encodes and whether an identity step follows come from a
 //     host-built table (LDS-resident).  An encoding's GEMM columns are their own stage of a runtime number of whole
 //     KCH-k-step chunks (zero-padded), accumulated into the same tiles as the hidden columns -- as the tuned kernels do for
@@ -29,8 +30,11 @@
 
 namespace nm {
 
-constexpr int G_ENC_STEPS = 24;     // k-steps one encoding may span: (3 F + 1) / 2 + include_input <= 24  (F <= 15; F = 16 without input)
+constexpr int G_ENC_STEPS = 24;     // k-steps of an encoding that live in registers at a time
 constexpr int G_ENC_ARGS = 2 * G_ENC_STEPS;
+constexpr int G_LONG_VARIANT = 50;  // MlpPlan::variant of the LONG instantiations
+constexpr int G_ENC_PARTS = 2;      // an encoding spans up to G_ENC_PARTS * 24 k-steps: (3 F + 1) / 2 + include_input <= 48 (F <= 31; 32 without the
+                                    // input); the second part is evaluated when its stage comes up (enc_stages_g), never held
 
 // Dynamic LDS of the generic kernels beyond the weight ring -- ONE definition for the kernels' carve-up and for every launcher
 // (nerf_mlp.hip: inference; nerf_train.hip: taping forward, delta kernel).  Forward / taping: biases (layer1 | layers_xyz.* |
@@ -39,14 +43,15 @@ constexpr int G_ENC_ARGS = 2 * G_ENC_STEPS;
 __host__ __device__ constexpr int g_bias_floats(int nt, int layers) { return 16 * nt * (1 + layers) + 16 * ((nt + 1) / 2) + 4; }
 __host__ __device__ constexpr int g_head_floats(int nt) { return 16 * nt + 3 * 16 * nt; }
 struct GEncArg;
-__host__ inline int g_lds_bytes(int ring_bytes, int nt, int layers);      // defined below GEncArg
+__host__ inline int g_lds_bytes(int ring_bytes, int nt, int layers, int enc_parts);      // defined below GEncArg
 __host__ inline int g_bwd_lds_bytes(int ring_bytes, int nt) { return ring_bytes + g_head_floats(nt) * 4; }
 
 // one encoding argument a < 3 F: coordinate a / F times frequency band a % F (modules.py:30-33, coordinate-major);
 // a >= 3 F (the odd tail): band 0 -> sin 0 / cos 1 against zero weights
 struct GEncArg { float band; int32_t coord; };
-__host__ inline int g_lds_bytes(int ring_bytes, int nt, int layers) {
-    return ring_bytes + (g_bias_floats(nt, layers) + g_head_floats(nt)) * 4 + 2 * G_ENC_ARGS * (int)sizeof(GEncArg);
+// (enc_parts: 1 for the one-part instantiations, G_ENC_PARTS for the LONG ones -- their tables hold both parts of both encodings)
+__host__ inline int g_lds_bytes(int ring_bytes, int nt, int layers, int enc_parts) {
+    return ring_bytes + (g_bias_floats(nt, layers) + g_head_floats(nt)) * 4 + 2 * enc_parts * G_ENC_ARGS * (int)sizeof(GEncArg);
 }
 
 // One GEMM stage of the generic kernel: acc[NT tiles] += W_stage * b, chunk by chunk through the 2-slot ring.
@@ -130,6 +135,48 @@ __device__ __forceinline__ void encode_g(float (&enc)[G_ENC_STEPS], const float 
     }
 }
 
+// The GEMM stages of one encoding's columns (layer1, a skip layer, layers_dir[0]): `ch` whole chunks of the stream, of which the
+// first G_ENC_STEPS / KCH carry part 0 of the encoding (k-steps 0 .. 23: `enc0` if the caller holds it -- HAVE0 --, evaluated here
+// otherwise) and the rest part 1 (k-steps 24 .. 47, more than 15 functions: evaluated here, into the same registers).  `ns` argument
+// k-steps in all, `ident`: an identity step follows them; tab: this encoding's [G_ENC_PARTS][G_ENC_ARGS] table.  The two-part code is its
+// own instantiation (LONG: the *_long translation units, plans of variant G_LONG_VARIANT): twelve more inlined sincosf sites per stage
+// cost the one-part kernels ~10 registers and a few spills for nothing.
+__device__ __forceinline__ int g_part_ns(int ns, int part) { const int r = ns - part * G_ENC_STEPS; return r < 0 ? 0 : (r > G_ENC_STEPS ? G_ENC_STEPS : r); }
+__device__ __forceinline__ int g_part_ident(int ns, int ident, int part) { return ident && ns >= part * G_ENC_STEPS && ns < (part + 1) * G_ENC_STEPS; }
+
+template <int NTO, int NW, int KCH, bool HAVE0, bool LONG>
+__device__ __forceinline__ void enc_stages_g(f32x4 (&acc)[NTO], const float (&enc0)[HAVE0 ? G_ENC_STEPS : 1], const float (&x)[3],
+                                             const GEncArg* tab, int ns, int ident, int ch, int g, const char* gw, const char* tail_src,
+                                             int tail_bytes, char* lds, int slot_bytes, int& par, int wave, int lane) {
+    if constexpr (!LONG) {          // one part: exactly the stage the kernels had before there were two
+        if constexpr (HAVE0) {
+            gemm_stage_g<NTO, G_ENC_STEPS, NW, KCH, true>(acc, enc0, ch, gw, tail_src, tail_bytes, lds, slot_bytes, par, wave, lane);
+        } else {
+            float e[G_ENC_STEPS];
+            encode_g(e, x, tab, ns, ident, g);
+            gemm_stage_g<NTO, G_ENC_STEPS, NW, KCH, true>(acc, e, ch, gw, tail_src, tail_bytes, lds, slot_bytes, par, wave, lane);
+        }
+    } else {
+        constexpr int CPP = G_ENC_STEPS / KCH, STEP_BYTES = ((NTO + 3) / 4) * 1024;
+        const int ch0 = ch < CPP ? ch : CPP, ch1 = ch - ch0;                    // uniform
+        const char* mid = gw + ch0 * KCH * STEP_BYTES;
+        if constexpr (HAVE0) {
+            gemm_stage_g<NTO, G_ENC_STEPS, NW, KCH, true>(acc, enc0, ch0, gw, ch1 ? mid : tail_src, ch1 ? KCH * STEP_BYTES : tail_bytes, lds,
+                                                          slot_bytes, par, wave, lane);
+        } else {
+            float e[G_ENC_STEPS];
+            encode_g(e, x, tab, g_part_ns(ns, 0), g_part_ident(ns, ident, 0), g);
+            gemm_stage_g<NTO, G_ENC_STEPS, NW, KCH, true>(acc, e, ch0, gw, ch1 ? mid : tail_src, ch1 ? KCH * STEP_BYTES : tail_bytes, lds,
+                                                          slot_bytes, par, wave, lane);
+        }
+        if (ch1) {
+            float e[G_ENC_STEPS];
+            encode_g(e, x, tab + G_ENC_ARGS, g_part_ns(ns, 1), g_part_ident(ns, ident, 1), g);
+            gemm_stage_g<NTO, G_ENC_STEPS, NW, KCH, true>(acc, e, ch1, mid, tail_src, tail_bytes, lds, slot_bytes, par, wave, lane);
+        }
+    }
+}
+
 // ---- training tape of the generic family: row-major [sample][width] rows of the REAL width (padding never leaves the
 // registers).  16-byte accesses when the row stride allows it (width % 4 == 0), element-wise otherwise (e.g. the 50-wide view
 // layer of a 100-wide network).
@@ -177,7 +224,7 @@ __device__ __forceinline__ void load_rows_g(const float* base, int width, int64_
 // spill 3 -- 88 registers for it, outside the k-step loops): +5 -- +6.5 points at 96 and 144 wide, +4.6 on the 8x128 shape, +1.2
 // at 160; wider classes lose more to spills than the two extra waves hide.  The training kernels of these classes measured
 // within +-3 % either way and simply share the bound.
-template <int NT, int NW, int KCH, bool TAPE = false>
+template <int NT, int NW, int KCH, bool TAPE = false, bool LONG = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp_kernel_g(const MlpArgs args, const int num_layers,
                                                                        const int density_only) {
     constexpr int HP = 16 * NT, NTD = (NT + 1) / 2, HPD = 16 * NTD;
@@ -194,11 +241,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp
     float* lds_wrgb = lds_walpha + HP;                          // [3][4][HPD / 4], or [3][4][HP / 4] for a use_viewdirs = 0 network
     const bool flat = density_only == 2;
     const int nrgb = flat ? 3 * HP : 3 * HPD;
-    GEncArg* lds_tab = reinterpret_cast<GEncArg*>(lds_walpha + g_head_floats(NT));   // [2][G_ENC_ARGS]
+    constexpr int PARTS = LONG ? G_ENC_PARTS : 1;
+    GEncArg* lds_tab = reinterpret_cast<GEncArg*>(lds_walpha + g_head_floats(NT));   // [xyz, dir][PARTS][G_ENC_ARGS]
     for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
     for (int i = threadIdx.x; i < HP; i += NW * 64) lds_walpha[i] = args.walpha[i];
     for (int i = threadIdx.x; i < nrgb; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
-    for (int i = threadIdx.x; i < 2 * G_ENC_ARGS; i += NW * 64) lds_tab[i] = static_cast<const GEncArg*>(args.g_tab)[i];
+    for (int i = threadIdx.x; i < 2 * PARTS * G_ENC_ARGS; i += NW * 64) lds_tab[i] = static_cast<const GEncArg*>(args.g_tab)[i];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
@@ -230,14 +278,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp
         const char* gw = args.wstream;
         // ---- layer1: xyz_enc -> H, no activation (models.py:62)
         load_bias<NT>(acc, lds_bias, g);
-        if constexpr (KEEP_ENC) {
-            encode_g(encx, p, lds_tab, args.g_nsx, args.g_idx, g);
-            gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
-        } else {
-            float e[G_ENC_STEPS];
-            encode_g(e, p, lds_tab, args.g_nsx, args.g_idx, opaque(g));
-            gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, e, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
-        }
+        if constexpr (KEEP_ENC) encode_g(encx, p, lds_tab, LONG ? g_part_ns(args.g_nsx, 0) : args.g_nsx, LONG ? g_part_ident(args.g_nsx, args.g_idx, 0) : args.g_idx, g);
+        enc_stages_g<NT, NW, KCH, KEEP_ENC, LONG>(acc, encx, p, lds_tab, args.g_nsx, args.g_idx, chx, KEEP_ENC ? g : opaque(g), gw, gw + enc_x_bytes,
+                                            FIRST_H, lds, SLOT, par, wave, lane);
         gw += enc_x_bytes;
         acc_to_operand<NT, false>(acc, in);
         if constexpr (TAPE) store_rows_g<NT>(args.tape_h, args.g_h, sample, valid, in, g);
@@ -267,13 +310,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp
                 const char* tsrc = after;
                 int tbytes = FIRST_H;
                 if (last_density) { tsrc = args.wstream; tbytes = wrap_bytes; }
-                if constexpr (KEEP_ENC) {
-                    gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, encx, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
-                } else {
-                    float e[G_ENC_STEPS];
-                    encode_g(e, p, lds_tab, args.g_nsx, args.g_idx, opaque(g));
-                    gemm_stage_g<NT, G_ENC_STEPS, NW, KCH, true>(acc, e, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
-                }
+                enc_stages_g<NT, NW, KCH, KEEP_ENC, LONG>(acc, encx, p, lds_tab, args.g_nsx, args.g_idx, chx, opaque(g), gw, tsrc, tbytes, lds, SLOT,
+                                                    par, wave, lane);
                 gw = after;
             }
             acc_to_operand<NT, true>(acc, in);
@@ -301,9 +339,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (NT <= 10 ? 4 : 2) : 1) void mlp
                                                   has_enc ? KCH * STEPD : wrap_bytes, lds, SLOT, par, wave, lane);
             gw = after;
             if (has_enc) {
-                float encd[G_ENC_STEPS];
-                encode_g(encd, d, lds_tab + G_ENC_ARGS, args.g_nsd, args.g_idd, g);
-                gemm_stage_g<NTD, G_ENC_STEPS, NW, KCH, true>(accd, encd, chd, gw, args.wstream, wrap_bytes, lds, SLOT, par, wave, lane);
+                const float none[1] = {0.0f};
+                enc_stages_g<NTD, NW, KCH, false, LONG>(accd, none, d, lds_tab + PARTS * G_ENC_ARGS, args.g_nsd, args.g_idd, chd, g, gw,
+                                                  args.wstream, wrap_bytes, lds, SLOT, par, wave, lane);
             }
         }
         acc_to_operand<NTD, true>(accd, v);

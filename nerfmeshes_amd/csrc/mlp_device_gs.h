@@ -173,7 +173,30 @@ __device__ __forceinline__ void gs_store_rows(float* base, int width, int64_t sa
     }
 }
 
-template <int NT, int KCH, bool TAPE, int HF>
+// the stages of one encoding's columns for this wave's tiles (enc_stages_g of mlp_device_g.h: one part, or -- LONG -- two)
+template <int NTO, int HF, int KCH, bool LONG, int N>
+__device__ __forceinline__ void gs_enc_stages(f32x4 (&acc)[N], const float (&x)[3], const GEncArg* tab, int ns, int ident, int ch, int g,
+                                              const char* gw, const char* tail_src, int tail_bytes, char* lds, int slot_bytes, int& par,
+                                              int wave, int lane) {
+    float e[G_ENC_STEPS];
+    if constexpr (!LONG) {
+        encode_g(e, x, tab, ns, ident, g);
+        gs_stage_regs<NTO, HF, G_ENC_STEPS, KCH, true>(acc, e, ch, gw, tail_src, tail_bytes, lds, slot_bytes, par, wave, lane);
+    } else {
+        constexpr int CPP = G_ENC_STEPS / KCH, STEP_BYTES = ((NTO + 3) / 4) * 1024;
+        const int ch0 = ch < CPP ? ch : CPP, ch1 = ch - ch0;                    // uniform
+        const char* mid = gw + ch0 * KCH * STEP_BYTES;
+        encode_g(e, x, tab, g_part_ns(ns, 0), g_part_ident(ns, ident, 0), g);
+        gs_stage_regs<NTO, HF, G_ENC_STEPS, KCH, true>(acc, e, ch0, gw, ch1 ? mid : tail_src, ch1 ? KCH * STEP_BYTES : tail_bytes, lds, slot_bytes,
+                                                       par, wave, lane);
+        if (ch1) {
+            encode_g(e, x, tab + G_ENC_ARGS, g_part_ns(ns, 1), g_part_ident(ns, ident, 1), g);
+            gs_stage_regs<NTO, HF, G_ENC_STEPS, KCH, true>(acc, e, ch1, mid, tail_src, tail_bytes, lds, slot_bytes, par, wave, lane);
+        }
+    }
+}
+
+template <int NT, int KCH, bool TAPE, bool LONG, int HF>
 __device__ __forceinline__ void gs_forward(const MlpArgs& args, const int num_layers, const int density_only, char* lds,
                                            const float* lds_bias, const int nbias, const float* lds_walpha, const float* lds_wrgb,
                                            const GEncArg* lds_tab, const int wave, const int lane) {
@@ -204,15 +227,19 @@ __device__ __forceinline__ void gs_forward(const MlpArgs& args, const int num_la
         const int64_t sidx = valid ? sample : args.n - 1;
         const SamplePD smp = fetch_sample(args, sidx);
         const float p[3] = {smp.px, smp.py, smp.pz}, d[3] = {smp.dx, smp.dy, smp.dz};
-        float encx[G_ENC_STEPS];
-        encode_g(encx, p, lds_tab, args.g_nsx, args.g_idx, g);
+        // LONG (16 -- 31 functions, two parts: gs_enc_stages) holds no encoding across the trunk: a skip layer evaluates it again
+        // (`opaque` keeps the compiler from hoisting that evaluation back up here)
+        auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+        float encx[LONG ? 1 : G_ENC_STEPS];
+        if constexpr (!LONG) encode_g(encx, p, lds_tab, args.g_nsx, args.g_idx, g);
 
         f32x4 acc[T::N];
         float own[4 * T::N];
         const char* gw = args.wstream;
         // ---- layer1: xyz_enc -> H, no activation (models.py:62)
         gs_load_bias<NT, HF>(acc, lds_bias, g);
-        gs_stage_regs<NT, HF, G_ENC_STEPS, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
+        if constexpr (!LONG) gs_stage_regs<NT, HF, G_ENC_STEPS, KCH, true>(acc, encx, chx, gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
+        else gs_enc_stages<NT, HF, KCH, true>(acc, p, lds_tab, args.g_nsx, args.g_idx, chx, opaque(g), gw, gw + enc_x_bytes, FIRST_H, lds, SLOT, par, wave, lane);
         gw += enc_x_bytes;
         gs_acc_to_own<T::N, false>(acc, own);
         if constexpr (TAPE) gs_store_rows<NT, HF>(args.tape_h, args.g_h, sample, valid, own, g);
@@ -246,7 +273,8 @@ __device__ __forceinline__ void gs_forward(const MlpArgs& args, const int num_la
                 const char* tsrc = after;
                 int tbytes = FIRST_H;
                 if (last_density) { tsrc = args.wstream; tbytes = wrap_bytes; }
-                gs_stage_regs<NT, HF, G_ENC_STEPS, KCH, true>(acc, encx, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                if constexpr (!LONG) gs_stage_regs<NT, HF, G_ENC_STEPS, KCH, true>(acc, encx, chx, gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
+                else gs_enc_stages<NT, HF, KCH, true>(acc, p, lds_tab, args.g_nsx, args.g_idx, chx, opaque(g), gw, tsrc, tbytes, lds, SLOT, par, wave, lane);
                 gw = after;
             }
             gs_acc_to_own<T::N, true>(acc, own);
@@ -295,11 +323,8 @@ __device__ __forceinline__ void gs_forward(const MlpArgs& args, const int num_la
             gs_stage_hidden<NT, NTD, HF, KCH>(accd, own, xch, gw, has_enc ? after : args.wstream, has_enc ? KCH * STEPD : wrap_bytes, lds,
                                               SLOT, par, wave, lane);
             gw = after;
-            if (has_enc) {
-                float encd[G_ENC_STEPS];
-                encode_g(encd, d, lds_tab + G_ENC_ARGS, args.g_nsd, args.g_idd, g);
-                gs_stage_regs<NTD, HF, G_ENC_STEPS, KCH, true>(accd, encd, chd, gw, args.wstream, wrap_bytes, lds, SLOT, par, wave, lane);
-            }
+            if (has_enc) gs_enc_stages<NTD, HF, KCH, LONG>(accd, d, lds_tab + (LONG ? G_ENC_PARTS : 1) * G_ENC_ARGS, args.g_nsd, args.g_idd, chd, g, gw, args.wstream,
+                                                           wrap_bytes, lds, SLOT, par, wave, lane);
         }
         gs_acc_to_own<D::N, true>(accd, v);
         if constexpr (TAPE) gs_store_rows<NTD, HF>(args.tape_v, args.g_hd, sample, valid, v, g);
@@ -323,7 +348,7 @@ __device__ __forceinline__ void gs_forward(const MlpArgs& args, const int num_la
     }
 }
 
-template <int NT, int KCH, bool TAPE = false>
+template <int NT, int KCH, bool TAPE = false, bool LONG = false>
 __global__ __launch_bounds__(2 * GS_PAIRS * 64, 2) void mlp_kernel_gs(const MlpArgs args, const int num_layers, const int density_only) {
     constexpr int NW = 2 * GS_PAIRS;
     constexpr int HP = 16 * NT, HPD = 16 * ((NT + 1) / 2);
@@ -338,14 +363,14 @@ __global__ __launch_bounds__(2 * GS_PAIRS * 64, 2) void mlp_kernel_gs(const MlpA
     for (int i = threadIdx.x; i < nbias; i += NW * 64) lds_bias[i] = args.bias[i];
     for (int i = threadIdx.x; i < HP; i += NW * 64) lds_walpha[i] = args.walpha[i];
     for (int i = threadIdx.x; i < nrgb; i += NW * 64) lds_wrgb[i] = args.wrgb[i];
-    for (int i = threadIdx.x; i < 2 * G_ENC_ARGS; i += NW * 64) lds_tab[i] = static_cast<const GEncArg*>(args.g_tab)[i];
+    for (int i = threadIdx.x; i < 2 * (LONG ? G_ENC_PARTS : 1) * G_ENC_ARGS; i += NW * 64) lds_tab[i] = static_cast<const GEncArg*>(args.g_tab)[i];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t wg_iters = (args.n + GS_PAIRS * 16 - 1) / (GS_PAIRS * 16);
     if ((int64_t)blockIdx.x < wg_iters) stream_to_lds<NW>(args.wstream, lds, KCH * STEP, wave, lane);
     __syncthreads();   // tables, biases and layer1's first chunk are resident
-    if (wave & 1) gs_forward<NT, KCH, TAPE, 1>(args, num_layers, density_only, lds, lds_bias, nbias, lds_walpha, lds_wrgb, lds_tab, wave, lane);
-    else gs_forward<NT, KCH, TAPE, 0>(args, num_layers, density_only, lds, lds_bias, nbias, lds_walpha, lds_wrgb, lds_tab, wave, lane);
+    if (wave & 1) gs_forward<NT, KCH, TAPE, LONG, 1>(args, num_layers, density_only, lds, lds_bias, nbias, lds_walpha, lds_wrgb, lds_tab, wave, lane);
+    else gs_forward<NT, KCH, TAPE, LONG, 0>(args, num_layers, density_only, lds, lds_bias, nbias, lds_walpha, lds_wrgb, lds_tab, wave, lane);
 }
 
 // ---- delta propagation (mlp_backward_kernel_g of mlp_device_g.h) on the same split: the transposed layers in reverse order, each

@@ -1,4 +1,4 @@
-// FlexibleNeRFModel beyond the fused kernel families' limits -- hidden_size > 512, or an encoding of more than 15 functions
+// FlexibleNeRFModel beyond the fused kernel families' limits -- hidden_size > 512, or an encoding of more than 48 k-steps (32 functions + input)
 // (/root/reference/src/nerf/models.py:5-58 takes ANY hidden_size / num_encoding_fn_*; nm_mlp_create refused those until
 // round 5) -- evaluated and trained LAYER BY LAYER on the general MFMA GEMM of nerf_dw_g.hip.
 //

@@ -105,11 +105,17 @@ void generic_plans_c(std::vector<MlpPlan>&);
 void generic_plans_d(std::vector<MlpPlan>&);
 void generic_plans_e(std::vector<MlpPlan>&);
 void generic_plans_s(std::vector<MlpPlan>&);
+void generic_plans_a_long(std::vector<MlpPlan>&);      // the same classes with two-part encoding stages (variant G_LONG_VARIANT)
+void generic_plans_b_long(std::vector<MlpPlan>&);
+void generic_plans_c_long(std::vector<MlpPlan>&);
+void generic_plans_d_long(std::vector<MlpPlan>&);
+void generic_plans_s_long(std::vector<MlpPlan>&);
 
 static const std::vector<MlpPlan>& all_plans() {
     static const std::vector<MlpPlan> plans = [] {
         std::vector<MlpPlan> v(std::begin(g_tuned_plans), std::end(g_tuned_plans));
         generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_s(v); generic_plans_e(v);
+        generic_plans_a_long(v); generic_plans_b_long(v); generic_plans_c_long(v); generic_plans_d_long(v); generic_plans_s_long(v);
 #ifdef NM_ABLATIONS
         // experiment (NM_MLP_VARIANT=200 + NM_KERNEL_GENERIC): two 16-sample column tiles per wave (mlp_device_g2.h)
         // (round 5: also the classes of 2 and 3 tiles -- VERDICT r4 item 7 -- compiled for four waves per SIMD (200) and two (201))
@@ -172,14 +178,16 @@ const MlpPlan* find_mlp_plan(int H, int FX, int FD) {
 }
 
 // the narrowest class of the generic family that holds hidden_size H and whose LDS image (weight ring + every bias of an L-layer
-// network + heads + tables) fits a CU; null if there is none (the caller then takes the layer-wise path)
-const MlpPlan* find_generic_plan(int H, int L) {
-    int want = 0;
+// network + heads + tables) fits a CU; `long_encoding`: an encoding of more than G_ENC_STEPS k-steps (16 -- 31 functions) -- the
+// instantiations with two-part encoding stages.  Null if there is none (the caller then takes the layer-wise path).
+const MlpPlan* find_generic_plan(int H, int L, bool long_encoding) {
+    int want = long_encoding ? G_LONG_VARIANT : 0;
 #ifdef NM_ABLATIONS
-    if (const char* v = getenv("NM_MLP_VARIANT")) want = (atoi(v) == 200 || atoi(v) == 201 || atoi(v) == 310) ? atoi(v) : 0;
+    if (const char* v = getenv("NM_MLP_VARIANT"))
+        if (!long_encoding) want = (atoi(v) == 200 || atoi(v) == 201 || atoi(v) == 310) ? atoi(v) : 0;
 #endif
     for (const MlpPlan& p : all_plans())
-        if (p.generic_nt && p.variant == want && p.H >= H && g_lds_bytes(p.ring_bytes, p.generic_nt, L) <= 160 * 1024) return &p;
+        if (p.generic_nt && p.variant == want && p.H >= H && g_lds_bytes(p.ring_bytes, p.generic_nt, L, p.variant == G_LONG_VARIANT ? G_ENC_PARTS : 1) <= 160 * 1024) return &p;
     return nullptr;
 }
 
@@ -235,7 +243,7 @@ int launch_mlp(const nm_mlp* m, const MlpArgs& args, int density_only, hipStream
     const int rgb_floats = density_only == 2 ? 3 * H : 3 * H / 2;
     int lds_bytes = p->ring_bytes + (p->lds_bias ? (((H * (1 + L) + H / 2 + 4 + H + rgb_floats) * 4 + 255) & ~255) : 0);
     if (p->generic_nt) {    // padded widths, both head layouts, the two argument tables (mlp_device_g.h)
-        lds_bytes = g_lds_bytes(p->ring_bytes, p->generic_nt, L);
+        lds_bytes = g_lds_bytes(p->ring_bytes, p->generic_nt, L, p->variant == G_LONG_VARIANT ? G_ENC_PARTS : 1);
     }
     NM_REQUIRE(lds_bytes <= 160 * 1024, "LDS budget exceeded (ring + bias cache)");
     // the dynamic-LDS attribute is per device: tracked per (device, plan)

@@ -5,6 +5,16 @@
 #include "nm_internal.h"
 #include "mlp_device_g.h"
 
+// compiled twice: as it is, and from nerf_mlp_generic_a_long.hip with NM_GENERIC_LONG defined -- the instantiations whose encoding
+// stages take two parts (16 -- 31 functions; enc_stages_g in mlp_device_g.h), registered as plans of variant G_LONG_VARIANT
+#ifdef NM_GENERIC_LONG
+#define NM_PLANS_FN generic_plans_a_long
+constexpr bool kLong = true;
+#else
+#define NM_PLANS_FN generic_plans_a
+constexpr bool kLong = false;
+#endif
+
 namespace nm {
 
 template <int NT>
@@ -12,11 +22,11 @@ static MlpPlan generic_plan() {
     static_assert(NT <= 24, "wider classes: nerf_mlp_generic_s.hip");
     constexpr int NW = 8, KCH = 8;            // two waves per SIMD; ring slots of at most 48 KiB
     constexpr int SLOT = KCH * ((NT + 3) / 4) * 1024;
-    return MlpPlan{16 * NT, -1, -1, NW, KCH, 0, 2 * SLOT, true, &mlp_kernel_g<NT, NW, KCH>, NW * 16, 1,
-                   &mlp_kernel_g<NT, NW, KCH>, NT, &mlp_kernel_g<NT, NW, KCH, true>, &mlp_backward_kernel_g<NT, NW, KCH>};
+    return MlpPlan{16 * NT, -1, -1, NW, KCH, kLong ? G_LONG_VARIANT : 0, 2 * SLOT, true, &mlp_kernel_g<NT, NW, KCH, false, kLong>, NW * 16, 1,
+                   &mlp_kernel_g<NT, NW, KCH, false, kLong>, NT, &mlp_kernel_g<NT, NW, KCH, true, kLong>, &mlp_backward_kernel_g<NT, NW, KCH>};
 }
 
-void generic_plans_a(std::vector<MlpPlan>& out) {
+void NM_PLANS_FN(std::vector<MlpPlan>& out) {
     out.push_back(generic_plan<1>());
     out.push_back(generic_plan<2>());
     out.push_back(generic_plan<3>());

@@ -5,17 +5,27 @@
 #include "nm_internal.h"
 #include "mlp_device_gs.h"
 
+// compiled twice: as it is, and from nerf_mlp_generic_s_long.hip with NM_GENERIC_LONG defined (two-part encoding stages, 16 -- 31
+// functions: plans of variant G_LONG_VARIANT)
+#ifdef NM_GENERIC_LONG
+#define NM_PLANS_FN generic_plans_s_long
+constexpr bool kLong = true;
+#else
+#define NM_PLANS_FN generic_plans_s
+constexpr bool kLong = false;
+#endif
+
 namespace nm {
 
 template <int NT>
 static MlpPlan split_plan() {
     constexpr int KCH = 4;                    // one input tile per chunk (the exchange schedule of mlp_device_gs.h)
     constexpr int SLOT = KCH * ((NT + 3) / 4) * 1024;
-    return MlpPlan{16 * NT, -1, -1, 2 * GS_PAIRS, KCH, 0, 2 * SLOT + GS_EXTRA_BYTES, true, &mlp_kernel_gs<NT, KCH>, GS_PAIRS * 16, 1,
-                   &mlp_kernel_gs<NT, KCH>, NT, &mlp_kernel_gs<NT, KCH, true>, &mlp_backward_kernel_gs<NT, KCH>};
+    return MlpPlan{16 * NT, -1, -1, 2 * GS_PAIRS, KCH, kLong ? G_LONG_VARIANT : 0, 2 * SLOT + GS_EXTRA_BYTES, true, &mlp_kernel_gs<NT, KCH, false, kLong>, GS_PAIRS * 16, 1,
+                   &mlp_kernel_gs<NT, KCH, false, kLong>, NT, &mlp_kernel_gs<NT, KCH, true, kLong>, &mlp_backward_kernel_gs<NT, KCH>};
 }
 
-void generic_plans_s(std::vector<MlpPlan>& out) {
+void NM_PLANS_FN(std::vector<MlpPlan>& out) {
     out.push_back(split_plan<26>());
     out.push_back(split_plan<28>());
     out.push_back(split_plan<30>());

@@ -323,7 +323,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
         a.tiles = (a.n + 15) / 16;
         const MlpPlan* p = m->plan;
         const int L = d.num_layers;
-        const int lds_bytes = g_lds_bytes(p->ring_bytes, p->generic_nt, L);
+        const int lds_bytes = g_lds_bytes(p->ring_bytes, p->generic_nt, L, p->variant == G_LONG_VARIANT ? G_ENC_PARTS : 1);
         if (int rc = set_lds((const void*)p->kernel_tape, lds_bytes)) return rc;
         const int64_t wg_iters = (a.n + p->wg_samples - 1) / p->wg_samples;
         hipLaunchKernelGGL(p->kernel_tape, dim3(persistent_grid(wg_iters, m->num_cus)), dim3(p->NW * 64), lds_bytes,

@@ -118,7 +118,7 @@ struct MlpArgs {
     int64_t tiles;           // ceil(n / 16)
     RayGen gen;              // VIEW: rays generated from the pose (c = t as in RAYS; a, b unused)
     // generic-shape kernels only (mlp_device_g.h): the encodings' run-time description
-    const void* g_tab;       // device: GEncArg[2][48] (xyz, dir): coordinate and frequency band of every encoding argument
+    const void* g_tab;       // device: GEncArg[2][96] (xyz, dir; two parts of 48): coordinate and frequency band of every encoding argument
     int32_t g_nsx, g_idx, g_chx;   // xyz: k-steps that carry arguments, 1 = an identity step follows, whole chunks in the stream
     int32_t g_nsd, g_idd, g_chd;   // direction encoding likewise (g_chd = 0: no encoded direction columns at all)
     int32_t g_h, g_hd;             // the REAL widths hidden_size and hidden_size // 2: row strides of the generic training tape

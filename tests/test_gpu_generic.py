@@ -61,10 +61,21 @@ OFF_MENU = [
     dict(hidden_size=1024, num_layers=3, skip_step=2),
     dict(hidden_size=530, num_layers=3, num_encoding_fn_xyz=6),                                       # not a multiple of 4: 4-byte DMA pieces, 265-row view layer
     dict(hidden_size=600, num_layers=4, use_viewdirs=False),
-    # ... or an encoding longer than 24 MFMA k-steps
-    dict(hidden_size=64, num_layers=3, num_encoding_fn_xyz=20, num_encoding_fn_dir=17),
-    dict(hidden_size=272, num_layers=4, skip_step=2, num_encoding_fn_xyz=16),
+    # an encoding longer than 24 MFMA k-steps (16 -- 31 functions): the fused instantiations with two-part encoding stages (round 5) ...
+    dict(hidden_size=64, num_layers=3, num_encoding_fn_xyz=20, num_encoding_fn_dir=17),              # both encodings in two parts
+    dict(hidden_size=272, num_layers=4, skip_step=2, num_encoding_fn_xyz=16),                          # 25 k-steps: the identity step alone is part two
+    dict(hidden_size=448, num_layers=3, skip_step=2, num_encoding_fn_xyz=31, num_encoding_fn_dir=0),  # 48 k-steps on a split class, no direction encoding
+    dict(hidden_size=100, num_layers=4, skip_step=2, num_encoding_fn_xyz=23, include_input_xyz=False, use_viewdirs=False),
+    # ... and beyond 48 k-steps layer by layer
+    dict(hidden_size=64, num_layers=3, num_encoding_fn_xyz=32, num_encoding_fn_dir=1),
 ]
+
+
+def _enc_steps(spec):
+    steps = [(3 * spec.num_encoding_fn_xyz + 1) // 2 + int(spec.include_input_xyz)]
+    if spec.use_viewdirs:
+        steps.append((3 * spec.num_encoding_fn_dir + 1) // 2 + int(spec.include_input_dir))
+    return max(steps)
 
 
 @pytest.mark.parametrize("kw", OFF_MENU, ids=lambda kw: "-".join(f"{k.replace('num_encoding_fn_', 'F').replace('hidden_size', 'H')}{v}" for k, v in kw.items()))
@@ -74,7 +85,7 @@ def test_off_menu_shapes_vs_oracle(ops, kw):
     mlp = ops.HipMLP(w, desc, "cuda")
     variant, waves = mlp.kernel_variant()
     on_menu = spec.hidden_size in (64, 128, 256) and spec.num_encoding_fn_xyz in (6, 10) and spec.num_encoding_fn_dir == 4
-    beyond = spec.hidden_size > 512 or max(spec.num_encoding_fn_xyz, spec.num_encoding_fn_dir if spec.use_viewdirs else 0) > 15
+    beyond = spec.hidden_size > 512 or _enc_steps(spec) > 48
     assert variant == 0 if on_menu else ((variant == 2000) if beyond else (1000 <= variant < 2000 and 16 * (variant - 1000) >= spec.hidden_size)), \
         "an off-menu shape runs on the generic family, one beyond its limits layer by layer"
     g = torch.Generator().manual_seed(5)
@@ -171,7 +182,8 @@ TRAIN_SHAPES = [
     dict(num_layers=3, hidden_size=128, num_encoding_fn_dir=0, include_input_dir=False),                 # no direction columns
     # the layer-wise path trains too (tape rows transposed out of its planes, delta chain on the same GEMM)
     dict(num_layers=3, hidden_size=544, skip_step=2, num_encoding_fn_xyz=6),
-    dict(num_layers=3, hidden_size=96, num_encoding_fn_xyz=17, num_encoding_fn_dir=2),
+    dict(num_layers=3, hidden_size=96, num_encoding_fn_xyz=17, num_encoding_fn_dir=2),                  # a two-part encoding trains on the fused kernels (its taping forward)
+    dict(num_layers=3, hidden_size=72, skip_step=2, num_encoding_fn_xyz=32, num_encoding_fn_dir=2),      # 49 k-steps: the layer-wise path trains it
     dict(num_layers=3, hidden_size=520, num_encoding_fn_xyz=4, use_viewdirs=False),
 ]
 
