@@ -340,8 +340,9 @@ def make_optimizer(kind, params, lr, **kw):
     cls = getattr(torch.optim, kind)
     params = list(params)
     flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
-    if "fused" in inspect.signature(cls.__init__).parameters and "fused" not in kw and "foreach" not in kw and flat and \
-            all(p.is_cuda and torch.is_floating_point(p) for p in flat):
+    # (only the optimizers whose fused implementation is a GPU one: torch's Adagrad, e.g., takes the flag for host tensors only)
+    if kind in ("Adam", "AdamW", "SGD") and "fused" in inspect.signature(cls.__init__).parameters and "fused" not in kw and \
+            "foreach" not in kw and flat and all(p.is_cuda and torch.is_floating_point(p) for p in flat):
         kw["fused"] = True
     return cls(params, lr=lr, **kw)
 
