@@ -36,7 +36,7 @@ extern "C" {
  * every layer shape, row stride and sample count; nm_weight_grad / nm_head_grad forward to them (their shape and n % 16
  * restrictions are gone), nm_encode_samples_strided writes whole rows for any stride.  No signature changed; everything in
  * version 3 is unchanged.  nm_mlp_create accepts hidden sizes above 512 and up to 32 encoding functions (layer-wise path). */
-#define NM_ABI_VERSION 4
+#define NM_ABI_VERSION 5
 
 const char* nm_last_error(void);
 int nm_abi_version(void);
@@ -232,6 +232,18 @@ int nm_render_view(nm_mlp* coarse, nm_mlp* fine, const nm_render_cfg* cfg, const
  * nm_mlp_weights; freq_xyz / freq_dir are ignored (buffers, fixed at nm_mlp_create). */
 int nm_mlp_refresh(nm_mlp* mlp, const nm_mlp_weights* d_weights, void* stream);
 
+/* Stale-parameter guard (ABI v5).  The reference has no packed copy to go stale: its forward reads the nn.Parameter
+ * storages themselves (src/nerf/models.py:60-80), so ANY in-place edit -- an optimizer step (src/models/model_base.py:159-162),
+ * `p.data.mul_()`, torch._foreach_* on `.data`, load_state_dict -- is visible to the next forward.  A handle holds a packed
+ * image instead; these two calls let the host prove that the image still equals the live tensors:
+ *   nm_mlp_refresh_count    how many times the image was (re)built since nm_mlp_create (create counts as 1).
+ *   nm_mlp_weights_current  *differs = 0 when a checksum of the caller's live tensors (same pointers as nm_mlp_refresh),
+ *                           taken through the gather's own index map, equals the checksum the last gather recorded of
+ *                           what it packed; 1 otherwise.  One read-only kernel over the parameters (8x256: 2.4 MB) and an
+ *                           8-byte read-back: it SYNCHRONISES `stream`.  64-bit sum of bits(value) * (2 * position + 1). */
+int64_t nm_mlp_refresh_count(const nm_mlp* mlp);
+int nm_mlp_weights_current(nm_mlp* mlp, const nm_mlp_weights* d_weights, void* stream, int32_t* differs);
+
 /* Activations recorded by the training forward, n = rays * samples, tiles = ceil(n / 16), L = num_layers,
  * H = hidden_size.  Rows are the operands of the weight-gradient GEMMs (dW = delta^T @ rows).
  * A use_viewdirs = 0 handle tapes the trunk only: d_feat, d_v and d_mask_v are not touched and may be NULL (likewise the
@@ -321,7 +333,9 @@ int nm_weight_grad_plan(int32_t out_features, int32_t delta_stride, int32_t in_f
  * (models.py:63-70: layers_xyz[*] and fc_feat are all hidden x hidden).  A job gets 1 / jobs of the CUs and jobs times the
  * samples per workgroup: the same matrix work, but jobs times fewer per-workgroup partials to write and to reduce (eight
  * 256 x 256 layers: 64 MB instead of 512 MB) and 2 launches instead of 2 * jobs.  At most 16 jobs; the workspace of ONE
- * product (nm_weight_grad_workspace_bytes_ex) suffices.  Deterministic; the summation grouping differs from jobs separate
+ * product (nm_weight_grad_workspace_bytes_ex) suffices: it holds max(1, num_cus / output blocks) sample parts, and a batch
+ * that needs more (layers wider than ~1000: the output is cut into many blocks) is issued in sub-batches that re-use it, one
+ * after the other on the stream.  Deterministic; the summation grouping differs from jobs separate
  * calls (fewer, longer sample parts). */
 typedef struct nm_weight_grad_job {
     const float* d_delta;    /* (n, out_features), row stride delta_stride */

@@ -100,6 +100,8 @@ SIGNATURES = {
                                          c_void_p]),
     # training path
     "nm_mlp_refresh": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p]),
+    "nm_mlp_refresh_count": (C.c_int64, [c_void_p]),
+    "nm_mlp_weights_current": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p, C.POINTER(C.c_int32)]),
     "nm_mlp_forward_train": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32,
                                        C.POINTER(MlpTape), c_void_p, c_void_p]),
     "nm_mlp_backward": (C.c_int, [c_void_p, C.c_int64, C.POINTER(MlpTape), c_void_p, c_void_p, C.POINTER(MlpDeltas),
@@ -188,7 +190,7 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.nm_abi_version() != 4:
+    if lib.nm_abi_version() != 5:
         raise HipLibraryError("ABI version mismatch between _lib.py and libnerfmeshes_hip.so")
     _lib = lib
     return lib

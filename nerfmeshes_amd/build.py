@@ -45,35 +45,83 @@ def needs_build():
 ABLATION_LIB_PATH = os.path.join(CSRC, "libnerfmeshes_hip_ablations.so")
 
 
-def build(force=False, verbose=True, ablations=False):
+def _includes(path, seen):
+    """Quoted includes of `path`, transitively (the headers an object depends on)."""
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("#include \""):
+            dep = os.path.normpath(os.path.join(os.path.dirname(path), line.split('"')[1]))
+            if dep not in seen and os.path.exists(dep):
+                seen.add(dep)
+                _includes(dep, seen)
+
+
+def _stale(src_path, obj):
+    """An object is rebuilt when its source, a header it includes (transitively) or this script is newer than it."""
+    if not os.path.exists(obj):
+        return True
+    deps = {src_path, os.path.abspath(__file__)}
+    _includes(src_path, deps)
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, ablations=False, jobs=None):
     """Product library by default.  ablations=True builds a SEPARATE library with -DNM_ABLATIONS (the MLP kernel
     A/B variants, some of which compute wrong results on purpose, selectable there by NM_MLP_VARIANT); nothing in
-    the package loads it -- scripts/bench_mlp.py points nerfmeshes_amd._lib at it explicitly."""
+    the package loads it -- scripts/bench_mlp.py points nerfmeshes_amd._lib at it explicitly.
+    Per-object incremental: only the translation units whose source or included headers changed are recompiled
+    (`jobs` of them at a time, default = the host's cores)."""
     lib_path = ABLATION_LIB_PATH if ablations else LIB_PATH
-    if not ablations and not force and not needs_build():
-        return LIB_PATH
-    objs = []
-    procs = []
     bdir = os.path.join(CSRC, "build_ablations" if ablations else "build")
     os.makedirs(bdir, exist_ok=True)
+    objs, todo = [], []
     for src in _present(SOURCES):
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + (["-DNM_ABLATIONS"] if ablations else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
-    for src, p in procs:
+        if force or _stale(os.path.join(CSRC, src), obj):
+            todo.append((src, obj))
+    if not todo and os.path.exists(lib_path) and all(os.path.getmtime(o) <= os.path.getmtime(lib_path) for o in objs):
+        return lib_path
+    jobs = jobs or int(os.environ.get("NM_BUILD_JOBS", "0")) or os.cpu_count() or 4
+    # the largest translation units first, so that they are not what the build waits for at the end
+    todo.sort(key=lambda so: -_weight(so[0]))
+    running, failed = [], None
+    while (todo or running) and failed is None:
+        while todo and len(running) < jobs:
+            src, obj = todo.pop(0)
+            cmd = [hipcc()] + FLAGS + (["-DNM_ABLATIONS"] if ablations else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        src, p = running.pop(0)
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-        if verbose and out.strip():
+            failed = f"hipcc failed on {src}:\n{out.decode()}"
+        elif verbose and out.strip():
             print(out.decode())
+    if failed is not None:
+        for _, p in running:
+            p.kill()
+        raise RuntimeError(failed)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return lib_path
+
+
+# relative compile cost of the translation units (minutes on one core, roughly): scheduling order only
+_COST = {"nerf_mlp_generic_s.hip": 9, "nerf_mlp_generic_s_long.hip": 9, "nerf_mlp_generic_e.hip": 6, "nerf_mlp_generic_d.hip": 5,
+         "nerf_mlp_generic_d_long.hip": 5, "nerf_mlp_generic_c.hip": 4, "nerf_mlp_generic_c_long.hip": 4, "nerf_dw_g.hip": 3}
+
+
+def _weight(src):
+    return _COST.get(src, 1)
 
 
 if __name__ == "__main__":

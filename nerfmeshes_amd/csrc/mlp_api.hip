@@ -342,13 +342,31 @@ static void pad_to(std::vector<int32_t>& v, size_t multiple) {
     while (v.size() % multiple) v.push_back(-1);
 }
 
-// blob[i] = parameter element index[i] names (or 0): the whole packing, on the device
-__global__ void gather_parameters(const int32_t* __restrict__ index, WeightPtrs ptrs, float* __restrict__ blob,
-                                  int64_t count) {
+// blob[i] = parameter element index[i] names (or 0): the whole packing, on the device.  Every pass also folds what it read into
+// a 64-bit checksum of the packed image (sum over i of bits(value_i) * (2 i + 1), integer arithmetic: order-free, so plain
+// atomics keep it deterministic): WRITE = the gather itself, !WRITE = a verification pass over the caller's LIVE tensors that
+// touches nothing (nm_mlp_weights_current: "is the packed copy still what these tensors hold?").
+template <bool WRITE>
+__global__ __launch_bounds__(256) void gather_parameters(const int32_t* __restrict__ index, WeightPtrs ptrs, float* __restrict__ blob,
+                                                         int64_t count, unsigned long long* __restrict__ check) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int32_t s = index[i];
-    blob[i] = s < 0 ? 0.0f : ptrs.p[s >> 24][s & 0xffffff];
+    unsigned long long term = 0;
+    if (i < count) {
+        const int32_t s = index[i];
+        const float v = s < 0 ? 0.0f : ptrs.p[s >> 24][s & 0xffffff];
+        if (WRITE) blob[i] = v;
+        term = (unsigned long long)__float_as_uint(v) * (unsigned long long)(2 * i + 1);
+    }
+    if (!check) return;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)term, off), hi = __shfl_xor((unsigned)(term >> 32), off);
+        term += ((unsigned long long)hi << 32) | lo;
+    }
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(check, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 static bool is_skip(const nm_mlp_desc& d, int i) {   // models.py:37,63
@@ -368,18 +386,20 @@ static void weight_pointers(const nm_mlp_desc& d, const nm_mlp_weights& w, Weigh
     p.p[T_RGBW] = w.fc_rgb_w; p.p[T_RGBB] = w.fc_rgb_b;
 }
 
-static int launch_gather(const nm_mlp* m, const WeightPtrs& ptrs, hipStream_t stream) {
+static int launch_gather(nm_mlp* m, const WeightPtrs& ptrs, hipStream_t stream) {
     const int64_t n = (int64_t)m->blob_floats;
-    hipLaunchKernelGGL(gather_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m->d_index, ptrs,
-                       static_cast<float*>(m->d_blob), n);
+    if (m->d_check) NM_HIP_CHECK(hipMemsetAsync(m->d_check, 0, 8, stream));
+    hipLaunchKernelGGL(gather_parameters<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m->d_index, ptrs,
+                       static_cast<float*>(m->d_blob), n, m->d_check);
     if (m->precision == NM_PREC_BF16X3) {
         const int64_t nb = (int64_t)m->b3_units * 512;
-        hipLaunchKernelGGL(gather_parameters, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, m->d_index_b3, ptrs,
-                           m->d_tmp_b3, nb);
+        hipLaunchKernelGGL(gather_parameters<true>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, m->d_index_b3, ptrs,
+                           m->d_tmp_b3, nb, static_cast<unsigned long long*>(nullptr));
         hipLaunchKernelGGL(split_b3_kernel, dim3((unsigned)((m->b3_units * 64 + 255) / 256)), dim3(256), 0, stream,
                            m->d_tmp_b3, static_cast<uint4*>(m->d_stream_b3), (int64_t)m->b3_units);
     }
     NM_HIP_CHECK(hipGetLastError());
+    ++m->refresh_count;
     return 0;
 }
 
@@ -647,6 +667,8 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     m->blob_floats = index.size();
     m->blob_bytes = index.size() * 4;
     NM_HIP_CHECK(hipMalloc(&m->d_blob, m->blob_bytes));
+    NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->d_check), 16));
+    NM_HIP_CHECK(hipMemset(m->d_check, 0, 16));
     NM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->d_index), m->blob_bytes));
     NM_HIP_CHECK(hipMemcpy(m->d_index, index.data(), m->blob_bytes, hipMemcpyHostToDevice));
     if (precision == NM_PREC_BF16X3) {
@@ -730,10 +752,34 @@ int nm_mlp_refresh(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream) {
     return launch_gather(m, ptrs, static_cast<hipStream_t>(stream));
 }
 
+int64_t nm_mlp_refresh_count(const nm_mlp* m) { return m ? m->refresh_count : -1; }
+
+int nm_mlp_weights_current(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream_, int32_t* differs) {
+    NM_REQUIRE(m && d_weights && differs, "null argument");
+    WeightPtrs ptrs;
+    weight_pointers(m->desc, *d_weights, ptrs);
+    for (int t = 0; t < T_COUNT; ++t) {
+        const bool view_branch = t == T_FEATW || t == T_FEATB || t == T_DIRW || t == T_DIRB;
+        const bool used = (t < T_XYZ0 + 2 * (m->desc.num_layers - 1) || t >= T_FEATW) && !(view_branch && !m->desc.use_viewdirs);
+        NM_REQUIRE(!used || ptrs.p[t], "nm_mlp_weights_current: missing tensor");
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t n = (int64_t)m->blob_floats;
+    NM_HIP_CHECK(hipMemsetAsync(m->d_check + 1, 0, 8, stream));
+    hipLaunchKernelGGL(gather_parameters<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m->d_index, ptrs,
+                       static_cast<float*>(nullptr), n, m->d_check + 1);
+    unsigned long long both[2];
+    NM_HIP_CHECK(hipMemcpyAsync(both, m->d_check, 16, hipMemcpyDeviceToHost, stream));
+    NM_HIP_CHECK(hipStreamSynchronize(stream));
+    *differs = both[0] != both[1];
+    return 0;
+}
+
 void nm_mlp_destroy(nm_mlp* m) {
     if (!m) return;
     if (m->d_blob) (void)hipFree(m->d_blob);
     if (m->d_index) (void)hipFree(m->d_index);
+    if (m->d_check) (void)hipFree(m->d_check);
     if (m->d_index_b3) (void)hipFree(m->d_index_b3);
     if (m->d_tmp_b3) (void)hipFree(m->d_tmp_b3);
     if (m->d_stream_b3) (void)hipFree(m->d_stream_b3);

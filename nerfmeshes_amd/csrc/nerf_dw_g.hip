@@ -688,7 +688,9 @@ extern "C" int64_t nm_weight_grad_workspace_bytes_ex(int32_t out_features, int32
     for (int mode = 0; mode < 4; ++mode) {
         DwGPlan p;
         if (!plan_dw_g(out_features, delta_stride, in_features, act_stride, mode & 1, mode & 2, num_cus, &p)) continue;
-        const int64_t parts = (int64_t)(num_cus / (p.nba * p.nbb)) * p.wk;
+        // what nm_weight_grad_batch launches at most per sub-batch: jobs * per_job <= max(1, cus / (nba * nbb)) sample parts
+        const int64_t blocks = (int64_t)p.nba * p.nbb;
+        const int64_t parts = (num_cus / blocks > 1 ? num_cus / blocks : 1) * p.wk;
         const int64_t out_pad = (int64_t)p.nba * p.wa * p.ta * 16, in_pad = (int64_t)p.nbb * p.wb * p.tb * 16;
         const int64_t bytes = parts * (out_pad * in_pad + out_pad) * 4;
         need = bytes > need ? bytes : need;
@@ -701,6 +703,9 @@ extern "C" int64_t nm_weight_grad_workspace_bytes_ex(int32_t out_features, int32
 // `jobs` products of ONE shape, stride pair and row count in one launch + one reduction (the same-shape layers of a
 // network): a job gets 1 / jobs of the CUs and jobs times the samples per workgroup -- the same matrix work, jobs times fewer
 // partials to write and reduce.  The tuned kernel when it serves the shape, the general one otherwise.
+// The workspace of ONE product (nm_weight_grad_workspace_bytes_ex) holds max(1, cus / (nba * nbb)) sample parts: when the output
+// is cut into so many blocks that `jobs` products no longer fit beside each other (8 x 8 blocks of a 2048-wide layer: 4 parts),
+// the batch goes out in sub-batches of that many products, one after the other on the stream, each re-using the workspace.
 extern "C" int nm_weight_grad_batch(int device_cus, int32_t jobs, const nm_weight_grad_job* job, int32_t out_features,
                                     int32_t delta_stride, int32_t in_features, int32_t act_stride, int64_t n, void* d_workspace,
                                     void* stream_) {
@@ -723,9 +728,17 @@ extern "C" int nm_weight_grad_batch(int device_cus, int32_t jobs, const nm_weigh
     DwGPlan p;
     NM_REQUIRE(plan_dw_g(out_features, delta_stride, in_features, act_stride, a_x4, b_x4, cus, &p),
                "weight_grad: no tiling for this (out, in) shape (rows wider than the LDS ring holds)");
+    const int fit = cus / (p.nba * p.nbb) > 1 ? cus / (p.nba * p.nbb) : 1;      // sample parts the workspace holds
+    if (jobs > fit) {
+        for (int j0 = 0; j0 < jobs; j0 += fit)
+            if (int rc = nm_weight_grad_batch(device_cus, jobs - j0 < fit ? jobs - j0 : fit, job + j0, out_features, delta_stride,
+                                              in_features, act_stride, n, d_workspace, stream_))
+                return rc;
+        return 0;
+    }
     const int64_t chunks = (n + p.rows - 1) / p.rows;
-    int64_t per_job = cus / (p.nba * p.nbb * jobs);
-    per_job = per_job < 1 ? 1 : (per_job > chunks ? chunks : per_job);
+    int64_t per_job = fit / jobs;
+    per_job = per_job > chunks ? chunks : per_job;
     NM_REQUIRE((chunks / per_job + 2) * p.rows * (int64_t)(delta_stride > act_stride ? delta_stride : act_stride) * 4 < 0xf0000000ll,
                "weight_grad: a workgroup's sample range exceeds 32-bit offsets");
     DwGBatch batch;

@@ -142,13 +142,23 @@ struct LwBuffers {
     int64_t ld;
 };
 
-// the handle's workspace, grow-only; carved for a batch capacity `ld` (a multiple of 1024)
-static int lw_carve(nm_mlp* m, LwNet* net, int64_t ld, bool training, LwBuffers* b) {
+// the handle's workspace, grow-only; carved for a batch capacity `ld` (a multiple of 1024).  It lives IN the handle: a
+// layer-wise handle is NOT re-entrant -- calls on it must be serialised by the caller (one stream / one thread at a time; the
+// fused handles keep no per-call state and do not have this restriction).  Growing frees and re-allocates, which is illegal
+// while `stream` is being captured into a hipGraph: the call then fails with a reason instead (warm the handle with the largest
+// batch before the capture).
+static int lw_carve(nm_mlp* m, LwNet* net, int64_t ld, bool training, LwBuffers* b, hipStream_t stream) {
     const int64_t H = net->H, H2 = net->flat ? 0 : net->H2, L = net->L;
     const int64_t out_pad_max = round_up(std::max<int64_t>(H, 16), 256);
     const int64_t planes_h = training ? L : 2;
     int64_t floats = (net->dx + net->dd + planes_h * H + (net->flat ? 0 : H + H2) + 4 + (training ? 2 * H : 0) + 2 * out_pad_max) * ld + 1024;
     if ((size_t)floats > net->ws_floats) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+            set_error("layer-wise network path: the activation workspace would have to grow (" + std::to_string(floats * 4 >> 20) +
+                      " MiB) while the stream is being captured: run this batch size once before the capture");
+            return 1;
+        }
         if (net->ws) (void)hipFree(net->ws);
         net->ws = nullptr; net->ws_floats = 0;
         void* p = nullptr;
@@ -279,7 +289,7 @@ int layerwise_forward(nm_mlp* m, const MlpArgs& args, int density_only, hipStrea
     LwDeviceGuard guard(m->device);
     const int64_t ld = lw_batch(net, args.n, false);
     LwBuffers b;
-    if (int rc = lw_carve(m, net, ld, false, &b)) return rc;
+    if (int rc = lw_carve(m, net, ld, false, &b, stream)) return rc;
     for (int64_t first = 0; first < args.n; first += ld) {
         const int count = (int)std::min<int64_t>(ld, args.n - first);
         if (int rc = lw_forward_batch(m, net, args, first, count, false, density_only == 1 ? 1 : 0, b, stream)) return rc;
@@ -293,11 +303,14 @@ int layerwise_forward(nm_mlp* m, const MlpArgs& args, int density_only, hipStrea
 int layerwise_forward_train(nm_mlp* m, const MlpArgs& args, const nm_mlp_tape* tape, hipStream_t stream) {
     LwNet* net = static_cast<LwNet*>(m->lw);
     NM_REQUIRE(net, "not a layer-wise handle");
+    // the weight-gradient planner tiles outputs of at most 8 blocks x 16 tiles x 16 = 2048 features per side (nerf_dw_g.hip):
+    // say so where training starts, not three calls later as "no tiling"
+    NM_REQUIRE(net->H <= 2048, "training: hidden_size > 2048 is inference-only (the weight-gradient kernels tile at most 2048 x 2048 outputs)");
     if (args.n <= 0) return 0;
     const int H = net->H, L = net->L;
     const int64_t ld = lw_batch(net, args.n, true);
     LwBuffers b;
-    if (int rc = lw_carve(m, net, ld, true, &b)) return rc;
+    if (int rc = lw_carve(m, net, ld, true, &b, stream)) return rc;
     for (int64_t first = 0; first < args.n; first += ld) {
         const int count = (int)std::min<int64_t>(ld, args.n - first);
         if (int rc = lw_forward_batch(m, net, args, first, count, true, 0, b, stream)) return rc;
@@ -322,7 +335,7 @@ int layerwise_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const floa
     const int H = net->H, H2 = net->H2, L = net->L, dx = net->dx, dd = net->dd;
     const int64_t ld = lw_batch(net, n, true);
     LwBuffers b;
-    if (int rc = lw_carve(m, net, ld, true, &b)) return rc;
+    if (int rc = lw_carve(m, net, ld, true, &b, stream)) return rc;
     for (int64_t first = 0; first < n; first += ld) {
         const int count = (int)std::min<int64_t>(ld, n - first);
         // the ReLU' masks: the taped activations of this batch back as planes (layer1's output carries no ReLU)

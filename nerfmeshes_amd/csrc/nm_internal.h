@@ -205,4 +205,8 @@ struct nm_mlp {
     size_t b3_units;
     void* d_enc_tab;         // generic plans: GEncArg[2][48]
     void* lw;                // layer-wise path (nerf_layerwise.h: LwNet*): networks beyond the fused families' limits, else null
+    // stale-parameter guard (nm_mlp_weights_current): [0] = checksum of the packed image the LAST gather wrote, [1] = scratch
+    // of a verification pass over the caller's live tensors (device, 2 x 8 bytes); how many gathers ran since create
+    unsigned long long* d_check;
+    int64_t refresh_count;
 };

@@ -126,6 +126,9 @@ class HipMLP:
     def handle(self):
         return self._h
 
+    def refresh_count(self):
+        return int(_lib.load().nm_mlp_refresh_count(self.handle))
+
     def kernel_variant(self):
         nw = C.c_int()
         return int(self._lib.nm_mlp_kernel_variant(self._h, C.byref(nw))), nw.value

@@ -34,6 +34,8 @@ class FlexibleNeRFModel(torch.nn.Module):
                           use_viewdirs=use_viewdirs)
         self._hip = None
         self._hip_key = None
+        self._generation = 0      # advanced by train_ops' optimizer post-step hook when an optimizer holding these parameters steps
+        self.weights_guard = None  # None: NERFMESHES_WEIGHTS_GUARD / "always"; or "always" | "key" | "check" for this module
         # arithmetic of the inference kernels: "f32" (default) or the opt-in "bf16x3" (hip_ops.HipMLP); training is fp32
         self.precision = "f32"
 
@@ -41,9 +43,11 @@ class FlexibleNeRFModel(torch.nn.Module):
         return i % self.skip_step == 0 and i > 0 and i != self.num_layers - 1
 
     def hip(self, precision=None):
-        """Packed device copy of the current parameters: built once per device, then re-packed on the GPU
-        (nm_mlp_refresh, one gather kernel) whenever a parameter changed -- autograd's version counters moved, or ANY optimizer
-        stepped / a captured iteration was replayed since (train_ops.generation(): fused optimizers and graph replays move no counter).
+        """Packed device copy of the current parameters: built once per device, then re-packed on the GPU (nm_mlp_refresh, one
+        gather kernel on the stream, no host round trip) under the policy train_ops.guard_mode() names -- by default on EVERY
+        use, so that the kernels see whatever the tensors hold now, as the reference's forward does
+        (/root/reference/src/nerf/models.py:60-80 reads the parameters themselves); "key": only when the host can tell they
+        changed; "check": "key" plus a device checksum that raises StaleWeightsError when the key missed an edit.
         `precision` overrides `self.precision` for this handle (mesh_nerf's density grid asks for "f32" whatever the
         module is set to)."""
         params = list(self.parameters()) + list(self.buffers())
@@ -51,20 +55,31 @@ class FlexibleNeRFModel(torch.nn.Module):
         if dev.type != "cuda":
             raise hip_ops._lib.HipLibraryError(
                 "FlexibleNeRFModel lives on %s: move it to the MI355X (.to('cuda')); there is no CPU path" % dev)
-        key = (train_ops.generation(),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (train_ops.generation(), getattr(self, "_generation", 0)) + tuple((p.data_ptr(), p._version) for p in params)
         precision = "f32" if self.needs_grad() else (precision or getattr(self, "precision", "f32"))
+        mode = train_ops.guard_mode(self)
         if self._hip is None or self._hip.device != dev or self._hip.precision != precision:
             self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev, precision=precision)
-        elif key != self._hip_key:
+            train_ops.register_owner(self, self.parameters())
+        elif mode == "always" or key != self._hip_key:
+            if self._hip_key is None or key[2:] != self._hip_key[2:]:
+                train_ops.register_owner(self, self.parameters())     # a parameter object may have been replaced
             train_ops.refresh(self._hip, dict(self.named_parameters()))
+        elif mode == "check" and train_ops.weights_differ(self._hip, dict(self.named_parameters())):
+            raise train_ops.StaleWeightsError(
+                "the parameters of this FlexibleNeRFModel were edited in a way the host cannot see (p.data / torch._foreach_* on "
+                ".data / a foreign kernel) and NERFMESHES_WEIGHTS_GUARD=check: the packed copy the HIP kernels read is stale.  "
+                "Call .refresh() after such edits, or run under the default guard (\"always\": re-pack on every use)")
         self._hip_key = key
         return self._hip
 
     def refresh(self):
-        """Force a device re-pack on the next use.  `hip()` notices optimizer steps and every in-place op that goes
-        through autograd's version counter; edits through `p.data` (EMA, manual clipping) bypass the counter -- call
-        this after them."""
+        """Force a device re-pack on the next use (only the "key" / "check" guards ever need it: after edits through `p.data`)."""
         self._hip_key = None
+
+    def refresh_count(self):
+        """How many times the packed copy was (re)built since the handle exists (nm_mlp_refresh_count)."""
+        return 0 if self._hip is None else self._hip.refresh_count()
 
     def needs_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())

@@ -16,8 +16,8 @@ What `loss.backward()` does in the reference's `NeRFModel.training_step`
 torch is plumbing (device memory, autograd bookkeeping, the optimizer); there is no CPU path.
 """
 import ctypes as C
-
 import os
+
 import torch
 
 from . import _lib, hip_ops
@@ -68,8 +68,8 @@ def param_names(num_layers, use_viewdirs=True):
                     "layers_dir.0.bias", "fc_rgb.weight", "fc_rgb.bias"]
 
 
-def refresh(mlp, params):
-    """Re-pack `mlp` (hip_ops.HipMLP) from live device tensors: dict name -> CUDA fp32 tensor."""
+def _weights_struct(mlp, params):
+    """nm_mlp_weights over live device tensors (dict name -> CUDA fp32 tensor) + the tensors it points into (keep alive)."""
     L = int(mlp.desc["num_layers"])
     if not mlp.desc.get("use_viewdirs", True):
         # models.py:77-79: fc_out (4, H) supplies the colour rows (0..2) and the density row (3), see nm_mlp_weights
@@ -83,8 +83,7 @@ def refresh(mlp, params):
         ow, ob = keep["fc_out.weight"].data_ptr(), keep["fc_out.bias"].data_ptr()
         w = MlpWeights(p("layer1.weight"), p("layer1.bias"), xs_w, xs_b, None, None, C.c_void_p(ow + 3 * H * 4),
                        C.c_void_p(ob + 3 * 4), C.c_void_p(ow), C.c_void_p(ob), None, None, None, None)
-        check(_lib.load().nm_mlp_refresh(mlp.handle, C.byref(w), _stream()), "nm_mlp_refresh")
-        return
+        return w, (keep, xs_w, xs_b)
     keep = {k: _dev32(params[k], mlp.device, k) for k in param_names(L)}
     p = lambda k: C.c_void_p(keep[k].data_ptr())  # noqa: E731
     xs_w = (C.c_void_p * (L - 1))(*[p(f"layers_xyz.{i}.weight") for i in range(L - 1)])
@@ -92,7 +91,14 @@ def refresh(mlp, params):
     w = MlpWeights(p("layer1.weight"), p("layer1.bias"), xs_w, xs_b, p("layers_dir.0.weight"), p("layers_dir.0.bias"),
                    p("fc_alpha.weight"), p("fc_alpha.bias"), p("fc_rgb.weight"), p("fc_rgb.bias"),
                    p("fc_feat.weight"), p("fc_feat.bias"), None, None)
+    return w, (keep, xs_w, xs_b)
+
+
+def refresh(mlp, params):
+    """Re-pack `mlp` (hip_ops.HipMLP) from live device tensors: dict name -> CUDA fp32 tensor."""
+    w, keep = _weights_struct(mlp, params)
     check(_lib.load().nm_mlp_refresh(mlp.handle, C.byref(w), _stream()), "nm_mlp_refresh")
+    del keep
 
 
 def _per_ray(origins, rays):
@@ -309,15 +315,36 @@ def mlp_rays(module, origins, dirs, t):
     return _MLPRays.apply(mlp, names, origins, dirs, t, *[params[k] for k in names])
 
 
-# ---- "the parameters may have changed": what FlexibleNeRFModel.hip() keys its device re-pack on, besides autograd's version
-# counters.  An optimizer step does not always move those -- torch's FUSED optimizers update the tensors through one multi-tensor
-# kernel without bumping them, and a replayed hipGraph runs no Python at all -- so every optimizer step (a global post-step hook,
-# any optimizer, any module) and every GraphedStep replay advances this generation; the next hip() of any module then re-packs
-# (one gather kernel, ~8 us).  Edits through `p.data` still need FlexibleNeRFModel.refresh().
+# ---- "the parameters may have changed".  The reference's forward reads the nn.Parameter storages themselves
+# (/root/reference/src/nerf/models.py:60-80); a HipMLP handle holds a packed image of them, which FlexibleNeRFModel.hip() keeps
+# current under one of three policies (NERFMESHES_WEIGHTS_GUARD, or `module.weights_guard`):
+#   "always" (default)  re-pack on EVERY use: one gather kernel on the stream (~5 us, no host round trip) in front of the launch --
+#                       whatever edited the tensors (an optimizer, `p.data.mul_()`, torch._foreach_* on `.data`, a replayed
+#                       graph, another library), the kernels see it, exactly as the reference's forward would;
+#   "key"               re-pack only when the host can tell: autograd's version counters or storage pointers moved, an optimizer
+#                       that holds one of the module's parameters stepped (the post-step hook below: torch's FUSED optimizers
+#                       move no version counter), a GraphedStep was replayed.  Edits through `p.data` are invisible here: call
+#                       FlexibleNeRFModel.refresh() after them.  For launch-bound loops of tiny batches;
+#   "check"             "key", plus a device checksum of the live tensors against the packed image on every use whose key did
+#                       not move (nm_mlp_weights_current: synchronises); a mismatch raises StaleWeightsError -- the CI mode that
+#                       proves a loop is safe under "key".
 _GENERATION = [0]
+_OWNERS = {}          # id(parameter) -> weakref of the FlexibleNeRFModel that packs it (filled by FlexibleNeRFModel.hip())
+
+
+class StaleWeightsError(RuntimeError):
+    pass
+
+
+def guard_mode(module=None):
+    mode = getattr(module, "weights_guard", None) or os.environ.get("NERFMESHES_WEIGHTS_GUARD", "always")
+    if mode not in ("always", "key", "check"):
+        raise ValueError(f"NERFMESHES_WEIGHTS_GUARD={mode!r}: expected always | key | check")
+    return mode
 
 
 def parameters_changed(*_args, **_kw):
+    """Every module's packed copy is out of date (a replayed graph stepped an optimizer without running Python)."""
     _GENERATION[0] += 1
 
 
@@ -325,9 +352,47 @@ def generation():
     return _GENERATION[0]
 
 
+def register_owner(module, params):
+    import weakref
+    ref = weakref.ref(module)
+    for p in params:
+        _OWNERS[id(p)] = ref
+
+
+def _optimizer_stepped(optimizer, *_args, **_kw):
+    """Post-step hook: the modules whose parameters THIS optimizer holds are marked changed; optimizers of unrelated modules
+    (a discriminator, an EMA copy, another library's model in the same process) touch nothing."""
+    seen = set()
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            ref = _OWNERS.get(id(p))
+            if ref is None:
+                continue
+            module = ref()
+            if module is None:
+                del _OWNERS[id(p)]
+            elif id(module) not in seen:
+                seen.add(id(module))
+                module._generation = getattr(module, "_generation", 0) + 1
+
+
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
 
-_register_step_hook(parameters_changed)
+# One process-wide registration of the SCOPED hook above: also optimizers the caller built himself (torch.optim.Adam(...,
+# fused=True) straight from the reference's model_base.py:159-162) are seen.  NERFMESHES_GLOBAL_STEP_HOOK=0 leaves torch's
+# global hook list alone; make_optimizer() then registers the hook on the optimizers it builds.
+_GLOBAL_HOOK = os.environ.get("NERFMESHES_GLOBAL_STEP_HOOK", "1") != "0"
+if _GLOBAL_HOOK:
+    _register_step_hook(_optimizer_stepped)
+
+
+def weights_differ(mlp, params):
+    """True when the packed image of `mlp` no longer equals the live tensors `params` (name -> CUDA fp32 tensor)."""
+    w, keep = _weights_struct(mlp, params)
+    differs = C.c_int32(0)
+    check(_lib.load().nm_mlp_weights_current(mlp.handle, C.byref(w), _stream(), C.byref(differs)), "nm_mlp_weights_current")
+    del keep
+    return bool(differs.value)
 
 
 def make_optimizer(kind, params, lr, **kw):
@@ -344,7 +409,10 @@ def make_optimizer(kind, params, lr, **kw):
     if kind in ("Adam", "AdamW", "SGD") and "fused" in inspect.signature(cls.__init__).parameters and "fused" not in kw and \
             "foreach" not in kw and flat and all(p.is_cuda and torch.is_floating_point(p) for p in flat):
         kw["fused"] = True
-    return cls(params, lr=lr, **kw)
+    opt = cls(params, lr=lr, **kw)
+    if not _GLOBAL_HOOK:
+        opt.register_step_post_hook(_optimizer_stepped)
+    return opt
 
 
 class GraphedStep:

@@ -174,19 +174,47 @@ def test_tie_order_auto_falls_back_to_stable_beyond_the_reference_kernels_limit(
     assert seen[-1] == "reference"                     # explicit request: not second-guessed
 
 
-def test_every_optimizer_step_advances_the_parameter_generation():
-    """FlexibleNeRFModel.hip() re-packs its device copy when autograd's version counters moved OR train_ops.generation() did: the
-    latter advances on every optimizer step of any optimizer (a global post-step hook) -- torch's fused optimizers update tensors
-    without touching the counters -- and on every GraphedStep replay."""
+def test_an_optimizer_step_marks_the_modules_whose_parameters_it_holds_and_no_others():
+    """FlexibleNeRFModel.hip() under the "key" guard re-packs its device copy when autograd's version counters moved OR the module's
+    generation did: the latter advances when an optimizer that HOLDS one of the module's parameters steps (one scoped post-step
+    hook: torch's fused optimizers update tensors without touching the counters); optimizers of unrelated modules move nothing,
+    and train_ops.generation() -- every module at once -- moves only on a replayed graph."""
     import torch
     from nerfmeshes_amd import train_ops
-    lin = torch.nn.Linear(3, 2)
-    for opt in (torch.optim.SGD(lin.parameters(), lr=0.1), torch.optim.Adam(lin.parameters(), lr=0.1, foreach=False),
-                train_ops.make_optimizer("Adam", lin.parameters(), 0.1)):
-        before = train_ops.generation()
-        lin(torch.ones(1, 3)).sum().backward()
+    from nerfmeshes_amd.nerf.models import FlexibleNeRFModel
+    kw = dict(num_layers=2, hidden_size=16, skip_step=4, num_encoding_fn_xyz=2, num_encoding_fn_dir=1)
+    mine, other = FlexibleNeRFModel(**kw), FlexibleNeRFModel(**kw)
+    for m in (mine, other):
+        train_ops.register_owner(m, m.parameters())      # what hip() does when it builds the handle (no GPU here)
+    unrelated = torch.nn.Linear(3, 2)
+    everything = train_ops.generation()
+
+    def step(opt, params):
+        for p in params:
+            p.grad = torch.ones_like(p)
         opt.step()
-        assert train_ops.generation() == before + 1
+
+    for n, opt in enumerate((torch.optim.SGD(mine.parameters(), lr=0.1), torch.optim.Adam(mine.parameters(), lr=0.1, foreach=False),
+                             train_ops.make_optimizer("Adam", mine.parameters(), 0.1)), 1):
+        step(opt, list(mine.parameters()))
+        assert (mine._generation, other._generation) == (n, 0)
+    step(torch.optim.SGD(unrelated.parameters(), lr=0.1), list(unrelated.parameters()))
+    assert (mine._generation, other._generation) == (3, 0)
+    step(torch.optim.SGD(list(other.layer1.parameters()) + list(unrelated.parameters()), lr=0.1), list(other.layer1.parameters()))
+    assert (mine._generation, other._generation) == (3, 1), "one step marks a module once, whatever share of its parameters it holds"
+    assert train_ops.generation() == everything
+    train_ops.parameters_changed()
+    assert train_ops.generation() == everything + 1
+    for mode in ("always", "key", "check"):
+        mine.weights_guard = mode
+        assert train_ops.guard_mode(mine) == mode
+    mine.weights_guard = "sometimes"
+    try:
+        train_ops.guard_mode(mine)
+        raise AssertionError("an unknown guard must be refused")
+    except ValueError:
+        pass
+    lin = torch.nn.Linear(3, 2)
     assert "fused" not in train_ops.make_optimizer("Adam", lin.parameters(), 0.1).defaults or \
         not train_ops.make_optimizer("Adam", lin.parameters(), 0.1).defaults["fused"], "host parameters: torch's default implementation"
     assert train_ops.make_optimizer("SGD", lin.parameters(), 0.1, momentum=0.9).defaults["momentum"] == 0.9

@@ -307,6 +307,116 @@ def test_adam_steps_reduce_the_loss_and_eval_follows_the_new_weights(adam):
     assert torch.equal(got, want)
 
 
+def _render_after(model, batch, edit):
+    """(rgb rendered after `edit`, rgb of a model rebuilt from the edited state_dict, re-packs the edit's render cost)."""
+    model.eval()
+    with torch.no_grad():
+        model.query(batch)                        # the handles exist and hold the un-edited parameters
+        before = model.model_fine.refresh_count()
+        edit(model)
+        got = model.query(batch).rgb_map
+        packs = model.model_fine.refresh_count() - before
+        fresh = _model(model._test_hp, seed=99)
+        fresh.load_state_dict(model.state_dict())
+        fresh.eval()
+        want = fresh.query(batch).rgb_map
+    return got, want, packs
+
+
+def _scale_data(model):                           # invisible to autograd's version counters and to every optimizer hook
+    for p in model.parameters():
+        p.data.mul_(1.25)
+
+
+def _foreach_data(model):
+    torch._foreach_add_([p.data for p in model.parameters()], 0.01)
+
+
+@pytest.mark.parametrize("edit", [_scale_data, _foreach_data], ids=["p.data.mul_", "_foreach_add_ on .data"])
+def test_edits_the_host_cannot_see_reach_the_kernels_or_raise(edit, monkeypatch):
+    """VERDICT r5 weak 3.  The reference's forward reads the nn.Parameter storages (models.py:60-80), so an edit through `p.data` or
+    a torch._foreach_* op on `.data` is simply seen by the next forward.  Here the kernels read a packed copy:
+      * default guard ("always"): the copy is rebuilt on the stream in front of every use -- the render equals a model rebuilt
+        from the edited state_dict bit for bit;
+      * "check": the version-key says "unchanged", the device checksum disagrees -> StaleWeightsError (loud), and after
+        .refresh() the render is right;
+      * "key" (opt-in, documented hazard): the stale copy renders -- what the default used to do silently."""
+    from nerfmeshes_amd import train_ops
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw)
+    o, d, _ = _rays(256, 2, 4)
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+    monkeypatch.delenv("NERFMESHES_WEIGHTS_GUARD", raising=False)
+
+    model = _model(hp, seed=3)
+    model._test_hp = hp
+    got, want, packs = _render_after(model, batch, edit)
+    assert torch.equal(got, want) and packs == 1
+
+    monkeypatch.setenv("NERFMESHES_WEIGHTS_GUARD", "check")
+    model = _model(hp, seed=3)
+    model._test_hp = hp
+    with pytest.raises(train_ops.StaleWeightsError, match="stale"):
+        _render_after(model, batch, edit)
+    for net in (model.model_coarse, model.model_fine):
+        net.refresh()
+    with torch.no_grad():
+        again = model.query(batch).rgb_map
+        assert model.query(batch).rgb_map.equal(again)            # unchanged parameters: the checksum agrees, nothing raises
+    fresh = _model(hp, seed=99)
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        assert torch.equal(again, fresh.query(batch).rgb_map)
+
+    monkeypatch.setenv("NERFMESHES_WEIGHTS_GUARD", "key")
+    model = _model(hp, seed=3)
+    model._test_hp = hp
+    got, want, packs = _render_after(model, batch, edit)
+    assert packs == 0 and not torch.equal(got, want), "the key guard re-packs only on what the host can see"
+
+
+def test_the_key_guard_repacks_once_per_visible_change_and_never_otherwise(monkeypatch):
+    """Under NERFMESHES_WEIGHTS_GUARD=key a render loop over unchanged parameters re-packs nothing; an in-place op autograd sees,
+    an optimizer step (fused Adam moves no version counter: the scoped post-step hook) and load_state_dict each cost exactly one
+    re-pack on the next use."""
+    from nerfmeshes_amd import train_ops
+    monkeypatch.setenv("NERFMESHES_WEIGHTS_GUARD", "key")
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw)
+    model = _model(hp, seed=3)
+    o, d, _ = _rays(256, 2, 4)
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+    model.eval()
+    net = model.model_fine
+    with torch.no_grad():
+        model.query(batch)
+        n0 = net.refresh_count()
+        for _ in range(5):
+            model.query(batch)
+        assert net.refresh_count() == n0
+        net.fc_alpha.weight.mul_(1.5)
+        model.query(batch); model.query(batch)
+        assert net.refresh_count() == n0 + 1
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(state)
+        model.query(batch); model.query(batch)
+        assert net.refresh_count() == n0 + 2
+    opt = train_ops.make_optimizer("Adam", model.parameters(), 1e-3)
+    assert opt.defaults.get("fused")
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    other = torch.optim.SGD(torch.nn.Linear(2, 2).cuda().parameters(), lr=0.1)      # somebody else's optimizer: not this module's business
+    for g in other.param_groups:
+        for p in g["params"]:
+            p.grad = torch.zeros_like(p)
+    other.step()
+    with torch.no_grad():
+        model.query(batch); model.query(batch)
+    assert net.refresh_count() == n0 + 3
+
+
 @pytest.mark.parametrize("kw", [dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
                                 dict(num_layers=3, hidden_size=100, skip_step=2, num_encoding_fn_xyz=5, num_encoding_fn_dir=2)],
                          ids=["tuned-4x64", "generic-3x100"])
@@ -619,7 +729,10 @@ def test_general_head_grad_kernel_vs_fp64(n, k, ld, monkeypatch):
 
 
 @pytest.mark.parametrize("out_f,in_f,jobs,n,general", [(256, 256, 8, 4096, False), (256, 256, 8, 4096, True), (128, 128, 3, 1040, False),
-                                                       (100, 100, 5, 583, True), (320, 320, 16, 2000, True), (64, 39, 2, 37, True)])
+                                                       (100, 100, 5, 583, True), (320, 320, 16, 2000, True), (64, 39, 2, 37, True),
+                                                       # more products than the one-product workspace holds sample parts for (8 x 8 output
+                                                       # blocks: 4 parts on 256 CUs): issued as sub-batches
+                                                       (2048, 2048, 8, 40, True), (1280, 1280, 16, 24, True)])
 def test_weight_grad_batch_vs_fp64(out_f, in_f, jobs, n, general, monkeypatch):
     """nm_weight_grad_batch: the same-shape layers of a network in ONE launch + one reduction (a job gets 1 / jobs of the CUs) --
     every job against delta^T @ act in fp64, tuned and general kernel, ragged row counts, a shared output with column windows."""
@@ -641,9 +754,20 @@ def test_weight_grad_batch_vs_fp64(out_f, in_f, jobs, n, general, monkeypatch):
         db = torch.empty(out_f, device="cuda") if j % 2 == 0 else None
         todo.append((deltas[j].cuda().contiguous(), buf[:, :in_f], in_f, out, 7 if j == 0 else 0, db))
         outs.append((out[:, 7:] if j == 0 else out, db))
+    # the workspace is exactly what nm_weight_grad_workspace_bytes_ex asked for, followed by a canary the kernels must not touch
+    canaries = []
+
+    def guarded_workspace(mlp_, tag, need):
+        ws = torch.empty(need + 4096, dtype=torch.uint8, device="cuda")
+        ws[need:] = 0xA5
+        canaries.append(ws[need:])
+        return ws[:need]
+
+    monkeypatch.setattr(T, "_workspace", guarded_workspace)
     T._weight_grad_batch(mlp, todo)
     first = [(o.clone(), None if b is None else b.clone()) for o, b in outs]
     T._weight_grad_batch(mlp, todo)
+    assert canaries and all(bool((c == 0xA5).all()) for c in canaries), "a weight-gradient launch wrote past its workspace"
     for j, ((o, b), (o1, b1)) in enumerate(zip(outs, first)):
         ref = deltas[j].double().t() @ acts[j].double()
         scale = float(ref.abs().max()) + 1e-30
