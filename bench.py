@@ -47,7 +47,7 @@ from benchlib.guard import PORT_OVER_REFERENCE_TIME, _Emergency, _annotate_ports
 from benchlib.line import render as render_line, write_full  # noqa: E402
 from benchlib.mesh import mesh_probe  # noqa: E402
 from benchlib.scenes import b3_probe, buff_probe, eval_probe, tiny_probe  # noqa: E402
-from benchlib.train import train_probe  # noqa: E402
+from benchlib.train import shapes_probe, train_probe  # noqa: E402
 
 
 def main():
@@ -287,7 +287,8 @@ def main():
     # ... and single-GPU objects
     for name, skip, fn in (("eval", args.no_eval_probe, lambda: eval_probe(dev, weights, views=args.eval_views, cpu_legs=cpu_legs)),
                            ("tiny", args.no_tiny_probe, lambda: tiny_probe(dev, cpu_legs)),
-                           ("train", args.no_train_probe, lambda: train_probe(dev, views[0][1], views[0][0], cpu_legs=cpu_legs)),
+                           ("train", args.no_train_probe, lambda: dict(train_probe(dev, views[0][1], views[0][0], cpu_legs=cpu_legs),
+                                                                       shapes=shapes_probe(dev))),
                            ("bf16x3", args.no_b3_probe,
                             lambda: b3_probe(dev, weights, views, near, far, u_c, u_f, args.chunk, ref_idx, ref_rgb))):
         if solo and not skip:

@@ -27,7 +27,9 @@ def _pick(obj, *keys):
 
 def _frac(obj):
     roof = obj.get("roofline") if isinstance(obj, dict) else None
-    return {"frac": _sig(roof["frac"]), "bound": roof.get("bound")} if isinstance(roof, dict) and "frac" in roof else {}
+    if not isinstance(roof, dict) or "frac" not in roof:
+        return {}
+    return {"frac": _sig(roof["frac"]), **({"bound": roof.get("bound")} if roof.get("bound") != "mfma" else {})}   # mfma unless it says so
 
 
 def _small(obj, *keys):
@@ -41,11 +43,19 @@ def _small(obj, *keys):
     out.update(_frac(obj))
     par = obj.get("parity")
     if isinstance(par, dict):
-        out.update(_pick(par, "abs_dpsnr_db", "max_abs_drgb", "rays_over_1e-4"))
+        out.update(_pick(par, "abs_dpsnr_db", "rays_over_1e-4"))
     cpu = obj.get("cpu_baseline")
     if isinstance(cpu, dict) and "value" in cpu:
-        out["cpu"] = _pick(cpu, "value", "unit", "cores", "kind")
+        out["cpu"] = _cpu(cpu, out.get("unit"))
     return out
+
+
+def _cpu(cpu, unit=None):
+    """A secondary CPU leg on the line: rate and threads (its unit only where it is not the object's own; kind / sample: full file)."""
+    c = _pick(cpu, "value", "cores")
+    if cpu.get("unit") != unit:
+        c["unit"] = cpu.get("unit")
+    return c
 
 
 def _mesh(m):
@@ -59,7 +69,7 @@ def _mesh(m):
         if isinstance(gq.get("parity"), dict):
             g.update(_pick(gq["parity"], "max_abs_dsigma_over_scale"))
         if isinstance(gq.get("cpu_baseline"), dict):
-            g["cpu"] = _pick(gq["cpu_baseline"], "value", "unit", "cores", "kind")
+            g["cpu"] = _cpu(gq["cpu_baseline"])
         if isinstance(gq.get("at_reference_batch_1024"), dict):
             g["at_reference_batch_1024"] = _pick(gq["at_reference_batch_1024"], "value", "unit", "calls", "ms_per_call", "full_grid_s",
                                                  "same_sigma_as_one_call")
@@ -69,21 +79,30 @@ def _mesh(m):
         out["grid_query"] = g
     mc = m.get("marching_cubes")
     if isinstance(mc, dict):
-        c = _pick(mc, "vertices", "faces", "ms_avg", "iso_equals_numpy_fp32", "bitwise_identical_to_oracle")
+        c = _pick(mc, "vertices", "faces", "ms_avg")
+        c.update({short: mc[k] for k, short in (("iso_equals_numpy_fp32", "iso_np_exact"), ("bitwise_identical_to_oracle", "bitwise")) if k in mc})
         c.update(_frac(mc))
         if isinstance(mc.get("roofline"), dict):
             c.update(_pick(mc["roofline"], "traffic"))
         if isinstance(mc.get("cpu_baseline"), dict):
-            c["cpu"] = _pick(mc["cpu_baseline"], "value", "unit", "cores", "kind")
+            c["cpu"] = _cpu(mc["cpu_baseline"])
         out["marching_cubes"] = c
     app = m.get("appearance")
     if isinstance(app, dict):
-        out["appearance"] = {k: _pick(v, "end_to_end_s", "requery_rays_per_s", "requery_frac", "obj_GBps", "obj_identical_to_oracle_writer")
-                             for k, v in app.items() if isinstance(v, dict)}
+        out["appearance"] = {}
+        for k, v in app.items():
+            if isinstance(v, dict):
+                a = _pick(v, "end_to_end_s", "requery_rays_per_s", "obj_MBps")
+                a.update(_frac(v))
+                if isinstance(v.get("parity"), dict):
+                    a.update(_pick(v["parity"], "abs_dpsnr_db"))
+                out["appearance"][k] = a
     par = m.get("parity")
     if isinstance(par, dict) and isinstance(par.get("topology"), dict):
-        out["topology_end_to_end_128"] = _pick(par["topology"], "iso_equal", "cut_cubes", "cut_cubes_differ", "sign_flips", "d_vertices",
-                                               "d_faces")
+        topo = par["topology"]
+        out["topology_128"] = {short: topo[k] for k, short in (("sign_flips_at_iso", "sign_flips"), ("cubes_cut_by_the_surface", "cut_cubes"),
+                                                                 ("cubes_whose_corner_pattern_differs", "differ"), ("abs_dV", "dV"),
+                                                                 ("abs_dF", "dF"), ("within_budget", "ok")) if k in topo}
     return out
 
 
@@ -92,7 +111,7 @@ def _train(t):
         return _small(t)
     out = _small(t, "ms_per_iteration", "rays_per_iteration")
     if isinstance(t.get("kernels"), dict):
-        out["stages"] = {k: _pick(v, "ms", "frac") for k, v in t["kernels"].items() if isinstance(v, dict)}
+        out["stages"] = {k: _pick(v, "ms", "frac") for k, v in t["kernels"].items() if isinstance(v, dict) and v.get("ms", 0) >= 0.1}
     if isinstance(t.get("shapes"), dict):
         out["shapes"] = {k: _pick(v, "ms_per_iteration", "frac", "ms_graph_replay", "frac_graph_replay") for k, v in t["shapes"].items()
                          if isinstance(v, dict)}
@@ -106,18 +125,17 @@ def compact_line(out, full_path=None):
         line["config"] = dict(line["config"])
     roof = out.get("roofline")
     if isinstance(roof, dict):
-        line["roofline"] = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms",
-                                 "algorithmic_flops_per_ray", "mlp_kernel_share_of_wall")
+        line["roofline"] = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms")
         line["roofline"].setdefault("traffic", None)
         if roof.get("traffic_source"):
             line["roofline"]["traffic_source"] = str(roof["traffic_source"]).split(":")[0]
     cpu = out.get("cpu_baseline")
     if isinstance(cpu, dict):
-        line["cpu_baseline"] = _pick(cpu, "value", "unit", "cores", "host_cores", "kind", "speedup", "port_over_reference_time")
-        line["cpu_baseline"]["sample"] = str(cpu.get("sample", ""))[:160]
+        line["cpu_baseline"] = _pick(cpu, "value", "unit", "cores", "kind", "speedup", "port_over_reference_time")
+        line["cpu_baseline"]["sample"] = str(cpu.get("sample", ""))[:110]
     par = out.get("parity")
     if isinstance(par, dict):
-        line["parity"] = _pick(par, "psnr_ref_db", "psnr_hip_db", "abs_dpsnr_db", "max_abs_drgb", "rays", "rays_over_1e-4")
+        line["parity"] = _pick(par, "psnr_ref_db", "abs_dpsnr_db", "max_abs_drgb", "rays", "rays_over_1e-4")
         if isinstance(par.get("rays_over_1e-4_explained"), dict):
             line["parity"]["unexplained"] = par["rays_over_1e-4_explained"].get("unexplained")
     for k in ("ranks_per_gpu", "note", "errors"):

@@ -118,14 +118,27 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
     return out
 
 
-def tiny_train_probe(dev, rays=8192, iters=40):
-    """Config 1's training iteration (4x64, 32 coarse samples, no fine network; perturb + noise, MSE, backward through the HIP
-    kernels, Adam) -- about forty launches of a few tens of microseconds: launched eagerly, and replayed from one captured hipGraph
-    (train_ops.GraphedStep; the same kernels: tests/test_gpu_train.py::test_training_iteration_replays_from_a_hipgraph)."""
+def train_flops_per_sample(kw):
+    """(forward, delta, weight-gradient) algorithmic FLOP per sample of a view-dependent FlexibleNeRFModel (weights only, as SURVEY
+    8(d): /root/reference/src/nerf/models.py:5-58 lists the layers)."""
+    Hh, L, ss = kw["hidden_size"], kw["num_layers"], kw["skip_step"]
+    dx, dd = 6 * kw["num_encoding_fn_xyz"] + 3, 6 * kw["num_encoding_fn_dir"] + 3
+    nskip = sum(1 for i in range(L - 1) if i % ss == 0 and i > 0 and i != L - 1)
+    fwd = dx * Hh + (L - 1) * Hh * Hh + nskip * dx * Hh + Hh * Hh + Hh + (Hh + dd) * (Hh // 2) + 3 * (Hh // 2)
+    delta = (L - 1) * Hh * Hh + Hh * Hh + Hh * (Hh // 2)
+    return 2 * fwd, 2 * delta, 2 * fwd
+
+
+def shape_train_probe(dev, name, over, rays, iters=20, replay=True):
+    """One training iteration (perturb + noise, MSE per network, backward through the HIP kernels, fused Adam) of a network shape
+    other than the headline's: eager, and replayed from one captured hipGraph (train_ops.GraphedStep) -- the whole iteration's
+    algorithmic fp32 matrix work over its wall time against the fp32 MFMA peak."""
     from nerfmeshes_amd import models, train_ops
     from nerfmeshes_amd.nerf import CfgNode
-    hp = S.hparams(train_perturb=True, train_noise_std=0.2, hidden_size=64, num_layers=4, skip_step=2, num_encoding_fn_xyz=6,
-                   num_encoding_fn_dir=4, num_coarse=32, num_fine=0, use_fine=False)
+    kw = dict(hidden_size=256, num_layers=8, skip_step=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4, num_coarse=64, num_fine=128,
+              use_fine=True)
+    kw.update(over)
+    hp = S.hparams(train_perturb=True, train_noise_std=0.2, **kw)
     g = torch.Generator().manual_seed(1)
     dirs = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1).to(dev)
     batch = (torch.tensor([[0.0, 0.0, 4.0]], device=dev), dirs, torch.tensor([NEAR, FAR]))
@@ -140,8 +153,11 @@ def tiny_train_probe(dev, rays=8192, iters=40):
         def iteration():
             opt.zero_grad(set_to_none=True)
             out = model(batch)
-            c = out[0] if isinstance(out, tuple) else out
-            torch.nn.functional.mse_loss(c.rgb_map, target).backward()
+            c, f = out if isinstance(out, tuple) else (out, None)
+            loss = torch.nn.functional.mse_loss(c.rgb_map, target)
+            if f is not None:
+                loss = loss + torch.nn.functional.mse_loss(f.rgb_map, target)
+            loss.backward()
             opt.step()
         return iteration
 
@@ -155,8 +171,36 @@ def tiny_train_probe(dev, rays=8192, iters=40):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
 
+    samples = rays * (kw["num_coarse"] + (kw["num_coarse"] + kw["num_fine"] if kw["use_fine"] else 0))
+    flops = samples * sum(train_flops_per_sample(kw))
+    frac = lambda ms: flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS  # noqa: E731
     eager = timed(build())
-    replay = timed(train_ops.GraphedStep(build(capturable=True)))
-    return {"workload": f"config 1 training iteration: 4x64, {rays} rays x 32 samples, perturb + noise, fused Adam",
-            "ms_per_iteration_eager": eager, "ms_per_iteration_graph_replay": replay, "rays_per_s_graph_replay": rays / replay * 1e3,
+    out = {"workload": f"{name}: {rays} rays x {samples // rays} samples, perturb + noise, fused Adam", "rays": rays,
+           "samples_per_iteration": samples, "ms_per_iteration": eager, "frac": frac(eager),
+           "floor_ms_at_peak": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3}
+    if replay:
+        ms = timed(train_ops.GraphedStep(build(capturable=True)))
+        out.update(ms_graph_replay=ms, frac_graph_replay=frac(ms), rays_per_s_graph_replay=rays / ms * 1e3)
+    return out
+
+
+TINY_TRAIN = dict(hidden_size=64, num_layers=4, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4, num_coarse=32, num_fine=0,
+                  use_fine=False)
+
+
+def tiny_train_probe(dev, rays=8192, iters=40):
+    """Config 1's training iteration (4x64, 32 coarse samples, no fine network; perturb + noise, MSE, backward through the HIP
+    kernels, Adam) -- about forty launches of a few tens of microseconds: launched eagerly, and replayed from one captured hipGraph
+    (train_ops.GraphedStep; the same kernels: tests/test_gpu_train.py::test_training_iteration_replays_from_a_hipgraph)."""
+    r = shape_train_probe(dev, "config 1 training iteration: 4x64", TINY_TRAIN, rays, iters)
+    return {"workload": r["workload"], "ms_per_iteration_eager": r["ms_per_iteration"], "frac_eager": r["frac"],
+            "ms_per_iteration_graph_replay": r["ms_graph_replay"], "frac_graph_replay": r["frac_graph_replay"],
+            "rays_per_s_graph_replay": r["rays_per_s_graph_replay"], "floor_ms_at_peak": r["floor_ms_at_peak"],
             "note": "launch-bound: one captured hipGraph replaces ~40 launches per iteration (train_ops.GraphedStep)"}
+
+
+def shapes_probe(dev):
+    """The shipped configs' OTHER network shapes through a whole training iteration: nerf-colmap-fern's 8x128
+    (/root/reference/config/nerf-colmap-fern.yml:115,152) and the 64-wide family of BASELINE config 1."""
+    return {"8x128": shape_train_probe(dev, "8x128 coarse+fine", dict(hidden_size=128), 2048),
+            "8x64": shape_train_probe(dev, "8x64 coarse+fine", dict(hidden_size=64), 2048)}

@@ -23,6 +23,8 @@
 //
 // Roofline: MFMA (2 * out * in FLOP per sample); HBM traffic 4 * (out + in) B per sample = 64 FLOP/B for 256 x 256,
 // i.e. 2.4 TB/s at the fp32 MFMA peak -- the two operand streams are read exactly once.
+#include <cstdlib>
+
 #include "nm_internal.h"
 #include "mlp_device.h"
 
@@ -46,23 +48,28 @@ struct DwBatch {
     int32_t jobs, per_job;
 };
 
-constexpr int DW_ROWS = 16;  // samples per chunk (4 k-groups of 4)
+constexpr int DW_ROWS = 16;  // samples per chunk of the base geometry (4 k-groups of 4)
 
-template <int AB, int BB>
+// ROWS: samples per chunk.  16 for the 256-wide products (32 KiB per chunk).  The narrower ones take 32: a chunk is what ONE
+// barrier interval computes on, and the DMA of chunk c + 2 has two such intervals to land -- at 16 rows of a 128 x 128 product
+// that is 2 x 0.85 us, less than the HBM latency under load (measured: tests/tools/probes/dma_ring.hip, 3-slot vs 4-slot leads);
+// 32 rows double the lead at the same bytes in flight per barrier.
+template <int AB, int BB, int ROWS = DW_ROWS>
 __global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
     const int job_i = blockIdx.x / batch.per_job;
     const int part_i = blockIdx.x - job_i * batch.per_job;
     const DwArgs args = batch.job[job_i];
     constexpr int NW = 8;
     constexpr int AW = AB * 64, BW = BB * 64;
-    constexpr int A_BYTES = DW_ROWS * AW * 4, B_BYTES = DW_ROWS * BW * 4, SLOT = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = ROWS * AW * 4, B_BYTES = ROWS * BW * 4, SLOT = A_BYTES + B_BYTES;
     constexpr int NBLK = AB * BB;
     constexpr int BPW = NBLK >= NW ? NBLK / NW : 1;       // 64 x 64 blocks per wave
     constexpr int KSPLIT = NBLK >= NW ? 1 : NW / NBLK;    // wave groups sharing a block, split over the k-groups
     static_assert(NBLK >= NW ? NBLK % NW == 0 : NW % NBLK == 0, "block / wave mapping");
-    static_assert(KSPLIT <= 4 && BPW <= 2, "unsupported shape");
+    static_assert(KSPLIT <= ROWS / 4 && BPW <= 2, "unsupported shape");
     static_assert(BPW == 1 || BB % BPW == 0, "a wave's blocks share their A block");
-    constexpr int KG = 4 / KSPLIT;                        // k-groups of a chunk this wave processes
+    static_assert(ROWS % 16 == 0, "whole k-groups for every k-split");
+    constexpr int KG = (ROWS / 4) / KSPLIT;               // k-groups of a chunk this wave processes
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
     const int b_off = A_BYTES + g * (BW * 4) + bblk0 * 256 + i * 16;
 
     constexpr int PIECES = (A_BYTES / 1024 + NW - 1) / NW + (B_BYTES / 1024 + NW - 1) / NW;   // DMA instructions per wave per chunk
-    static_assert(PIECES >= 2 && PIECES <= 4, "counted wait below");
+    static_assert(PIECES >= 2 && PIECES <= 8, "counted wait below");
     dma(c_lo, 0);
     dma(c_lo + 1, 1);
     dma(c_lo + 2, 2);
@@ -146,13 +153,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
         }
         // chunk c + 2 (issued during chunk c - 1) must have landed before anybody reads it (from the end of chunk
         // c + 1 on); chunk c + 3, issued during this chunk, may stay in flight across the barrier
-        if (c + 3 < c_hi) {
-            if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (PIECES == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (c + 3 < c_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         slot = slot1;
     }
@@ -316,13 +318,29 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
 constexpr int HEAD_MAX_PARTS = 512;
 
 struct DwPlan {
-    int ab, bb, ksplit;
+    int ab, bb, ksplit, rows;
     void (*kernel)(const DwBatch);
 };
+// per shape: the 16-row kernel (any n % 16 == 0) and, for the products narrower than 256 x 256, the 32-row one (n % 32 == 0),
+// listed first so that it is preferred
 static const DwPlan g_dw_plans[] = {
-    {4, 4, 1, &dw_kernel<4, 4>}, {4, 1, 2, &dw_kernel<4, 1>}, {2, 4, 1, &dw_kernel<2, 4>}, {2, 1, 4, &dw_kernel<2, 1>},
-    {2, 2, 2, &dw_kernel<2, 2>}, {1, 2, 4, &dw_kernel<1, 2>},
+    {4, 4, 1, 16, &dw_kernel<4, 4>},
+    {4, 1, 2, 16, &dw_kernel<4, 1>},
+    {2, 4, 1, 16, &dw_kernel<2, 4>},
+    {2, 1, 4, 32, &dw_kernel<2, 1, 32>}, {2, 1, 4, 16, &dw_kernel<2, 1>},
+    {2, 2, 2, 32, &dw_kernel<2, 2, 32>}, {2, 2, 2, 16, &dw_kernel<2, 2>},
+    {1, 2, 4, 32, &dw_kernel<1, 2, 32>}, {1, 2, 4, 16, &dw_kernel<1, 2>},
+    // 64 x 64 (the hidden layers of the 64-wide networks, BASELINE config 1): ONE 64 x 64 block, every wave the whole block on an
+    // eighth of a chunk's k-groups -- HBM-bound (16 FLOP / B), so what counts is rows in flight: 64-row chunks
+    {1, 1, 8, 64, &dw_kernel<1, 1, 64>}, {1, 1, 8, 32, &dw_kernel<1, 1, 32>},
 };
+
+static const DwPlan* pick_dw_plan(int ab, int bb, int64_t n) {
+    static const int force = getenv("NM_DW_ROWS") ? atoi(getenv("NM_DW_ROWS")) : 0;      // A/B hook of the tools: 16 | 32
+    for (const DwPlan& p : g_dw_plans)
+        if (p.ab == ab && p.bb == bb && n % p.rows == 0 && (!force || p.rows == force)) return &p;
+    return nullptr;
+}
 
 }  // namespace nm
 
@@ -349,11 +367,9 @@ int weight_grad_tuned(int device_cus, int jobs, const nm_weight_grad_job* job, i
                       int32_t in_features, int64_t n, void* d_workspace, hipStream_t stream) {
     if (n % DW_ROWS || out_features % 64 || act_stride % 64 || jobs < 1 || jobs > DW_MAX_JOBS) return -1;
     const int ab = out_features / 64, bb = act_stride / 64;
-    const DwPlan* plan = nullptr;
-    for (const DwPlan& p : g_dw_plans)
-        if (p.ab == ab && p.bb == bb) plan = &p;
+    const DwPlan* plan = pick_dw_plan(ab, bb, n);
     if (!plan) return -1;
-    const int64_t chunks = n / DW_ROWS;
+    const int64_t chunks = n / plan->rows;
     const int cus = device_cus > 0 ? device_cus : 256;
     int64_t per_job = cus / jobs;
     per_job = per_job < 1 ? 1 : (per_job > chunks ? chunks : per_job);
@@ -369,7 +385,7 @@ int weight_grad_tuned(int device_cus, int jobs, const nm_weight_grad_job* job, i
         a.partial_bias = a.partial + (int64_t)parts * out_features * act_stride;
         rb.job[j] = DwReduceJob{a.partial, a.partial_bias, job[j].d_dw, job[j].d_dbias, job[j].dw_ld, job[j].dw_col0};
     }
-    const int lds_bytes = 4 * DW_ROWS * (out_features + act_stride) * 4;
+    const int lds_bytes = 4 * plan->rows * (out_features + act_stride) * 4;
     if (int rc = ensure_dynamic_lds((const void*)plan->kernel, lds_bytes)) return rc;
     hipLaunchKernelGGL(plan->kernel, dim3((unsigned)(per_job * jobs)), dim3(512), lds_bytes, stream, batch);
     const int64_t elems = (int64_t)out_features * in_features;

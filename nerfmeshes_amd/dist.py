@@ -285,15 +285,27 @@ def marching_cubes_sharded(query_fn, n0, n1, n2, iso_fn):
     else:
         v, f, nrm, val = piece.emit(sum(nv[:rank]) - piece.ghost_vertices)       # (verts, faces, normals, values)
         payload = torch.cat([t.contiguous().view(-1).view(torch.uint8) for t in (v, nrm, val, f)])
-    sizes = [28 * a + 12 * b for a, b in zip(nv, nf)]
-    if payload.numel() != sizes[rank]:
-        raise RuntimeError(f"marching_cubes_sharded: rank {rank} emitted {payload.numel()} bytes, its counts say {sizes[rank]}")
-    flat = all_gather_rows(payload, sizes)
-    parts, lo = ([], [], [], []), 0
-    for a, b in zip(nv, nf):
+    # every rank's part ends in a 4-byte status word: a rank whose emit disagrees with the counts it announced still joins the
+    # collective (with zeros of the promised size) -- raising before it would leave the other ranks inside the all-gather for
+    # ever -- and ALL ranks raise together afterwards
+    body = [28 * a + 12 * b for a, b in zip(nv, nf)]
+    sizes = [b + 4 for b in body]
+    bad = payload.numel() != body[rank]
+    status = torch.tensor([payload.numel() if bad else -1], dtype=torch.int32, device=dev).view(torch.uint8)
+    if bad:
+        payload = torch.zeros(body[rank], dtype=torch.uint8, device=dev)
+    flat = all_gather_rows(torch.cat([payload, status]), sizes)
+    parts, lo, failed = ([], [], [], []), 0, []
+    for r, (a, b) in enumerate(zip(nv, nf)):
         for k, (n_items, dtype) in enumerate(((3 * a, torch.float32), (3 * a, torch.float32), (a, torch.float32), (3 * b, torch.int32))):
             parts[k].append(flat[lo:lo + 4 * n_items].view(dtype))
             lo += 4 * n_items
+        emitted = int(flat[lo:lo + 4].view(torch.int32).item())
+        lo += 4
+        if emitted != -1:
+            failed.append(f"rank {r} emitted {emitted} bytes, its counts say {body[r]}")
+    if failed:
+        raise RuntimeError("marching_cubes_sharded: " + "; ".join(failed))
     vertices, normals, values, faces = (torch.cat(p) for p in parts)
     return vertices.view(-1, 3), faces.view(-1, 3), normals.view(-1, 3), values, slab
 

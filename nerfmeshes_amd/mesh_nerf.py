@@ -9,6 +9,12 @@ generated in the MLP kernel from the three axis arrays), the radiance stays in H
 marching cubes runs on the GPU grid directly.  `extract_radiance` still returns the same (n0,n1,n2,4) fp32
 array for callers that want it; `extract_geometry` uses the density-only path (the colour branch of the MLP is
 skipped; sigma is bit-identical to the full evaluation).
+
+`--route script` (addition) runs the UNMODIFIED script's own call sequence over the same kernels instead -- host-built sample
+points, `batchify` at `--batch-size`, `model.sample_points` + `.cpu()` per batch, numpy's iso level,
+`skimage.measure.marching_cubes`, the per-vertex re-query in `--batch-size` calls -- i.e. INTEGRATION.md's route A without the
+reference checkout: what a maintainer gets who changes nothing (tests/test_gpu_script_traces.py compares its call trace with the
+one recorded from the reference's script; bench.py times its inner loop as `mesh.grid_query.at_reference_batch_1024`).
 """
 import argparse
 import os
@@ -56,6 +62,14 @@ def _grid_query(model, args, device, nums, density_only, shard=None):
 
 def extract_radiance(model, args, device, nums):
     """(n0,n1,n2,4) numpy fp32 [rgb, raw sigma], as mesh_nerf.py:27-53."""
+    if getattr(args, "route", "kernel") == "script":
+        # the script's own loop (mesh_nerf.py:37-51): the (N,3) sample tensor on the host, one sample_points call and one D2H
+        # copy per `--batch-size` points
+        nums = _nums(nums)
+        tiles = [torch.linspace(-args.limit, args.limit, n) for n in nums]
+        samples = torch.stack(torch.meshgrid(*tiles, indexing="ij"), -1).view(-1, 3).float()
+        parts = [model.sample_points(x, x).cpu() for (x,) in batchify(samples, batch_size=args.batch_size, device=device)]
+        return torch.cat(parts, 0).view(*nums, 4).contiguous().numpy()
     out, nums = _grid_query(model, args, device, nums, density_only=False)
     return out.view(*nums, 4).cpu().numpy()
 
@@ -122,6 +136,20 @@ def extract_geometry(model, device, args):
     `--gather grid` assembles the density grid on every rank first (extract_density) and meshes it redundantly."""
     from . import dist as nd
     rank, world = nd.world()
+    if getattr(args, "route", "kernel") == "script":
+        # mesh_nerf.py:68-92 as written: the full radiance grid on the host, numpy's statistics, scikit-image's entry point
+        # (the real package, or compat's nm_mc_* stand-in where it is not installed)
+        import numpy as np
+        try:
+            from skimage import measure
+            marching_cubes = measure.marching_cubes
+        except ImportError:
+            from .compat import marching_cubes
+        density = extract_radiance(model, args, device, args.res)[..., 3]
+        iso_value = extract_iso_level(density, args)
+        vertices, triangles, normals, _ = [torch.from_numpy(np.ascontiguousarray(r)) for r in marching_cubes(density, iso_value)]
+        vertices = args.limit * (vertices / (args.res / 2.0) - 1.0)
+        return vertices, triangles, normals, density
     if world > 1 and getattr(args, "gather", "triangles") == "triangles":
         nums = _nums(args.res)
         net = model.get_model().hip("f32")
@@ -191,7 +219,8 @@ def export_marching_cubes(model, args, cfg, device):
             if nd.world()[1] > 1 and getattr(args, "gather", "triangles") == "triangles":
                 density = _assemble_grid_from_slabs(density, _nums(args.res), device)   # the cache holds the whole grid
             if nd.world()[0] == 0:
-                torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(), density.cpu().numpy()), cache_path)
+                torch.save((vertices.cpu(), triangles.cpu(), normals.cpu(),
+                            density.cpu().numpy() if isinstance(density, torch.Tensor) else density), cache_path)
                 print(f"Cached mesh geometry saved to {cache_path}")
 
     if getattr(args, "precision", "f32") != "f32":     # the geometry above is fp32 by contract; only the colours may use the mode
@@ -206,16 +235,22 @@ def export_marching_cubes(model, args, cfg, device):
     # --batch-size bounds the reference's per-call memory (default 1024); on a 288 GB device the per-call overhead
     # of a 1024-ray launch sequence dominates, so at least 65 536 vertices go into one call
     chunk = max(int(args.batch_size), 65536)
+    script = getattr(args, "route", "kernel") == "script"
+    if script:
+        if world > 1:
+            raise ValueError("--route script is the unmodified script's single-process call sequence: run it on one rank")
+        chunk = int(args.batch_size)                       # the script's calls as they are (mesh_nerf.py:172-191), D2H per batch
+    keep = (lambda t: t.cpu()) if script else (lambda t: t)
     if args.no_view_dependence:
         print("Diffuse map query directly  without specific-views...")
         for pos, dirs in batchify(targets, directions, batch_size=chunk, device=device, progress=False):
-            diffuse.append(model.sample_points(pos, dirs)[..., :3])
+            diffuse.append(keep(model.sample_points(pos, dirs)[..., :3]))
     else:
         print("Diffuse map query with view dependence...")
         ray_bounds = torch.tensor([0.0, args.view_disparity_max_bound], dtype=directions.dtype)
         ray_origins = targets - args.view_disparity * directions
         for o, d in batchify(ray_origins, directions, batch_size=chunk, device=device, progress=False):
-            diffuse.append(model.query((o, d, ray_bounds)).rgb_map)
+            diffuse.append(keep(model.query((o, d, ray_bounds)).rgb_map))
     diffuse = torch.cat(diffuse, dim=0) if diffuse else torch.empty(0, 3, dtype=torch.float32, device=device)
     diffuse = nd.all_gather_rows(diffuse.contiguous(), counts).cpu().numpy()
     if getattr(args, "precision", "f32") != "f32":
@@ -245,6 +280,10 @@ def build_parser():
     p.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
                    help="(addition) arithmetic of the per-vertex appearance re-query; the density grid -- hence the mesh topology "
                         "-- is always computed in fp32")
+    p.add_argument("--route", choices=("kernel", "script"), default="kernel",
+                   help="(addition) kernel: one density-grid launch, GPU statistics and marching cubes (default); script: the "
+                        "unmodified script's own call sequence -- sample_points + D2H per --batch-size points, numpy iso level, "
+                        "skimage.measure.marching_cubes, the re-query in --batch-size calls (single process)")
     p.add_argument("--gather", choices=("triangles", "grid"), default="triangles",
                    help="(addition, multi-GPU) what travels between the ranks: the emitted triangles of per-slab marching "
                         "cubes (default) or the density grid")

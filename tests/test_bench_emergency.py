@@ -84,3 +84,41 @@ def test_the_committed_bench_line_keeps_the_drivers_contract():
     train = line["train"]
     assert abs(train["roofline"]["frac"] - train["roofline"]["achieved"] / train["roofline"]["peak"]) < 1e-9
     assert abs(sum(k["ms"] for k in train["kernels"].values()) - train["ms_per_iteration"]) < 0.6, "the breakdown adds up to the iteration"
+
+
+def test_the_printed_line_is_compact_and_keeps_the_contract():
+    """What bench.py prints since round 6 (benchlib/line.py): the contract's keys untouched, `roofline` / `cpu_baseline` / `parity`,
+    one small object per secondary figure -- at most 4 KiB, so that the driver's record holds it whole (round 5's 15 KB line
+    survived there as key names and two truncated tails) -- and the name of the file that holds every object in full.  Fed with
+    a full set of objects as measured on the MI355X (profiles/r05_bench_line.json)."""
+    sys.path.insert(0, ROOT)
+    from benchlib import line as L
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    text = L.render(full, "bench_full.json")
+    assert len(text) <= L.LINE_BUDGET_BYTES and "\n" not in text
+    line = json.loads(text)
+    for key in L.CONTRACT:
+        assert line[key] == full[key], key
+    assert line["full"] == "bench_full.json"
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert roof["traffic"] > 0 and roof["avg_launch_ms"] > 0 and roof["kernel"].startswith("nm::")
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"] and cpu["port_over_reference_time"] == 1.15
+    assert line["parity"]["abs_dpsnr_db"] <= 1e-4 and line["parity"]["unexplained"] == 0
+    # the figures a reviewer needs from each secondary object, without opening the full file
+    assert line["mesh"]["marching_cubes"]["bitwise"] is True and line["mesh"]["marching_cubes"]["bound"] == "hbm"
+    assert 0 < line["mesh"]["grid_query"]["frac"] <= 1 and line["mesh"]["topology_128"]["ok"] is True
+    for name in ("buff", "eval", "tiny", "train", "bf16x3"):
+        assert line[name]["value"] > 0 and "unit" in line[name], name
+    for name in ("buff", "eval", "tiny", "train"):
+        assert 0 < line[name]["frac"] <= 1, name
+    assert set(line["train"]["stages"]) >= {"taping_forward", "delta", "weight_gradients"}
+    # an object that failed stays an error; one that outgrows the budget is cut to its scalars, never dropped
+    full["buff"] = {"error": "RuntimeError('x')", "failed_ranks": [1]}
+    full["train"]["stages_blowup"] = {str(i): {"ms": float(i)} for i in range(400)}
+    full["train"]["kernels"].update({f"stage{i}": {"ms": 1.0 + i, "frac": 0.5} for i in range(200)})
+    text = L.render(full, "bench_full.json")
+    line = json.loads(text)
+    assert len(text) <= L.LINE_BUDGET_BYTES and line["buff"] == {"error": "RuntimeError('x')", "failed_ranks": [1]}
+    assert line["train"]["value"] == 145040.0 and "stages" not in line["train"]

@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int CHUNK, int SLOTS, bool LOAD>
+template <int CHUNK, int SLOTS, bool LOAD, bool OPS = false>
 __global__ __launch_bounds__(512) void ring(const char* __restrict__ src, int64_t chunks_per_wg, int mfmas, float* out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NW = 8, P = CHUNK / 1024 / NW;
@@ -34,22 +34,47 @@ __global__ __launch_bounds__(512) void ring(const char* __restrict__ src, int64_
     for (int c = 0; c < SLOTS - 1; ++c) dma(c);
     wait_vm<(SLOTS - 2) * P>();
     __syncthreads();
-    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    f32x4 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = f32x4{0, 0, 0, 0};
     float sum = 0.f;
     for (int64_t c = 0; c < chunks_per_wg; ++c) {
         dma(c + SLOTS - 1);
-        const float a = *reinterpret_cast<const float*>(lds + (int)(c % SLOTS) * CHUNK + lane * 4 + wave * 1024);
+        const char* slot = lds + (int)(c % SLOTS) * CHUNK;
+        const float a = *reinterpret_cast<const float*>(slot + lane * 4 + wave * 1024);
         sum += a;
-        for (int m = 0; m < mfmas; m += 4) {
+        if (OPS) {
+            // the weight-gradient kernels' operand traffic: two ds_read_b128 per 16 MFMAs, operands straight from the chunk
+            for (int m = 0; m < mfmas; m += 16) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(slot + ((m * 64 + lane * 16) & (CHUNK / 2 - 1)));
+                const f32x4 y = *reinterpret_cast<const f32x4*>(slot + CHUNK / 2 + ((m * 64 + lane * 16) & (CHUNK / 2 - 1)));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, acc[q], 0, 0, 0);
+                for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+                    for (int qb = 0; qb < 4; ++qb) acc[qa * 4 + qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[qa], y[qb], acc[qa * 4 + qb], 0, 0, 0);
+            }
+        } else {
+            for (int m = 0; m < mfmas; m += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, acc[q], 0, 0, 0);
+            }
         }
         if (c + SLOTS - 1 < chunks_per_wg) wait_vm<(SLOTS - 2) * P>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
     }
-    const float r = sum + acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    float r = sum;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r += acc[q][q & 3];
     if (r == 12345.678f) out[0] = r;
+}
+
+__global__ void fill_random(float* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)(i * 2654435761u) ^ (uint32_t)(i >> 32);
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+        p[i] = ((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * ((h & 1) ? 1.0f : 0.0f);   // ~half zeros (ReLU rows), the rest uniform in [-1, 1)
+    }
 }
 
 int main() {
@@ -89,5 +114,23 @@ int main() {
     RUN(16384, 4, 1, 32); RUN(16384, 8, 1, 32); RUN(16384, 4, 2, 32); RUN(32768, 4, 1, 64);
     RUN(8192, 4, 1, 8); RUN(8192, 16, 1, 8); RUN(32768, 4, 1, 32); RUN(8192, 4, 4, 8);
     RUN(32768, 4, 1, 128); RUN(32768, 2, 2, 128);
+    // the same with REAL operands: ds_read_b128 pairs feeding 16 independent accumulators, first on the zero buffer, then on
+    // random data (half zeros like ReLU rows): the matrix pipe's power draw -- hence the clock -- depends on the bits it multiplies
+#define RUNOPS(CH, SL, WPC, MF, TAG) do { \
+        const int grid = cus * (WPC); const int64_t cpw = bytes / ((int64_t)grid * (CH)); const int ldsb = (CH) * (SL); \
+        CK(hipFuncSetAttribute((const void*)ring<CH, SL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
+        CK(hipFuncSetAttribute((const void*)ring<CH, SL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); \
+        const float both = time([&] { hipLaunchKernelGGL((ring<CH, SL, true, true>), dim3(grid), dim3(512), ldsb, 0, d, cpw, MF, out); }); \
+        const float mf = time([&] { hipLaunchKernelGGL((ring<CH, SL, false, true>), dim3(grid), dim3(512), ldsb, 0, d, cpw, MF, out); }); \
+        const double flop = (double)cpw * grid * 8 * (MF) * 2048.0; \
+        printf("%-7s %4d %3d %2d %4d  both %8.3f ms %6.2f TB/s %6.1f TFLOP/s | mfma on stale LDS only %8.3f ms %6.1f TFLOP/s\n", TAG, (CH) / 1024, SL, WPC, MF, both, \
+               (double)cpw * grid * (CH) / (both * 1e-3) / 1e12, flop / (both * 1e-3) / 1e12, mf, flop / (mf * 1e-3) / 1e12); } while (0)
+    printf("data   chunk_KiB slots wgs_per_cu mfmas_per_wave_chunk\n");
+    for (int pass = 0; pass < 2; ++pass) {
+        const char* tag = pass ? "random" : "zeros";
+        if (pass) { hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (float*)d, bytes / 4); CK(hipDeviceSynchronize()); }
+        RUNOPS(16384, 4, 1, 32, tag); RUNOPS(16384, 4, 2, 32, tag); RUNOPS(32768, 4, 1, 64, tag); RUNOPS(32768, 4, 1, 128, tag); RUNOPS(8192, 4, 1, 16, tag);
+        RUNOPS(8192, 4, 2, 16, tag); RUNOPS(32768, 4, 1, 32, tag);
+    }
     return 0;
 }
