@@ -195,21 +195,20 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
 }
 
 // ---- R5: inverse-CDF resampling + merge -------------------------------------------------------------
-constexpr int PDF_MAX_COARSE = 256;
-constexpr int PDF_MAX_TOTAL = 512;
+// One wave per ray, its cdf / bins / merged depths in LDS: 3 * coarse + fine floats per wave, sized per launch (192-sample
+// rays: 1.3 KB per wave; the limit is what four waves fit into a CU's 160 KB: 3 * num_coarse + num_fine <= 10 240).
+constexpr int PDF_MAX_FLOATS_PER_WAVE = 10240;
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ t, const float* __restrict__ weights,
                                                          const float* __restrict__ u, int u_per_ray, int64_t rays,
                                                          int coarse, int fine, float* __restrict__ t_out) {
-    __shared__ float s_cdf[4][PDF_MAX_COARSE];
-    __shared__ float s_bins[4][PDF_MAX_COARSE];
-    __shared__ float s_all[4][PDF_MAX_TOTAL];
+    extern __shared__ __attribute__((aligned(16))) float s_pdf[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
     if (ray >= rays) return;  // wave-uniform; no block-level barriers below
-    float* cdf = s_cdf[wv];
-    float* bins = s_bins[wv];
-    float* all = s_all[wv];
+    float* cdf = s_pdf + (size_t)wv * (3 * coarse + fine);
+    float* bins = cdf + coarse;
+    float* all = bins + coarse;
     const float* tr = t + ray * coarse;
     const float* wr = weights + ray * coarse;
     const int nb = coarse - 1;   // bins / cdf entries
@@ -367,6 +366,155 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float* __
     }
 }
 
+// ---- rays of MORE than 512 samples (no shipped config has them; /root/reference/src/nerf/modules.py:67-121 takes any count):
+// the same arithmetic in segments of 512 samples (8 per lane), the transmittance carried from segment to segment in fp64.
+// The <= 512 kernels above keep their one-pass form (and their bits).
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__shfl(hi, src), __shfl(lo, src));
+}
+
+__global__ __launch_bounds__(256) void composite_long_kernel(const float* __restrict__ radiance, const float* __restrict__ t,
+                                                             const float* __restrict__ dirs, const float* __restrict__ noise,
+                                                             int64_t rays, int samples, float thr, int white_bg, int training,
+                                                             nm_bundle_out out, const RayGen gen) {
+    constexpr int PER = 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= rays) return;
+    float norm;
+    if (gen.enabled) {
+        float go[3], gd[3];
+        nm_gen_ray(gen, ray, go, gd);
+        norm = torch_norm3(gd[0], gd[1], gd[2]);
+    } else {
+        norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    }
+    const float* tr = t + ray * samples;
+    const f32x4* rr = reinterpret_cast<const f32x4*>(radiance) + ray * samples;
+    double carry = 1.0;                                       // product of (1 - alpha + 1e-10) over every earlier segment
+    float r = 0, g = 0, b = 0, acc = 0, depth = 0;
+    for (int base = 0; base < samples; base += 64 * PER) {
+        float alpha[PER], tt[PER];
+        f32x4 rad[PER];
+        double local = 1.0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int s = base + lane * PER + q;
+            alpha[q] = 0.0f; tt[q] = 0.0f; rad[q] = f32x4{0, 0, 0, 0};
+            if (s < samples) {
+                tt[q] = tr[s];
+                rad[q] = rr[s];
+                float dist = (s + 1 < samples) ? (tr[s + 1] - tt[q]) : 1e10f;
+                dist = dist * norm;
+                const float sig = fmaxf(rad[q][3] + (noise ? noise[ray * samples + s] : 0.0f), 0.0f);
+                alpha[q] = 1.0f - expf(-sig * dist);
+                local *= (double)((1.0f - alpha[q]) + 1e-10f);
+            }
+        }
+        double run = carry * wave_exclusive_scan<true>(local, lane);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int s = base + lane * PER + q;
+            if (s < samples) {
+                const float T = (float)run;
+                const float w = alpha[q] * T;
+                if (out.d_weights) out.d_weights[ray * samples + s] = w;
+                if (out.d_mask_weights) out.d_mask_weights[ray * samples + s] = T > thr ? 1.0f : 0.0f;
+                r += w * rad[q][0]; g += w * rad[q][1]; b += w * rad[q][2];
+                acc += w;
+                depth += w * tt[q];
+                run *= (double)((1.0f - alpha[q]) + 1e-10f);
+            }
+        }
+        carry = shfl_f64(run, 63);                            // lane 63 has walked to the end of the segment
+    }
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); acc = wave_sum(acc); depth = wave_sum(depth);
+    if (lane == 0) {
+        float disp = 1.0f / fmaxf(1e-10f, depth / acc);
+        if (disp != disp || (depth / acc) != (depth / acc)) disp = 0.0f;
+        if (!training && acc < 1.0f) depth = 0.0f;
+        if (white_bg) { const float bg = 1.0f - acc; r += bg; g += bg; b += bg; }
+        if (out.d_rgb_map) { out.d_rgb_map[3 * ray] = r; out.d_rgb_map[3 * ray + 1] = g; out.d_rgb_map[3 * ray + 2] = b; }
+        if (out.d_depth_map) out.d_depth_map[ray] = depth;
+        if (out.d_acc_map) out.d_acc_map[ray] = acc;
+        if (out.d_disp_map) out.d_disp_map[ray] = disp;
+    }
+}
+
+// backward, two sweeps: the first yields total = sum_j dL/dw_j * w_j, the second walks the samples again with the running
+// prefix, so that the suffix sum_{j>k} of the one-pass kernel is total - prefix_k - dL/dw_k * w_k (all fp64)
+__global__ __launch_bounds__(256) void composite_backward_long_kernel(const float* __restrict__ radiance, const float* __restrict__ t,
+                                                                      const float* __restrict__ dirs, const float* __restrict__ noise,
+                                                                      int64_t rays, int samples, int white_bg, nm_bundle_grads g,
+                                                                      float* __restrict__ grad_radiance) {
+    constexpr int PER = 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= rays) return;
+    const float norm = torch_norm3(dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]);
+    const float* tr = t + ray * samples;
+    const f32x4* rr = reinterpret_cast<const f32x4*>(radiance) + ray * samples;
+    f32x4* out = reinterpret_cast<f32x4*>(grad_radiance) + ray * samples;
+    float gr = 0.0f, gg = 0.0f, gb = 0.0f;
+    if (g.d_rgb_map) { gr = g.d_rgb_map[3 * ray]; gg = g.d_rgb_map[3 * ray + 1]; gb = g.d_rgb_map[3 * ray + 2]; }
+    const float gacc = (g.d_acc_map ? g.d_acc_map[ray] : 0.0f) - (white_bg ? (gr + gg + gb) : 0.0f);
+    const float gdepth = g.d_depth_map ? g.d_depth_map[ray] : 0.0f;
+    double total = 0.0;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        double carry = 1.0, prefix = 0.0;                     // transmittance / sum of dL/dw_j * w_j in front of this segment
+        for (int base = 0; base < samples; base += 64 * PER) {
+            float alpha[PER], dist[PER], dw[PER], raw[PER];
+            f32x4 rad[PER];
+            double local = 1.0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int s = base + lane * PER + q;
+                alpha[q] = 0.0f; dist[q] = 0.0f; dw[q] = 0.0f; raw[q] = 0.0f; rad[q] = f32x4{0, 0, 0, 0};
+                if (s < samples) {
+                    const float ts = tr[s];
+                    rad[q] = rr[s];
+                    float d = (s + 1 < samples) ? (tr[s + 1] - ts) : 1e10f;
+                    d = d * norm;
+                    dist[q] = d;
+                    raw[q] = rad[q][3] + (noise ? noise[ray * samples + s] : 0.0f);
+                    alpha[q] = 1.0f - expf(-fmaxf(raw[q], 0.0f) * d);
+                    local *= (double)((1.0f - alpha[q]) + 1e-10f);
+                    dw[q] = (gr * rad[q][0] + gg * rad[q][1] + gb * rad[q][2]) + gacc + gdepth * ts;
+                    if (g.d_weights) dw[q] += g.d_weights[ray * samples + s];
+                }
+            }
+            double run = carry * wave_exclusive_scan<true>(local, lane);
+            float T[PER];
+            double own = 0.0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                T[q] = (float)run;
+                run *= (double)((1.0f - alpha[q]) + 1e-10f);
+                own += (double)(dw[q] * (alpha[q] * T[q]));
+            }
+            carry = shfl_f64(run, 63);
+            const double before = prefix + wave_exclusive_scan<false>(own, lane);    // everything in front of this lane's samples
+            prefix = shfl_f64(before + own, 63);
+            if (sweep == 0) continue;
+            double done = before;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int s = base + lane * PER + q;
+                if (s < samples) {
+                    const float w = alpha[q] * T[q];
+                    const float keep = (1.0f - alpha[q]) + 1e-10f;
+                    done += (double)(dw[q] * w);
+                    const float dalpha = dw[q] * T[q] - (float)(total - done) / keep;
+                    const float dsigma = raw[q] > 0.0f ? dalpha * dist[q] * (1.0f - alpha[q]) : 0.0f;
+                    out[s] = f32x4{w * gr, w * gg, w * gb, dsigma};
+                }
+            }
+        }
+        total = prefix;
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 int launch_ray_bundle(const float* c2w, int height, int width, float focal, int64_t first, int64_t count, float* d_dirs,
                       hipStream_t stream) {
@@ -396,9 +544,15 @@ int launch_composite(const float* d_radiance, const float* d_t, const float* d_d
     if (rays <= 0) return 0;
     RayGen gen;
     if (gen_ptr) gen = *gen_ptr; else memset(&gen, 0, sizeof(gen));
-    NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
+    NM_REQUIRE(samples >= 1, "composite: samples per ray must be >= 1");
     const dim3 grid((unsigned)((rays + 3) / 4)), block(256);
     const int per = (samples + 63) / 64;
+    if (per > 8) {                        // more than 512 samples: segments of 512 (composite_long_kernel)
+        hipLaunchKernelGGL(composite_long_kernel, grid, block, 0, stream, d_radiance, d_t, d_dirs, d_noise, rays, samples, thr, white_bg,
+                           training, out, gen);
+        NM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define NM_COMPOSITE(P)                                                                                      \
     hipLaunchKernelGGL(composite_kernel<P>, grid, block, 0, stream, d_radiance, d_t, d_dirs, d_noise, rays, samples, \
                        thr, white_bg, training, out, gen)
@@ -417,9 +571,12 @@ int launch_composite(const float* d_radiance, const float* d_t, const float* d_d
 int launch_sample_pdf(const float* d_t, const float* d_weights, const float* d_u, int u_per_ray, int64_t rays, int coarse,
                       int fine, float* d_t_out, hipStream_t stream) {
     if (rays <= 0) return 0;
-    NM_REQUIRE(coarse >= 3 && coarse <= PDF_MAX_COARSE, "sample_pdf: num_coarse must be in [3, 256]");
-    NM_REQUIRE(fine >= 1 && coarse + fine <= PDF_MAX_TOTAL, "sample_pdf: num_coarse + num_fine must be <= 512");
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, stream, d_t, d_weights, d_u,
+    NM_REQUIRE(coarse >= 3 && fine >= 1, "sample_pdf: num_coarse must be >= 3 and num_fine >= 1");
+    NM_REQUIRE(3 * (int64_t)coarse + fine <= PDF_MAX_FLOATS_PER_WAVE,
+               "sample_pdf: 3 * num_coarse + num_fine must be <= 10240 (a ray's cdf, bins and merged depths live in LDS)");
+    const int lds_bytes = 4 * (3 * coarse + fine) * 4;
+    if (int rc = ensure_dynamic_lds((const void*)sample_pdf_kernel, lds_bytes)) return rc;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), lds_bytes, stream, d_t, d_weights, d_u,
                        u_per_ray, rays, coarse, fine, d_t_out);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -484,9 +641,15 @@ int nm_composite_backward(const float* d_radiance, const float* d_t, const float
                           int64_t rays, int32_t samples, int white_background, const nm_bundle_grads* grads,
                           float* d_grad_radiance, void* stream) {
     NM_REQUIRE(d_radiance && d_t && d_dirs && grads && d_grad_radiance && rays >= 0, "bad argument");
-    NM_REQUIRE(samples >= 1 && samples <= 512, "composite: samples per ray must be in [1, 512]");
+    NM_REQUIRE(samples >= 1, "composite: samples per ray must be >= 1");
     if (rays == 0) return 0;
     const dim3 grid((unsigned)((rays + 3) / 4)), block(256);
+    if (samples > 512) {
+        hipLaunchKernelGGL(composite_backward_long_kernel, grid, block, 0, static_cast<hipStream_t>(stream), d_radiance, d_t, d_dirs,
+                           d_noise, rays, samples, white_background, *grads, d_grad_radiance);
+        NM_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define NM_COMPOSITE_BWD(P)                                                                                                     \
     hipLaunchKernelGGL(composite_backward_kernel<P>, grid, block, 0, static_cast<hipStream_t>(stream), d_radiance, d_t, d_dirs, \
                        d_noise, rays, samples, white_background, *grads, d_grad_radiance)

@@ -256,7 +256,8 @@ def test_coarse_intervals_bit_exact(ops, lindisp, per_ray):
     assert torch.equal(got.cpu(), ref.contiguous())
 
 
-@pytest.mark.parametrize("samples", [32, 64, 192, 200])
+# 513 / 700 / 1500: beyond one 512-sample pass -- the segmented kernel (the reference takes any count: modules.py:67-121)
+@pytest.mark.parametrize("samples", [32, 64, 192, 200, 512, 513, 700, 1500])
 @pytest.mark.parametrize("white", [False, True])
 def test_composite_vs_oracle(ops, samples, white):
     g = torch.Generator().manual_seed(samples)
@@ -270,20 +271,24 @@ def test_composite_vs_oracle(ops, samples, white):
     rs = O.RenderSpec(white_background=white)
     ref = O.composite(rad, t, dirs, rs)
     got = ops.composite(rad.cuda(), t.cuda(), dirs.cuda(), white_background=white)
+    # the per-ray sums run over `samples` fp32 terms in another order than torch's: the budget of the shipped counts (<= 256),
+    # growing with the count beyond
+    tol = 2e-6 * max(1.0, samples / 256.0)
     for k in BUNDLE_KEYS:
         if k == "mask_weights":
             assert (got[k].cpu() != ref[k]).float().mean() < 1e-4
         elif k == "disp_map":
-            _close(got[k], ref[k], 1e-6, rtol=2e-5, what=k)
+            _close(got[k], ref[k], 1e-6, rtol=10 * tol, what=k)
         elif k == "depth_map":
             # eval mode zeroes depth where acc < 1 (modules.py:108); acc within 1 ulp of 1.0 may take
             # the other branch under a different summation order -> compare where the branch agrees
-            _depth_close(got[k].cpu(), ref[k], got["acc_map"].cpu(), ref["acc_map"], 2e-6, 2e-6, k)
+            _depth_close(got[k].cpu(), ref[k], got["acc_map"].cpu(), ref["acc_map"], tol, tol, k)
         else:
-            _close(got[k], ref[k], 2e-6, rtol=2e-6, what=k)
+            _close(got[k], ref[k], tol, rtol=tol, what=k)
 
 
-@pytest.mark.parametrize("coarse,fine", [(64, 128), (64, 64), (32, 16), (200, 56)])
+# (300, 400), (64, 900): past the former 256 / 512 limits (a ray's tables are sized per launch now)
+@pytest.mark.parametrize("coarse,fine", [(64, 128), (64, 64), (32, 16), (200, 56), (300, 400), (64, 900)])
 def test_sample_pdf_vs_oracle(ops, coarse, fine):
     """Conditioning: sample = bins_b + (u - cdf_b) / (cdf_a - cdf_b) * binwidth, so a 1-ulp difference in
     the fp32 cdf (torch.sum's blocking vs a wavefront reduction for the pdf normaliser) moves a sample by
@@ -305,7 +310,9 @@ def test_sample_pdf_vs_oracle(ops, coarse, fine):
     assert torch.equal(got[:, -1], t[:, -1]) and torch.equal(got[:, 0], t[:, 0])
     a, b = _fine_samples_without_last(got, t), _fine_samples_without_last(ref, t)
     binw = 4.0 / (coarse - 1)
-    _close(a[71:], b[71:], 1e-3 * binw, what="fine depths (well conditioned)")
+    # (the pdf entries of rows [71:] shrink with the bin count -- ~1 / coarse --, and with them the conditioning: the budget of the
+    # shipped counts up to 128 bins, proportionally more beyond)
+    _close(a[71:], b[71:], 1e-3 * binw * max(1.0, coarse / 128.0), what="fine depths (well conditioned)")
     _close(a[:71], b[:71], 2e-2 * binw, what="fine depths (clamped bins)")
     # ... and the excluded u == 1.0 sample is not free either: it can only land where the cdf is within rounding of 1,
     # i.e. between the bin edge in front of the first cdf entry >= 1 - 4 ulp (fp64 cdf) and bins[-1]; when no earlier

@@ -173,7 +173,7 @@ def test_mlp_tape_and_backward_vs_autograd(ops, T, kw, rays, samples):
     assert not bad, f"gradient mismatch (ours, torch-fp32) relative to fp64 autograd: {bad}"
 
 
-@pytest.mark.parametrize("rays,samples,white", [(5, 7, False), (64, 64, False), (33, 192, True)])
+@pytest.mark.parametrize("rays,samples,white", [(5, 7, False), (64, 64, False), (33, 192, True), (9, 700, False), (7, 1100, True)])
 def test_composite_forward_backward_vs_autograd(ops, T, rays, samples, white):
     g = torch.Generator().manual_seed(samples)
     rad = torch.cat((torch.rand(rays, samples, 3, generator=g), 3.0 * torch.randn(rays, samples, 1, generator=g)), -1)
