@@ -87,6 +87,14 @@ def _mesh(m):
         if isinstance(mc.get("cpu_baseline"), dict):
             c["cpu"] = _cpu(mc["cpu_baseline"])
         out["marching_cubes"] = c
+    sh = m.get("sharded")
+    if isinstance(sh, dict) and isinstance(sh.get("strategies"), dict):
+        st = sh["strategies"]
+        out["sharded"] = {"default": sh.get("default"),
+                          **{k + "_ms": _sig(v.get("ms_end_to_end")) for k, v in st.items() if isinstance(v, dict)},
+                          "meshes_equal_single_grid": all(v.get("faces_and_normals_equal_single_grid_mesh") is True for v in st.values()
+                                                          if isinstance(v, dict)),
+                          "grid_all_gather_ms": _sig((sh.get("all_gather_of_the_grid") or {}).get("ms"))}
     app = m.get("appearance")
     if isinstance(app, dict):
         out["appearance"] = {}

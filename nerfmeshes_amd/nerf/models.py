@@ -34,6 +34,7 @@ class FlexibleNeRFModel(torch.nn.Module):
                           use_viewdirs=use_viewdirs)
         self._hip = None
         self._hip_key = None
+        self._pack = None         # [registration count, names, Parameter objects, storage pointers, nm_mlp_weights over them]
         self._generation = 0      # advanced by train_ops' optimizer post-step hook when an optimizer holding these parameters steps
         self.weights_guard = None  # None: NERFMESHES_WEIGHTS_GUARD / "always"; or "always" | "key" | "check" for this module
         # arithmetic of the inference kernels: "f32" (default) or the opt-in "bf16x3" (hip_ops.HipMLP); training is fp32
@@ -50,28 +51,43 @@ class FlexibleNeRFModel(torch.nn.Module):
         changed; "check": "key" plus a device checksum that raises StaleWeightsError when the key missed an edit.
         `precision` overrides `self.precision` for this handle (mesh_nerf's density grid asks for "f32" whatever the
         module is set to)."""
-        params = list(self.parameters()) + list(self.buffers())
+        # the Parameter objects are cached (walking the module tree costs more than the re-pack it guards); torch tells us when
+        # any module registers a parameter (train_ops.registrations()), which is the only way the list can change
+        pack = getattr(self, "_pack", None)
+        if pack is None or pack[0] != train_ops.registrations() or not train_ops.PARAMETER_HOOK:
+            named = list(self.named_parameters())
+            pack = self._pack = [train_ops.registrations(), [n for n, _ in named], [p for _, p in named], None, None]
+        names, params = pack[1], pack[2]
         dev = params[0].device
         if dev.type != "cuda":
             raise hip_ops._lib.HipLibraryError(
                 "FlexibleNeRFModel lives on %s: move it to the MI355X (.to('cuda')); there is no CPU path" % dev)
-        key = (train_ops.generation(), getattr(self, "_generation", 0)) + tuple((p.data_ptr(), p._version) for p in params)
+        ptrs = tuple([p.data_ptr() for p in params])
+        key = (train_ops.generation(), getattr(self, "_generation", 0), ptrs, tuple([p._version for p in params]))
         precision = "f32" if self.needs_grad() else (precision or getattr(self, "precision", "f32"))
         mode = train_ops.guard_mode(self)
         if self._hip is None or self._hip.device != dev or self._hip.precision != precision:
             self._hip = hip_ops.HipMLP(self.state_dict(), self._desc, dev, precision=precision)
-            train_ops.register_owner(self, self.parameters())
+            train_ops.register_owner(self, params)
+            pack[3] = None
         elif mode == "always" or key != self._hip_key:
-            if self._hip_key is None or key[2:] != self._hip_key[2:]:
-                train_ops.register_owner(self, self.parameters())     # a parameter object may have been replaced
-            train_ops.refresh(self._hip, dict(self.named_parameters()))
-        elif mode == "check" and train_ops.weights_differ(self._hip, dict(self.named_parameters())):
+            if self._hip_key is None or ptrs != self._hip_key[2]:
+                train_ops.register_owner(self, params)     # a parameter object / storage may have been replaced
+            pack[4] = train_ops.refresh(self._hip, None, self._struct(pack, ptrs))
+        elif mode == "check" and train_ops.weights_differ(self._hip, None, self._struct(pack, ptrs)):
             raise train_ops.StaleWeightsError(
                 "the parameters of this FlexibleNeRFModel were edited in a way the host cannot see (p.data / torch._foreach_* on "
                 ".data / a foreign kernel) and NERFMESHES_WEIGHTS_GUARD=check: the packed copy the HIP kernels read is stale.  "
                 "Call .refresh() after such edits, or run under the default guard (\"always\": re-pack on every use)")
         self._hip_key = key
         return self._hip
+
+    def _struct(self, pack, ptrs):
+        """The nm_mlp_weights over the live storages, rebuilt only when a storage moved (26 ctypes fields otherwise per use)."""
+        if pack[3] != ptrs or pack[4] is None:
+            pack[4] = train_ops._weights_struct(self._hip, dict(zip(pack[1], pack[2])))
+            pack[3] = ptrs
+        return pack[4]
 
     def refresh(self):
         """Force a device re-pack on the next use (only the "key" / "check" guards ever need it: after edits through `p.data`)."""

@@ -94,11 +94,12 @@ def _weights_struct(mlp, params):
     return w, (keep, xs_w, xs_b)
 
 
-def refresh(mlp, params):
-    """Re-pack `mlp` (hip_ops.HipMLP) from live device tensors: dict name -> CUDA fp32 tensor."""
-    w, keep = _weights_struct(mlp, params)
+def refresh(mlp, params, struct=None):
+    """Re-pack `mlp` (hip_ops.HipMLP) from live device tensors: dict name -> CUDA fp32 tensor, or a (MlpWeights, keep-alive)
+    pair `_weights_struct` built earlier over the same storages.  Returns that pair (for the caller to cache)."""
+    w, keep = struct if struct is not None else _weights_struct(mlp, params)
     check(_lib.load().nm_mlp_refresh(mlp.handle, C.byref(w), _stream()), "nm_mlp_refresh")
-    del keep
+    return w, keep
 
 
 def _per_ray(origins, rays):
@@ -352,6 +353,27 @@ def generation():
     return _GENERATION[0]
 
 
+# how often ANY module registered a parameter (torch calls the hook below from Module.register_parameter / __setattr__): the cheap
+# way for FlexibleNeRFModel.hip() to know that its cached list of Parameter objects is still the module's
+_REGISTRATIONS = [0]
+
+
+def registrations():
+    return _REGISTRATIONS[0]
+
+
+def _parameter_registered(module, name, param):
+    _REGISTRATIONS[0] += 1
+
+
+try:
+    from torch.nn.modules.module import register_module_parameter_registration_hook as _register_param_hook
+    _register_param_hook(_parameter_registered)
+    PARAMETER_HOOK = True
+except ImportError:         # an older torch: no caching of the parameter list (hip() walks the module tree on every use)
+    PARAMETER_HOOK = False
+
+
 def register_owner(module, params):
     import weakref
     ref = weakref.ref(module)
@@ -386,9 +408,9 @@ if _GLOBAL_HOOK:
     _register_step_hook(_optimizer_stepped)
 
 
-def weights_differ(mlp, params):
+def weights_differ(mlp, params, struct=None):
     """True when the packed image of `mlp` no longer equals the live tensors `params` (name -> CUDA fp32 tensor)."""
-    w, keep = _weights_struct(mlp, params)
+    w, keep = struct if struct is not None else _weights_struct(mlp, params)
     differs = C.c_int32(0)
     check(_lib.load().nm_mlp_weights_current(mlp.handle, C.byref(w), _stream(), C.byref(differs)), "nm_mlp_weights_current")
     del keep

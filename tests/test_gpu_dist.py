@@ -104,10 +104,19 @@ def test_bench_two_ranks_on_one_gpu_carries_the_sharded_objects(mode):
     printed = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(printed) == 1, printed
     line = json.loads(printed[0])
+    assert len(printed[0]) <= 4096, "the printed line is the compact one (benchlib/line.py)"
     assert line["n_gpus"] == 1 and line["ranks_per_gpu"] == 2 and line["scaling"] == mode and "FUNCTIONAL" in line["note"]
     assert line["rccl"]["backend"] == "gloo" and line["rccl"]["ranks_in_all_gather"] == 2
     assert line["rccl"]["slots_match_rank_checksums"] is True and len(line["rccl"]["roofline_frac_per_rank"]) == 2
     assert line["config"]["rays_per_step_per_rank"] == (320000 if mode == "strong" else 640000)
+    # what a SCALE record needs to be read on its own, on the line itself
+    sd = line["scaling_detail"]
+    assert sd["mode"] == mode and sd["collectives_per_step"] == 1 and sd["gathered_bytes_per_step"] == line["rccl"]["gathered_bytes_per_step"]
+    assert abs(sd["value_per_gpu"] - line["value"]) < 1e-3 * line["value"] and sd["efficiency_vs_n1_frac"] > 0 and sd["n1_value_source"].startswith("profiles/")
+    assert line["mesh"]["sharded"]["meshes_equal_single_grid"] is True and line["mesh"]["marching_cubes"]["bitwise"] is True
+    assert line["mesh"]["sharded"]["grid_ms"] > 0 and line["mesh"]["sharded"]["triangles_ms"] > 0 and 0 < line["buff"]["frac"] <= 1
+    # ... and every object as measured in the file the line names
+    line = json.load(open(os.path.join(ROOT, line["full"])))
     mesh, buff = line["mesh"], line["buff"]
     assert mesh["grid_query"]["planes_per_rank"] == [60, 60] and len(mesh["grid_query"]["roofline"]["frac_per_rank"]) == 2
     sh = mesh["sharded"]
@@ -140,7 +149,7 @@ def test_bench_line_survives_a_failing_secondary_object_at_two_ranks(inject, exp
     else:
         assert r.returncode == 0, r.stderr[-3000:]
         assert "injected failure" in line["buff"]["error"] and line["buff"]["failed_ranks"] == [0, 1]
-        assert line["mesh"]["marching_cubes"]["bitwise_identical_to_oracle"] is True, "the other objects still ran"
+        assert line["mesh"]["marching_cubes"]["bitwise"] is True, "the other objects still ran"
 
 
 def test_bench_eight_ranks_on_one_gpu():
@@ -157,6 +166,8 @@ def test_bench_eight_ranks_on_one_gpu():
     assert line["n_gpus"] == 1 and line["ranks_per_gpu"] == 8 and line["scaling"] == "weak" and "FUNCTIONAL" in line["note"]
     assert line["rccl"]["ranks_in_all_gather"] == 8 and line["rccl"]["slots_match_rank_checksums"] is True
     assert line["rccl"]["gathered_bytes_per_step"] == 8 * 640000 * 3 * 4 and len(line["rccl"]["roofline_frac_per_rank"]) == 8
+    assert line["scaling_detail"]["gathered_bytes_per_step"] == 8 * 640000 * 3 * 4 and len(printed[0]) <= 4096
+    line = json.load(open(os.path.join(ROOT, line["full"])))
     mesh = line["mesh"]
     assert mesh["grid_query"]["planes_per_rank"] == [15] * 8
     for strategy in ("grid", "triangles"):
