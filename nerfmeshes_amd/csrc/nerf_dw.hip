@@ -159,10 +159,15 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
         slot = slot1;
     }
 
-    // ---- write this workgroup's partial (feature permutation undone: tile (qa, qb) row i' = 4g + r, column j' = i
-    //      is dW[64 ablk + 4 i' + qa][64 bblk + 4 j' + qb])
-    const int64_t part = (int64_t)part_i * KSPLIT + kpart;
-    float* out = args.partial + part * (int64_t)(AW * BW);
+    // ---- this workgroup's partial (feature permutation undone: tile (qa, qb) row i' = 4g + r, column j' = i is
+    //      dW[64 ablk + 4 i' + qa][64 bblk + 4 j' + qb]).  Waves that split the k-groups of a block between them (KSPLIT > 1) first
+    //      add their accumulators up through the LDS the ring no longer needs, in k-part order 0, 1, ... (deterministic): ONE partial
+    //      per workgroup instead of KSPLIT -- the 64 x 64 kernel's 8 would otherwise make the order-fixed reduction read 8 x as much
+    //      as the operands of a short product are worth (config 1: a 32 us reduction behind a 50 us product).
+    float* out = args.partial + (int64_t)part_i * (AW * BW);
+    float* out_bias = args.partial_bias + (int64_t)part_i * AW;
+    float* red = reinterpret_cast<float*>(lds);                    // [KSPLIT][AW * BW] then [KSPLIT][AW]
+    float* dst = KSPLIT > 1 ? red + kpart * (AW * BW) : out;
 #pragma unroll
     for (int p = 0; p < BPW; ++p)
 #pragma unroll
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
             for (int r = 0; r < 4; ++r) {
                 const int row = 64 * ablk + 4 * (4 * g + r) + qa;
                 const f32x4 v = {acc[p][qa][0][r], acc[p][qa][1][r], acc[p][qa][2][r], acc[p][qa][3][r]};
-                *reinterpret_cast<f32x4*>(out + (int64_t)row * BW + 64 * (bblk0 + p) + 4 * i) = v;
+                *reinterpret_cast<f32x4*>(dst + (int64_t)row * BW + 64 * (bblk0 + p) + 4 * i) = v;
             }
     if (bblk0 == 0) {
         // lanes (g, i) hold the sums over samples = g (mod 4) of features 4i .. 4i+3: fold the 4 lane groups
@@ -182,7 +187,25 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(const DwBatch batch) {
             v += __shfl_xor(v, 32);
             bias[q] = v;
         }
-        if (g == 0) *reinterpret_cast<f32x4*>(args.partial_bias + part * AW + 64 * ablk + 4 * i) = bias;
+        float* bdst = KSPLIT > 1 ? red + KSPLIT * (AW * BW) + kpart * AW : out_bias;
+        if (g == 0) *reinterpret_cast<f32x4*>(bdst + 64 * ablk + 4 * i) = bias;
+    }
+    if constexpr (KSPLIT > 1) {
+        __syncthreads();
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(red);
+        for (int e = threadIdx.x; e < AW * BW / 4; e += NW * 64) {
+            f32x4 sum = r4[e];
+#pragma unroll
+            for (int k = 1; k < KSPLIT; ++k) sum += r4[k * (AW * BW / 4) + e];
+            reinterpret_cast<f32x4*>(out)[e] = sum;
+        }
+        const float* rb = red + KSPLIT * (AW * BW);
+        for (int e = threadIdx.x; e < AW; e += NW * 64) {
+            float sum = rb[e];
+#pragma unroll
+            for (int k = 1; k < KSPLIT; ++k) sum += rb[k * AW + e];
+            out_bias[e] = sum;
+        }
     }
 }
 
@@ -373,7 +396,7 @@ int weight_grad_tuned(int device_cus, int jobs, const nm_weight_grad_job* job, i
     const int cus = device_cus > 0 ? device_cus : 256;
     int64_t per_job = cus / jobs;
     per_job = per_job < 1 ? 1 : (per_job > chunks ? chunks : per_job);
-    const int parts = (int)per_job * plan->ksplit;
+    const int parts = (int)per_job;          // one partial per workgroup: the k-split waves add up in LDS (dw_kernel's epilogue)
     const int64_t job_floats = (int64_t)parts * ((int64_t)out_features * act_stride + out_features);
     DwBatch batch;
     DwReduceBatch rb;
@@ -385,7 +408,9 @@ int weight_grad_tuned(int device_cus, int jobs, const nm_weight_grad_job* job, i
         a.partial_bias = a.partial + (int64_t)parts * out_features * act_stride;
         rb.job[j] = DwReduceJob{a.partial, a.partial_bias, job[j].d_dw, job[j].d_dbias, job[j].dw_ld, job[j].dw_col0};
     }
-    const int lds_bytes = 4 * plan->rows * (out_features + act_stride) * 4;
+    const int ring_bytes = 4 * plan->rows * (out_features + act_stride) * 4;
+    const int fold_bytes = plan->ksplit > 1 ? plan->ksplit * (out_features * act_stride + out_features) * 4 : 0;   // the epilogue's k-part sums
+    const int lds_bytes = ring_bytes > fold_bytes ? ring_bytes : fold_bytes;
     if (int rc = ensure_dynamic_lds((const void*)plan->kernel, lds_bytes)) return rc;
     hipLaunchKernelGGL(plan->kernel, dim3((unsigned)(per_job * jobs)), dim3(512), lds_bytes, stream, batch);
     const int64_t elems = (int64_t)out_features * in_features;
