@@ -256,7 +256,18 @@ typedef struct nm_mlp_tape {
     float* d_v;          /* (n, H/2): relu(layers_dir[0](cat(feat, view)))                         */
     uint64_t* d_mask_h;  /* (L, tiles, 64) ReLU masks of layers_xyz[0..L-2] and fc_feat, kernel-private layout */
     uint64_t* d_mask_v;  /* (tiles, 64)                                                            */
+    /* ABI v5, optional (NULL: not written).  The PositionalEncoding rows (src/nerf/modules.py:26-34) of every sample point /
+     * view direction, 64 floats per sample in the reference's column order [x | sin c-major | cos c-major] -- what the layer1 /
+     * skip / view weight gradients contract with.  The taping kernel has these values in registers anyway; writing them here
+     * saves the separate nm_encode_samples_strided pass of the backward.  Tuned-family handles only (nm_mlp_kernel_variant
+     * < 1000, both encodings <= 64 wide); other handles leave the buffers untouched -- ask nm_mlp_tapes_encodings().
+     * Columns beyond the encoding's width are not written. */
+    float* d_enc_xyz;    /* (n, 64) or NULL                                                         */
+    float* d_enc_dir;    /* (n, 64) or NULL                                                         */
 } nm_mlp_tape;
+/* 1 when nm_mlp_forward_train on this handle fills d_enc_xyz / d_enc_dir (when given), 0 when the caller still needs
+ * nm_encode_samples_strided. */
+int nm_mlp_tapes_encodings(const nm_mlp* mlp);
 
 /* dL/d(pre-activation) of every layer, written by nm_mlp_backward (same row layout as the tape). */
 typedef struct nm_mlp_deltas {

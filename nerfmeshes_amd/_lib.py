@@ -35,7 +35,7 @@ class BundleOut(C.Structure):
 
 
 class MlpTape(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v")]
+    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v", "d_enc_xyz", "d_enc_dir")]
 
 
 class MlpDeltas(C.Structure):
@@ -101,6 +101,7 @@ SIGNATURES = {
     # training path
     "nm_mlp_refresh": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p]),
     "nm_mlp_refresh_count": (C.c_int64, [c_void_p]),
+    "nm_mlp_tapes_encodings": (C.c_int, [c_void_p]),
     "nm_mlp_weights_current": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p, C.POINTER(C.c_int32)]),
     "nm_mlp_forward_train": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32,
                                        C.POINTER(MlpTape), c_void_p, c_void_p]),

@@ -219,6 +219,41 @@ __device__ __forceinline__ void encode(float (&enc)[STEPS], const float (&x)[3],
     enc[STEPS - 1] = g == 0 ? x[0] : (g == 1 ? x[1] : (g == 2 ? x[2] : 0.0f));
 }
 
+// TAPE: the encoding a lane holds as B operands (encode() above), written as this sample's row in the reference's column order
+// [x y z | sin, argument-major | cos] (modules.py:26-34): k-step s < STEPS - 1 carries sin / cos of arguments 2s (lane groups
+// 0 / 1) and 2s + 1 (groups 2 / 3), the last step the raw coordinates.  One dword per lane and k-step; the four groups of a
+// sample fill two 8-byte runs of its row.  The weight-gradient kernels contract the layer1 / skip / view deltas with these rows;
+// until round 6 a separate pass recomputed them (nm_encode_samples_strided: 0.15 ms of a 2048-ray iteration).
+template <int F, int STEPS>
+__device__ __forceinline__ void store_encoding_row(float* row, const float (&enc)[STEPS], int g) {
+    // Two k-steps per 8-byte store: the arguments 2s and 2s + 1 of a step sit in lanes l and l + 32 (groups 0 / 2 for the sines,
+    // 1 / 3 for the cosines) and are neighbours in the row, so ONE v_permlane32_swap per step hands each half of the wave the
+    // other's value; the lower half then stores step s, the upper half step s + 1 -- 13 store instructions per sample tile of the
+    // 8x256 network instead of 23 dword ones (each VGPR-addressed store holds up the SIMD's MFMA issue, section 3.5).
+    const bool upper = g >= 2;
+    float* sincos = row ? row + 3 + ((g & 1) ? 3 * F : 0) : nullptr;
+    constexpr int NS = STEPS - 1;
+#pragma unroll
+    for (int s = 0; s < NS; s += 2) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(enc[s]), __float_as_uint(enc[s]), false, false);
+        float first = enc[s], second = __uint_as_float(lo[1]);              // lower half: (own, partner) of step s
+        int a = 2 * s;
+        if (s + 1 < NS) {
+            const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(enc[s + 1]), __float_as_uint(enc[s + 1]), false, false);
+            if (upper) { first = __uint_as_float(hi[0]); second = enc[s + 1]; a = 2 * s + 2; }   // upper half: (partner, own) of step s + 1
+        } else if (upper) {
+            a = 3 * F;                                                       // no step s + 1: nothing to store
+        }
+        if (row && a + 1 < 3 * F) {
+            typedef float f32x2 __attribute__((ext_vector_type(2), aligned(4)));
+            *reinterpret_cast<f32x2*>(sincos + a) = f32x2{first, second};
+        } else if (row && a < 3 * F) {
+            sincos[a] = first;
+        }
+    }
+    if (row && g < 3) row[g] = enc[STEPS - 1];
+}
+
 __device__ __forceinline__ float group_sum(float v) {  // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
@@ -362,6 +397,7 @@ __global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kern
         const float dummy[1] = {0.0f};
         float encx_keep[KEEP_ENC ? N::EX : 1];
         if constexpr (KEEP_ENC) encode<FX, N::EX, ABL>(encx_keep, p, args.bands_xyz, g);
+        if constexpr (KEEP_ENC && TAPE) store_encoding_row<FX, N::EX>((valid && args.tape_encx) ? args.tape_encx + sample * 64 : nullptr, encx_keep, g);
 
         f32x4 acc[N::NT];
         float in[N::KH];
@@ -375,6 +411,7 @@ __global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kern
         } else {   // the encoding registers live only for this stage; the skip layer recomputes them
             float encx[N::EX];
             encode<FX, N::EX, ABL>(encx, p, args.bands_xyz, g);
+            if constexpr (TAPE) store_encoding_row<FX, N::EX>((valid && args.tape_encx) ? args.tape_encx + sample * 64 : nullptr, encx, g);
             gemm_stage<N::NT, N::EX, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL>(acc, encx, dummy, gw, gw + N::EX * N::STEP, N::LDSBUF,
                                                                    lds, par, wave, lane);
         }
@@ -442,6 +479,7 @@ __global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kern
         load_bias<N::NTD>(accd, bias_src + H * (1 + num_layers), g);
         float encd[N::ED];
         encode<FD, N::ED, ABL>(encd, d, args.bands_dir, g);
+        if constexpr (TAPE) store_encoding_row<FD, N::ED>((valid && args.tape_encd) ? args.tape_encd + sample * 64 : nullptr, encd, g);
         gemm_stage<N::NTD, N::KH, N::ED, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL, TAPE>(
             accd, in, encd, gw, args.wstream, has_next ? N::L1_FIRST : 0, lds, par, wave, lane,
             (TAPE && valid) ? args.tape_feat + sample * H + 4 * g : nullptr);

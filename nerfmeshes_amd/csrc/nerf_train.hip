@@ -295,6 +295,15 @@ using namespace nm;
 
 extern "C" {
 
+int nm_mlp_tapes_encodings(const nm_mlp* m) {
+    if (!m || m->lw || m->plan->generic_nt != 0) return 0;           // tuned family only (mlp_device.h: store_encoding_row)
+    static const bool off = getenv("NM_TAPE_ENCODINGS") && atoi(getenv("NM_TAPE_ENCODINGS")) == 0;   // A/B hook of the tools
+    if (off) return 0;
+    const nm_mlp_desc& d = m->desc;
+    return d.include_input_xyz && (d.use_viewdirs == 0 || d.include_input_dir) && 6 * d.num_encoding_fn_xyz + 3 <= 64 &&
+           6 * d.num_encoding_fn_dir + 3 <= 64;
+}
+
 int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray, const float* d_dirs, const float* d_t,
                          int64_t rays, int32_t samples, const nm_mlp_tape* tape, float* d_radiance, void* stream) {
     NM_REQUIRE(m && d_origins && d_dirs && d_t && tape && d_radiance && rays >= 0 && samples > 0, "bad argument");
@@ -350,6 +359,10 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
     a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
     a.tiles = (a.n + 15) / 16;
+    if (nm_mlp_tapes_encodings(m)) {       // the encoding rows the weight gradients contract with, straight from the registers
+        a.tape_encx = tape->d_enc_xyz;
+        a.tape_encd = flat ? nullptr : tape->d_enc_dir;
+    }
     const int H = d.hidden_size, L = d.num_layers;
     const int ring = plan->ring_slots * KC * (H / 16) * 256;
     const int lds_bytes = ring + (((H * (1 + L) + H / 2 + 4 + H + (flat ? 3 * H : 3 * H / 2)) * 4 + 255) & ~255);

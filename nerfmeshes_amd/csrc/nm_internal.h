@@ -116,6 +116,8 @@ struct MlpArgs {
     uint64_t* mask_h;        // (L, tiles, 64): layers_xyz[0..L-2] then fc_feat; per lane, bit 4*tile+reg = activation > 0
     uint64_t* mask_v;        // (tiles, 64)
     int64_t tiles;           // ceil(n / 16)
+    float* tape_encx;        // (n, 64) or null: the positional-encoding row of every sample point, reference column order
+    float* tape_encd;        // (n, 64) or null: likewise for the view direction (tuned family only: nm_mlp_tape.d_enc_*)
     RayGen gen;              // VIEW: rays generated from the pose (c = t as in RAYS; a, b unused)
     // generic-shape kernels only (mlp_device_g.h): the encodings' run-time description
     const void* g_tab;       // device: GEncArg[2][96] (xyz, dir; two parts of 48): coordinate and frequency band of every encoding argument

@@ -124,7 +124,13 @@ def forward_train(mlp, origins, dirs, t):
     tape = dict(h=torch.empty(L, n, H, **f32), feat=None if flat else torch.empty(n, H, **f32),
                 v=None if flat else torch.empty(n, H // 2, **f32),
                 mask_h=None if generic else torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
-                mask_v=None if flat or generic else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device))
+                mask_v=None if flat or generic else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device),
+                enc_x=None, enc_d=None)
+    if lib.nm_mlp_tapes_encodings(mlp.handle):
+        # tuned family: the kernel writes the encoding rows the layer1 / skip / view weight gradients contract with (it has
+        # them in registers); the backward then skips its nm_encode_samples_strided pass
+        tape["enc_x"] = torch.empty(n, 64, **f32)
+        tape["enc_d"] = None if flat else torch.empty(n, 64, **f32)
     out = torch.empty(rays, samples, 4, **f32)
     ct = _tape_struct(tape)
     with _stage("taping_forward"):
@@ -135,7 +141,8 @@ def forward_train(mlp, origins, dirs, t):
 
 def _tape_struct(tape):
     opt = lambda x: None if x is None else _ptr(x)   # noqa: E731
-    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(tape["v"]), opt(tape["mask_h"]), opt(tape["mask_v"]))
+    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(tape["v"]), opt(tape["mask_h"]), opt(tape["mask_v"]),
+                   opt(tape.get("enc_x")), opt(tape.get("enc_d")))
 
 
 def encode_samples(mlp, origins, dirs, t):
@@ -243,11 +250,14 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     # DMA pieces for the general kernel; whatever lies beyond the width only reaches dW entries that are never read)
     origins, dirs, t = (_dev32(x, mlp.device) for x in (origins, dirs, t))
     rays, samples = t.shape
-    sx, sd = (64, 64) if dx <= 64 and dd <= 64 else ((dx + 3) & ~3, (max(dd, 1) + 3) & ~3)
-    enc_x, enc_d = torch.empty(n, sx, **f32), (torch.empty(n, sd, **f32) if dd else None)
-    with _stage("encodings"):
-        check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
-                                            samples, _ptr(enc_x), sx, _ptr(enc_d), sd, _stream()), "nm_encode_samples_strided")
+    if tape.get("enc_x") is not None:          # written by the taping forward (tuned family)
+        enc_x, enc_d = tape["enc_x"], tape.get("enc_d")
+    else:
+        sx, sd = (64, 64) if dx <= 64 and dd <= 64 else ((dx + 3) & ~3, (max(dd, 1) + 3) & ~3)
+        enc_x, enc_d = torch.empty(n, sx, **f32), (torch.empty(n, sd, **f32) if dd else None)
+        with _stage("encodings"):
+            check(lib.nm_encode_samples_strided(mlp.handle, _ptr(origins), _per_ray(origins, rays), _ptr(dirs), _ptr(t), rays,
+                                                samples, _ptr(enc_x), sx, _ptr(enc_d), sd, _stream()), "nm_encode_samples_strided")
     # every dW product of the backward as a job (delta, act, in_features, out, col0, bias): the same-shape ones -- the hidden x hidden
     # layers, the two encoding products -- each go out as ONE launch (nm_weight_grad_batch)
     g, jobs = {}, []

@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
 
     /* ---- training ABI: every point is a one-sample ray (origin = point, t = 0) */
     const size_t tiles = ((size_t)n + 15) / 16;
-    nm_mlp_tape tape;
+    nm_mlp_tape tape = {0};       /* the optional members (d_enc_xyz / d_enc_dir, ABI v5) stay NULL: not wanted here */
     nm_mlp_deltas dl;
     float *d_t, *d_grad, *d_rad2;
     hipMalloc((void**)&tape.d_h, (size_t)L * n * H * 4); hipMalloc((void**)&tape.d_feat, (size_t)n * H * 4);

@@ -307,6 +307,42 @@ def test_adam_steps_reduce_the_loss_and_eval_follows_the_new_weights(adam):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("kw", SHAPES + FLAT_SHAPES[:1], ids=["4x64", "8x256", "3x128", "4x64-flat"])
+@pytest.mark.parametrize("rays,samples", [(37, 9), (256, 16)])
+def test_the_taping_forward_writes_the_encoding_rows_the_backward_used_to_recompute(ops, T, kw, rays, samples):
+    """Round 6: the tuned taping kernels write the PositionalEncoding row of every sample point / view direction (modules.py:26-34,
+    reference column order, 64 floats per sample) from the registers they encode into anyway (nm_mlp_tape.d_enc_xyz / d_enc_dir);
+    the backward contracts the layer1 / skip / view deltas with those rows instead of running nm_encode_samples_strided.  The rows
+    equal that kernel's output bit for bit on every column of the encoding; the gradients are unchanged (the tests above)."""
+    import ctypes as C
+    from nerfmeshes_amd import _lib
+    lib = _lib.load()
+    w = _weights(kw)
+    mlp = ops.HipMLP(w, kw, "cuda")
+    assert lib.nm_mlp_tapes_encodings(mlp.handle) == 1
+    o, d, t = _rays(rays, samples, 21)
+    o, d, t = o[:1].cuda(), d.cuda(), t.cuda().contiguous()
+    _, tape = T.forward_train(mlp, o, d, t)
+    torch.cuda.synchronize()
+    dx, dd = 6 * kw["num_encoding_fn_xyz"] + 3, 6 * kw["num_encoding_fn_dir"] + 3
+    flat = not kw.get("use_viewdirs", True)
+    n = rays * samples
+    ex = torch.full((n, 64), float("nan"), device="cuda")
+    ed = torch.full((n, 64), float("nan"), device="cuda")
+    ptr = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    assert lib.nm_encode_samples_strided(mlp.handle, ptr(o), 0, ptr(d), ptr(t), rays, samples, ptr(ex), 64, None if flat else ptr(ed), 64,
+                                         None) == 0, lib.nm_last_error()
+    torch.cuda.synchronize()
+    assert tape["enc_x"].shape == (n, 64) and torch.equal(tape["enc_x"][:, :dx], ex[:, :dx])
+    if flat:
+        assert tape["enc_d"] is None
+    else:
+        assert torch.equal(tape["enc_d"][:, :dd], ed[:, :dd])
+    # a generic-family handle says so and leaves the job to the separate pass
+    g = dict(num_layers=3, hidden_size=100, skip_step=2, num_encoding_fn_xyz=5, num_encoding_fn_dir=2)
+    assert lib.nm_mlp_tapes_encodings(ops.HipMLP(_weights(g), g, "cuda").handle) == 0
+
+
 def _render_after(model, batch, edit):
     """(rgb rendered after `edit`, rgb of a model rebuilt from the edited state_dict, re-packs the edit's render cost)."""
     model.eval()
