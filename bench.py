@@ -184,7 +184,7 @@ def main():
     flops_per_ray = (NUM_COARSE + NUM_COARSE + NUM_FINE) * coarse.flops_per_sample()
 
     traffic, traffic_source = None, None
-    for name in ("r05_pmc_mlp_kernel.json", "r04_pmc_mlp_kernel.json", "r03_pmc_mlp_kernel.json", "r02_pmc_mlp_kernel.json", "r01_pmc_mlp_kernel.json"):
+    for name in ("r06_pmc_mlp_kernel.json", "r05_pmc_mlp_kernel.json", "r04_pmc_mlp_kernel.json", "r03_pmc_mlp_kernel.json", "r02_pmc_mlp_kernel.json", "r01_pmc_mlp_kernel.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:

@@ -24,7 +24,8 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
         for net in (model.model_coarse, model.model_fine):
             net.fc_alpha.weight.mul_(30.0)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    from nerfmeshes_amd import train_ops
+    opt = train_ops.make_optimizer("Adam", model.parameters(), 5e-4)     # what BaseModel.configure_optimizers builds (fused on the GPU)
     pick = torch.randperm(dirs.shape[0], generator=torch.Generator().manual_seed(1))[:rays].to(dev)
     batch = (origin.reshape(1, 3), dirs[pick].contiguous(), torch.tensor([2.0, 6.0]))
     target = torch.rand(rays, 3, device=dev)
@@ -62,7 +63,6 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
                                 "against the fp32 MFMA peak"}}
     # ---- where the iteration's time goes (HIP events around the stages of train_ops, a separate pass of `iters` iterations):
     # the three matrix stages each against the fp32 MFMA peak on their own algorithmic FLOP, everything else as milliseconds
-    from nerfmeshes_amd import train_ops
     train_ops.profile_stages(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

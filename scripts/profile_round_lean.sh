@@ -11,6 +11,7 @@ tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof_$tag $R/gpurun_out/pmc_$tag
 cd $R && python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+cp $R/bench_full.json $R/gpurun_out/bench_full_$tag.json 2>/dev/null      # every object as measured (the line is the compact form)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/bench_${tag}_profiled.log 2>&1
 for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
@@ -18,8 +19,7 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
   rocprofv3 --pmc $group --kernel-trace -d $R/gpurun_out/pmc_$tag/$name -o pmc --output-format csv -- python $R/bench.py --headline-only --steps 1 --warmup 0 > $R/gpurun_out/pmc_$tag/$name.log 2>&1
 done
 cd $R
-python tests/tools/bench_shapes.py 2>/dev/null | tail -1 > gpurun_out/shapes_$tag.json
-for shape in "8 512 10" "8 320 10" "8 96 10"; do
-  bash scripts/pmc_run.sh generic_${tag}_$(echo $shape | tr ' ' x) "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "mlp_kernel_g" python $R/tests/tools/one_shape.py $shape > gpurun_out/generic_pmc_${tag}_$(echo $shape | tr ' ' x).txt 2>&1
-done
+# round 6: the narrow shapes' training iterations with their stage tables, and the drop-in report (call traces of the unmodified scripts)
+python tests/tools/bench_train_shapes.py --iters 10 --only "4x64 (config 1: 32 coarse, no fine),8x64,8x128,8x256" > gpurun_out/train_shapes_$tag.txt 2>/dev/null
+python -m pytest tests/test_gpu_script_traces.py -q > gpurun_out/script_traces_$tag.txt 2>&1
 ls $R/gpurun_out/prof_$tag $R/gpurun_out/pmc_$tag
