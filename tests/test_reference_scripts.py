@@ -80,3 +80,32 @@ def test_reference_train_nerf_main(tmp_path):
     # resumed with train_iters 10 on 3 training images: BaseModel.setup sizes the run as 10 // 3 = 3 epochs = 9 steps
     assert out["global_step"] == 6 and out["resumed_global_step"] == 9 and out["weights_moved"]
     assert "[TRAIN] Iter: 8" in out["resume_stdout"]
+
+
+@pytest.mark.parametrize("scenario", ["eval", "mesh", "train"])
+def test_the_committed_call_traces_are_what_the_unmodified_scripts_do(scenario, tmp_path):
+    """tests/golden/script_traces.json (the fixture tests/test_gpu_script_traces.py holds the package's command lines to on the
+    MI355X) regenerates from the UNMODIFIED reference scripts: the tiny shapes are re-run here (seconds) and must reproduce the
+    committed trace and printed numbers exactly; the shipped-shape entries (minutes of CPU: tests/golden/make_script_traces.py) are
+    checked for the structure the scripts' own loops imply."""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", NM_REF_BACKEND="oracle", NM_REF_WHICH="reference", NM_REF_SHAPES="tiny")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "script_trace_runner.py"), scenario, str(tmp_path)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "script_traces.json")))
+    want = fixture["tiny"][scenario]
+    assert got["trace"] == want["trace"]
+    for key in ("stdout_losses", "stdout_total", "train_losses", "eval_losses", "global_step", "resumed_global_step", "checkpoints"):
+        if key in want:
+            assert got[key] == want[key], key
+    if scenario == "mesh":
+        assert {k: got["view"][k] for k in ("v", "f", "iso", "first_v")} == {k: want["view"][k] for k in ("v", "f", "iso", "first_v")}
+    calls = lambda trace, name: sum(c for (n, _, _), c in trace if n == name)  # noqa: E731
+    ship = fixture["shipped"][scenario]["trace"]
+    if scenario == "eval":        # two 100 x 100 views in chunks of 2048 rays: 5 queries each (eval_nerf.py:62-65)
+        assert calls(ship, "query") == 10 and calls(ship, "load_from_checkpoint") == 1
+    elif scenario == "mesh":      # 128^3 points at the script's own --batch-size 1024, twice (mesh_nerf.py:37-48,239)
+        assert calls(ship, "sample_points") >= 2 * 2048 and calls(ship, "marching_cubes") == 2 and calls(ship, "export_obj") == 2
+    else:                          # 18 + 6 steps, a validation pass per epoch of 3 views, then eval_nerf.py on the result
+        assert calls(ship, "training_step") == 24 and calls(ship, "configure_optimizers") == 2 and calls(ship, "query") > 0
