@@ -34,7 +34,7 @@ class FlexibleNeRFModel(torch.nn.Module):
                           use_viewdirs=use_viewdirs)
         self._hip = None
         self._hip_key = None
-        self._pack = None         # [registration count, names, Parameter objects, storage pointers, nm_mlp_weights over them]
+        self._pack = None         # [registration count, names, Parameter objects, storage pointers, nm_mlp_weights over them, owners]
         self._generation = 0      # advanced by train_ops' optimizer post-step hook when an optimizer holding these parameters steps
         self.weights_guard = None  # None: NERFMESHES_WEIGHTS_GUARD / "always"; or "always" | "key" | "check" for this module
         # arithmetic of the inference kernels: "f32" (default) or the opt-in "bf16x3" (hip_ops.HipMLP); training is fp32
@@ -54,9 +54,14 @@ class FlexibleNeRFModel(torch.nn.Module):
         # the Parameter objects are cached (walking the module tree costs more than the re-pack it guards); torch tells us when
         # any module registers a parameter (train_ops.registrations()), which is the only way the list can change
         pack = getattr(self, "_pack", None)
-        if pack is None or pack[0] != train_ops.registrations() or not train_ops.PARAMETER_HOOK:
+        if pack is None or pack[0] != train_ops.registrations() or not train_ops.PARAMETER_HOOK or \
+                any(owner._parameters.get(leaf) is not p for owner, leaf, p in pack[5]):      # (a direct `_parameters[...] = ` bypasses the hook)
             named = list(self.named_parameters())
-            pack = self._pack = [train_ops.registrations(), [n for n, _ in named], [p for _, p in named], None, None]
+            owners = []
+            for n, p in named:
+                path, _, leaf = n.rpartition(".")
+                owners.append((self.get_submodule(path) if path else self, leaf, p))
+            pack = self._pack = [train_ops.registrations(), [n for n, _ in named], [p for _, p in named], None, None, owners]
         names, params = pack[1], pack[2]
         dev = params[0].device
         if dev.type != "cuda":

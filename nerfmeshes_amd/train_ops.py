@@ -377,8 +377,10 @@ def _parameter_registered(module, name, param):
 
 
 try:
-    from torch.nn.modules.module import register_module_parameter_registration_hook as _register_param_hook
+    from torch.nn.modules.module import (register_module_module_registration_hook as _register_module_hook,
+                                         register_module_parameter_registration_hook as _register_param_hook)
     _register_param_hook(_parameter_registered)
+    _register_module_hook(_parameter_registered)       # a replaced sub-module brings new Parameter objects with it
     PARAMETER_HOOK = True
 except ImportError:         # an older torch: no caching of the parameter list (hip() walks the module tree on every use)
     PARAMETER_HOOK = False

@@ -412,6 +412,35 @@ def test_edits_the_host_cannot_see_reach_the_kernels_or_raise(edit, monkeypatch)
     assert packs == 0 and not torch.equal(got, want), "the key guard re-packs only on what the host can see"
 
 
+@pytest.mark.parametrize("guard", ["always", "key"])
+def test_replaced_parameter_objects_and_submodules_are_seen(guard, monkeypatch):
+    """hip() caches the module's Parameter objects (walking the tree costs more than the re-pack it guards): a parameter that is
+    re-assigned, a sub-module that is replaced, and a Parameter put straight into `_parameters` must all be picked up."""
+    monkeypatch.setenv("NERFMESHES_WEIGHTS_GUARD", guard)
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw)
+    model = _model(hp, seed=3).eval()
+    o, d, _ = _rays(128, 2, 4)
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+
+    def same_as_rebuilt():
+        with torch.no_grad():
+            got = model.query(batch).rgb_map
+            fresh = _model(hp, seed=99).eval()
+            fresh.load_state_dict(model.state_dict())
+            return torch.equal(got, fresh.query(batch).rgb_map)
+
+    assert same_as_rebuilt()
+    net = model.model_fine
+    net.fc_alpha.weight = torch.nn.Parameter(net.fc_alpha.weight.detach() * 1.5)                   # re-assigned (register_parameter)
+    assert same_as_rebuilt()
+    new = torch.nn.Linear(net.fc_feat.in_features, net.fc_feat.out_features).cuda()
+    net.fc_feat = new                                                                              # a replaced sub-module
+    assert same_as_rebuilt()
+    net.layer1._parameters["bias"] = torch.nn.Parameter(torch.full_like(net.layer1.bias, 0.25))    # behind torch's back
+    assert same_as_rebuilt()
+
+
 def test_the_key_guard_repacks_once_per_visible_change_and_never_otherwise(monkeypatch):
     """Under NERFMESHES_WEIGHTS_GUARD=key a render loop over unchanged parameters re-packs nothing; an in-place op autograd sees,
     an optimizer step (fused Adam moves no version counter: the scoped post-step hook) and load_state_dict each cost exactly one
