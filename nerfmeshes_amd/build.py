@@ -14,7 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libnerfmeshes_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["nerf_mlp.hip", "nerf_mlp_generic_a.hip", "nerf_mlp_generic_b.hip", "nerf_mlp_generic_c.hip", "nerf_mlp_generic_d.hip", "nerf_mlp_generic_e.hip", "nerf_mlp_generic_s.hip", "nerf_mlp_generic_a_long.hip", "nerf_mlp_generic_b_long.hip", "nerf_mlp_generic_c_long.hip", "nerf_mlp_generic_d_long.hip", "nerf_mlp_generic_s_long.hip", "nerf_train.hip", "nerf_dw.hip", "nerf_dw_g.hip", "nerf_layerwise.hip", "mlp_api.hip", "ray_ops.hip", "marching_cubes.hip", "buff_tree.hip", "np_reduce.hip", "obj_writer.cpp"]
+SOURCES = ["nerf_mlp.hip", "nerf_mlp_generic_a.hip", "nerf_mlp_generic_b.hip", "nerf_mlp_generic_c.hip", "nerf_mlp_generic_d.hip", "nerf_mlp_generic_e.hip", "nerf_mlp_generic_s.hip", "nerf_mlp_generic_a_long.hip", "nerf_mlp_generic_b_long.hip", "nerf_mlp_generic_c_long.hip", "nerf_mlp_generic_d_long.hip", "nerf_mlp_generic_s_long.hip", "nerf_mlp_generic_s_long2.hip", "nerf_train.hip", "nerf_dw.hip", "nerf_dw_g.hip", "nerf_layerwise.hip", "mlp_api.hip", "ray_ops.hip", "marching_cubes.hip", "buff_tree.hip", "np_reduce.hip", "obj_writer.cpp"]
 # every header next to the sources (mlp_device*.h, nm_internal.h, mc_luts.h, ...) + the public C ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "nerfmeshes_hip.h")]
 # -ffp-contract=off: the reference computes a*b+c with two roundings (torch eager ops); every fused
@@ -115,13 +115,15 @@ def build(force=False, verbose=True, ablations=False, jobs=None):
     return lib_path
 
 
-# relative compile cost of the translation units (minutes on one core, roughly): scheduling order only
-_COST = {"nerf_mlp_generic_s.hip": 9, "nerf_mlp_generic_s_long.hip": 9, "nerf_mlp_generic_e.hip": 6, "nerf_mlp_generic_d.hip": 5,
-         "nerf_mlp_generic_d_long.hip": 5, "nerf_mlp_generic_c.hip": 4, "nerf_mlp_generic_c_long.hip": 4, "nerf_dw_g.hip": 3}
+# compile cost of the translation units (CPU seconds on this image, measured in round 6): scheduling order only -- the split
+# kernels' long-encoding instantiations were the critical path (172 s in one unit: two units now); 740 s of CPU in all
+_COST = {"nerf_mlp_generic_s_long.hip": 90, "nerf_mlp_generic_s_long2.hip": 90, "nerf_mlp_generic_s.hip": 74, "nerf_mlp_generic_b_long.hip": 67, "nerf_mlp_generic_c_long.hip": 65,
+         "nerf_mlp_generic_a_long.hip": 63, "nerf_mlp_generic_d_long.hip": 39, "nerf_mlp_generic_c.hip": 34, "nerf_mlp_generic_b.hip": 31,
+         "nerf_dw_g.hip": 29, "nerf_mlp_generic_a.hip": 25, "nerf_mlp_generic_d.hip": 24, "nerf_mlp.hip": 13, "nerf_train.hip": 10}
 
 
 def _weight(src):
-    return _COST.get(src, 1)
+    return _COST.get(src, 3)
 
 
 if __name__ == "__main__":

@@ -110,12 +110,13 @@ void generic_plans_b_long(std::vector<MlpPlan>&);
 void generic_plans_c_long(std::vector<MlpPlan>&);
 void generic_plans_d_long(std::vector<MlpPlan>&);
 void generic_plans_s_long(std::vector<MlpPlan>&);
+void generic_plans_s_long_upper(std::vector<MlpPlan>&);
 
 static const std::vector<MlpPlan>& all_plans() {
     static const std::vector<MlpPlan> plans = [] {
         std::vector<MlpPlan> v(std::begin(g_tuned_plans), std::end(g_tuned_plans));
         generic_plans_a(v); generic_plans_b(v); generic_plans_c(v); generic_plans_d(v); generic_plans_s(v); generic_plans_e(v);
-        generic_plans_a_long(v); generic_plans_b_long(v); generic_plans_c_long(v); generic_plans_d_long(v); generic_plans_s_long(v);
+        generic_plans_a_long(v); generic_plans_b_long(v); generic_plans_c_long(v); generic_plans_d_long(v); generic_plans_s_long(v); generic_plans_s_long_upper(v);
 #ifdef NM_ABLATIONS
         // experiment (NM_MLP_VARIANT=200 + NM_KERNEL_GENERIC): two 16-sample column tiles per wave (mlp_device_g2.h)
         // (round 5: also the classes of 2 and 3 tiles -- VERDICT r4 item 7 -- compiled for four waves per SIMD (200) and two (201))

@@ -7,7 +7,10 @@
 
 // compiled twice: as it is, and from nerf_mlp_generic_s_long.hip with NM_GENERIC_LONG defined (two-part encoding stages, 16 -- 31
 // functions: plans of variant G_LONG_VARIANT)
-#ifdef NM_GENERIC_LONG
+#if defined(NM_GENERIC_LONG) && defined(NM_GENERIC_UPPER)
+#define NM_PLANS_FN generic_plans_s_long_upper      // (the long-encoding unit was the build's critical path: 172 s; halved)
+constexpr bool kLong = true;
+#elif defined(NM_GENERIC_LONG)
 #define NM_PLANS_FN generic_plans_s_long
 constexpr bool kLong = true;
 #else
@@ -26,10 +29,14 @@ static MlpPlan split_plan() {
 }
 
 void NM_PLANS_FN(std::vector<MlpPlan>& out) {
+#if !defined(NM_GENERIC_UPPER)
     out.push_back(split_plan<26>());
     out.push_back(split_plan<28>());
+#endif
+#if !defined(NM_GENERIC_LONG) || defined(NM_GENERIC_UPPER)
     out.push_back(split_plan<30>());
     out.push_back(split_plan<32>());
+#endif
 }
 
 }  // namespace nm
