@@ -40,6 +40,13 @@ class FlexibleNeRFModel(torch.nn.Module):
         # arithmetic of the inference kernels: "f32" (default) or the opt-in "bf16x3" (hip_ops.HipMLP); training is fp32
         self.precision = "f32"
 
+    def __getstate__(self):
+        """copy.deepcopy (an EMA copy), pickling, torch.save(module): the device handle and the caches over it are run-time state
+        of THIS object -- a copy builds its own on first use."""
+        state = self.__dict__.copy()
+        state["_hip"], state["_hip_key"], state["_pack"] = None, None, None
+        return state
+
     def _is_skip(self, i):
         return i % self.skip_step == 0 and i > 0 and i != self.num_layers - 1
 

@@ -441,6 +441,31 @@ def test_replaced_parameter_objects_and_submodules_are_seen(guard, monkeypatch):
     assert same_as_rebuilt()
 
 
+def test_copies_and_pickles_of_a_module_get_their_own_handle(tmp_path):
+    """copy.deepcopy (how an EMA copy is made), pickle and torch.save of a module that has already rendered: the device handle is
+    run-time state of the original -- the copy packs its own on first use and follows ITS parameters."""
+    import copy
+    import pickle
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    hp = dict(num_coarse=16, num_fine=16, train_noise_std=0.0, **kw)
+    model = _model(hp, seed=3).eval()
+    o, d, _ = _rays(128, 2, 4)
+    batch = (o[:1].cuda(), d.cuda(), torch.tensor([2.0, 6.0]))
+    with torch.no_grad():
+        before = model.query(batch).rgb_map.clone()
+        ema = copy.deepcopy(model)
+        assert ema.model_fine._hip is None and model.model_fine._hip is not None
+        assert torch.equal(ema.query(batch).rgb_map, before)
+        for p in ema.parameters():
+            p.mul_(0.5)
+        assert not torch.equal(ema.query(batch).rgb_map, before) and torch.equal(model.query(batch).rgb_map, before)
+        assert ema.model_fine._hip is not model.model_fine._hip
+        again = pickle.loads(pickle.dumps(model))
+        assert torch.equal(again.query(batch).rgb_map, before)
+        torch.save(model, tmp_path / "whole_module.pt")
+        assert torch.equal(torch.load(tmp_path / "whole_module.pt", weights_only=False).query(batch).rgb_map, before)
+
+
 def test_the_key_guard_repacks_once_per_visible_change_and_never_otherwise(monkeypatch):
     """Under NERFMESHES_WEIGHTS_GUARD=key a render loop over unchanged parameters re-packs nothing; an in-place op autograd sees,
     an optimizer step (fused Adam moves no version counter: the scoped post-step hook) and load_state_dict each cost exactly one
