@@ -320,6 +320,11 @@ class _MLPRays(torch.autograd.Function):
 def mlp_rays(module, origins, dirs, t):
     """Differentiable FlexibleNeRFModel.forward over (R,S) ray samples; `module` is the nn.Module mirror
     (nerfmeshes_amd.nerf.models.FlexibleNeRFModel) whose parameters receive the gradients."""
+    for name, x in (("ray origins", origins), ("ray directions", dirs), ("sample depths", t)):
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError(
+                f"the {name} require a gradient: the HIP backward produces parameter gradients only (what NeRFModel.training_step "
+                "asks for, model_nerf.py:88-151); detach them, or they would silently receive none")
     mlp = module.hip()          # re-packed on the device if an optimizer step changed the parameters
     names = param_names(int(mlp.desc["num_layers"]), bool(mlp.desc.get("use_viewdirs", True)))
     params = dict(module.named_parameters())
@@ -531,6 +536,10 @@ class _Composite(torch.autograd.Function):
 
 def composite(radiance, t, dirs, noise=None, attenuation_threshold=1e-5, white_background=False):
     """Differentiable VolumeRenderer.forward in training mode -> dict of the six bundle fields."""
+    for name, x in (("sample depths", t), ("ray directions", dirs)):
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError(f"the {name} require a gradient: the compositing backward differentiates the radiance only "
+                                      "(modules.py:67-121 as NeRFModel.training_step uses it); detach them")
     radiance = radiance if radiance.is_contiguous() else radiance.contiguous()
     t, dirs = _dev32(t), _dev32(dirs, radiance.device)
     noise = None if noise is None else _dev32(noise, radiance.device)

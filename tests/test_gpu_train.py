@@ -441,6 +441,26 @@ def test_replaced_parameter_objects_and_submodules_are_seen(guard, monkeypatch):
     assert same_as_rebuilt()
 
 
+def test_gradients_the_backward_does_not_produce_are_refused_not_dropped(ops, T):
+    """The HIP backward yields parameter gradients (and the compositing backward the radiance's): a caller who asks for gradients
+    with respect to ray origins, directions or depths -- the reference's autograd would deliver them -- gets an error with the
+    reason, never a silent zero."""
+    from nerfmeshes_amd.nerf.models import FlexibleNeRFModel
+    kw = dict(num_layers=4, hidden_size=64, skip_step=2, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    net = FlexibleNeRFModel(**kw).cuda().train()
+    pts = torch.rand(32, 3, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError, match="require a gradient"):
+        net(pts, pts.detach())
+    net(pts.detach(), pts.detach()).sum().backward()
+    assert all(p.grad is not None for p in net.parameters())
+    o, d, t = _rays(8, 16, 1)
+    rad = torch.rand(8, 16, 4, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError, match="require a gradient"):
+        T.composite(rad, t.cuda().requires_grad_(True), d.cuda())
+    T.composite(rad, t.cuda(), d.cuda())["rgb_map"].sum().backward()
+    assert rad.grad is not None
+
+
 def test_copies_and_pickles_of_a_module_get_their_own_handle(tmp_path):
     """copy.deepcopy (how an EMA copy is made), pickle and torch.save of a module that has already rendered: the device handle is
     run-time state of the original -- the copy packs its own on first use and follows ITS parameters."""
