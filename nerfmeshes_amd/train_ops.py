@@ -325,9 +325,10 @@ def mlp_rays(module, origins, dirs, t):
             raise NotImplementedError(
                 f"the {name} require a gradient: the HIP backward produces parameter gradients only (what NeRFModel.training_step "
                 "asks for, model_nerf.py:88-151); detach them, or they would silently receive none")
-    mlp = module.hip()          # re-packed on the device if an optimizer step changed the parameters
+    mlp = module.hip()          # the packed copy rebuilt from the live parameters (guard_mode() below)
     names = param_names(int(mlp.desc["num_layers"]), bool(mlp.desc.get("use_viewdirs", True)))
-    params = dict(module.named_parameters())
+    pack = getattr(module, "_pack", None)                  # hip() has just validated its list of (name, Parameter)
+    params = dict(zip(pack[1], pack[2])) if pack else dict(module.named_parameters())
     return _MLPRays.apply(mlp, names, origins, dirs, t, *[params[k] for k in names])
 
 
