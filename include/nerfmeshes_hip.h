@@ -36,7 +36,7 @@ extern "C" {
  * every layer shape, row stride and sample count; nm_weight_grad / nm_head_grad forward to them (their shape and n % 16
  * restrictions are gone), nm_encode_samples_strided writes whole rows for any stride.  No signature changed; everything in
  * version 3 is unchanged.  nm_mlp_create accepts hidden sizes above 512 and up to 32 encoding functions (layer-wise path). */
-#define NM_ABI_VERSION 5
+#define NM_ABI_VERSION 6
 
 const char* nm_last_error(void);
 int nm_abi_version(void);
@@ -289,6 +289,35 @@ int nm_mlp_forward_train(nm_mlp* mlp, const float* d_origins, int origins_per_ra
  * backward lists all of them; tests/cabi_smoke.c does one from plain C). */
 int nm_mlp_backward(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
                     const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream);
+
+/* ABI v6.  The whole back-propagation of a 64-wide network in ONE kernel (nerf_bwd_fused.hip): the delta chain of
+ * nm_mlp_backward AND the weight / bias gradients of layer1, layers_xyz[*], fc_feat and layers_dir[0] -- what loss.backward()
+ * leaves in the .grad of those parameters under NeRFModel.training_step (src/models/model_nerf.py:88-151, through
+ * FlexibleNeRFModel.forward, src/nerf/models.py:60-80) -- without a delta row ever reaching HBM (the tape is read once, the
+ * per-workgroup partials of all products are added up by one order-fixed reduction: deterministic).  What is left to the
+ * caller are the two 4-row heads: d_last (n, 4) is written as by nm_mlp_backward; fc_alpha / fc_rgb = nm_head_grad_ex of it.
+ * Served: tuned-family fp32 handles with hidden_size 64, use_viewdirs = 1, 2 <= num_layers <= 8, at most one skip layer, that
+ * tape their encodings (nm_mlp_tapes_encodings; tape->d_enc_xyz / d_enc_dir must be given), n a multiple of 128 -- ask
+ * nm_mlp_backward_fused_supported; everything else takes nm_mlp_backward + nm_weight_grad_batch.  Wider networks do not fit:
+ * the accumulators of all products must stay resident per workgroup (128 wide: 630 KB, a CU's register file is 512 KB).
+ * Gradient buffers are written in the parameters' own shapes: layer1 (H, dx), layers_xyz[i] (H, H) or (H, H + dx) for the
+ * skip layer, fc_feat (H, H), layers_dir[0] (H / 2, H + dd), biases (rows,). */
+#define NM_FUSED_MAX_LAYERS 8
+typedef struct nm_mlp_param_grads {
+    float* layer1_weight;
+    float* layer1_bias;
+    float* xyz_weight[NM_FUSED_MAX_LAYERS];   /* layers_xyz[0 .. num_layers - 2] */
+    float* xyz_bias[NM_FUSED_MAX_LAYERS];
+    float* feat_weight;
+    float* feat_bias;
+    float* dir_weight;
+    float* dir_bias;
+} nm_mlp_param_grads;
+int nm_mlp_backward_fused_supported(const nm_mlp* mlp, int64_t n);
+int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* mlp);
+int nm_mlp_backward_fused(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
+                          const float* d_grad_radiance, float* d_last, const nm_mlp_param_grads* grads, void* d_workspace,
+                          void* stream);
 
 /* PositionalEncoding.forward (src/nerf/modules.py:26-34) of the sample points / view directions as
  * rows in the reference's column order: d_enc_xyz (n, 3+6*Fx), d_enc_dir (n, 3+6*Fd); either may be NULL. */

@@ -42,6 +42,11 @@ class MlpDeltas(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_last")]
 
 
+class MlpParamGrads(C.Structure):          # nm_mlp_param_grads (ABI v6: nm_mlp_backward_fused)
+    _fields_ = [("layer1_weight", c_void_p), ("layer1_bias", c_void_p), ("xyz_weight", c_void_p * 8), ("xyz_bias", c_void_p * 8),
+                ("feat_weight", c_void_p), ("feat_bias", c_void_p), ("dir_weight", c_void_p), ("dir_bias", c_void_p)]
+
+
 class WeightGradJob(C.Structure):
     _fields_ = [("d_delta", c_void_p), ("d_act", c_void_p), ("d_dw", c_void_p), ("dw_ld", C.c_int32), ("dw_col0", C.c_int32),
                 ("d_dbias", c_void_p)]
@@ -105,6 +110,10 @@ SIGNATURES = {
     "nm_mlp_weights_current": (C.c_int, [c_void_p, C.POINTER(MlpWeights), c_void_p, C.POINTER(C.c_int32)]),
     "nm_mlp_forward_train": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32,
                                        C.POINTER(MlpTape), c_void_p, c_void_p]),
+    "nm_mlp_backward_fused_supported": (C.c_int, [c_void_p, C.c_int64]),
+    "nm_mlp_backward_fused_workspace_bytes": (C.c_int64, [c_void_p]),
+    "nm_mlp_backward_fused": (C.c_int, [c_void_p, C.c_int64, C.POINTER(MlpTape), c_void_p, c_void_p, c_void_p, C.POINTER(MlpParamGrads),
+                                        c_void_p, c_void_p]),
     "nm_mlp_backward": (C.c_int, [c_void_p, C.c_int64, C.POINTER(MlpTape), c_void_p, c_void_p, C.POINTER(MlpDeltas),
                                   c_void_p]),
     "nm_encode_samples": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p,
@@ -191,7 +200,7 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.nm_abi_version() != 5:
+    if lib.nm_abi_version() != 6:
         raise HipLibraryError("ABI version mismatch between _lib.py and libnerfmeshes_hip.so")
     _lib = lib
     return lib

@@ -14,7 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_NAME = "libnerfmeshes_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["nerf_mlp.hip", "nerf_mlp_generic_a.hip", "nerf_mlp_generic_b.hip", "nerf_mlp_generic_c.hip", "nerf_mlp_generic_d.hip", "nerf_mlp_generic_e.hip", "nerf_mlp_generic_s.hip", "nerf_mlp_generic_a_long.hip", "nerf_mlp_generic_b_long.hip", "nerf_mlp_generic_c_long.hip", "nerf_mlp_generic_d_long.hip", "nerf_mlp_generic_s_long.hip", "nerf_mlp_generic_s_long2.hip", "nerf_train.hip", "nerf_dw.hip", "nerf_dw_g.hip", "nerf_layerwise.hip", "mlp_api.hip", "ray_ops.hip", "marching_cubes.hip", "buff_tree.hip", "np_reduce.hip", "obj_writer.cpp"]
+SOURCES = ["nerf_mlp.hip", "nerf_mlp_generic_a.hip", "nerf_mlp_generic_b.hip", "nerf_mlp_generic_c.hip", "nerf_mlp_generic_d.hip", "nerf_mlp_generic_e.hip", "nerf_mlp_generic_s.hip", "nerf_mlp_generic_a_long.hip", "nerf_mlp_generic_b_long.hip", "nerf_mlp_generic_c_long.hip", "nerf_mlp_generic_d_long.hip", "nerf_mlp_generic_s_long.hip", "nerf_mlp_generic_s_long2.hip", "nerf_train.hip", "nerf_bwd_fused.hip", "nerf_dw.hip", "nerf_dw_g.hip", "nerf_layerwise.hip", "mlp_api.hip", "ray_ops.hip", "marching_cubes.hip", "buff_tree.hip", "np_reduce.hip", "obj_writer.cpp"]
 # every header next to the sources (mlp_device*.h, nm_internal.h, mc_luts.h, ...) + the public C ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "nerfmeshes_hip.h")]
 # -ffp-contract=off: the reference computes a*b+c with two roundings (torch eager ops); every fused

@@ -1,0 +1,499 @@
+// Back-propagation of the 64-wide networks (BASELINE config 1's 4x64, 8x64) in ONE kernel for gfx950: the delta chain of
+// nerf_train.hip's mlp_backward_kernel AND every weight / bias gradient of
+//   /root/reference/src/nerf/models.py:60-80 (what autograd's addmm backward computes for layer1, layers_xyz[*], fc_feat,
+//   layers_dir[0]) under /root/reference/src/models/model_nerf.py:88-151 (training_step + loss.backward()),
+// so that no delta row is ever written to HBM and the tape is read exactly once.
+//
+// Why only 64 wide.  dW = delta^T @ act contracts over the samples: its accumulators must stay resident while a workgroup walks
+// through its samples, for ALL layers at once because the chain produces one layer's delta after the other per sample tile.  A
+// 64 x 64 product is 16 KB: the 7 - 11 products of a 4 - 8 layer network are 56 - 88 accumulator registers per wave of an
+// 8-wave workgroup.  At 128 wide the same set is 630 KB per workgroup -- more than a CU's register file --,
+// which is why the wider networks keep the separate delta and weight-gradient kernels.
+//
+// Dataflow of one workgroup iteration (128 samples = 8 waves x one 16-sample MFMA tile):
+//   * the delta chain as in mlp_backward_kernel: a wave's tile stays in registers (D layout of stage k == B layout of stage
+//     k + 1), the transposed weights stream L2 -> LDS through the 2-slot ring of mlp_device.h, ReLU' from the taped bit masks;
+//   * each delta, once masked, is ALSO written to an LDS tile [sample][feature] (16-byte chunks XOR-swizzled by the sample so
+//     that the 16 lanes of a store hit 16 different bank groups);
+//   * the activation rows that delta contracts with (tape_h[i] / tape_feat / the encoding rows: 128 consecutive 256-byte rows =
+//     one contiguous 32 KB run) are DMA'd HBM -> LDS by scalar-addressed buffer_load ... lds one delta ahead into a 3-slot ring;
+//   * every wave owns 2 of the 16 output tiles of each 64 x 64 product (1 of the 8 tiles of the 32 x 64 view-layer products)
+//     and contracts them over all 128 samples: v_mfma_f32_16x16x4_f32 with the sample index as the instruction's contraction
+//     index, A = one float of the delta tile, B = two floats of the activation row per lane and k-group (dw_kernel's feature
+//     permutation: tile q row i stands for feature 4 i + q);  bias gradients are the column sums of the A operands.
+// Phases (one barrier each), for delta k:  A_k = [write delta_k to LDS | first weight chunk of stage k],  B_k = [second chunk |
+// the dW products of delta_k | DMA of the rows delta_k+1 needs].  Waits are COUNTED (s_waitcnt vmcnt(n) in front of a bare
+// s_barrier): the activation rows come from HBM and get a whole stage (~3 us) to land.
+// At the end a workgroup writes ONE partial of every product; fb_reduce_kernel adds the partials in index order (deterministic).
+//
+// Roofline: MFMA (delta chain + weight gradients: 2 x the forward's FLOP); HBM traffic = the tape once (2 KB / sample).
+#include <cstdlib>
+
+#include "nm_internal.h"
+#include "mlp_device.h"
+
+namespace nm {
+
+constexpr int FB_ROWS = 128;                       // samples per workgroup iteration
+constexpr int FB_ROWB = 256;                       // bytes per 64-float row
+constexpr int FB_CHUNK = 8192;                     // one weight chunk: 8 k-steps x 4 tiles x 256 B
+constexpr int FB_OFF_DBUF = 2 * FB_CHUNK;          // the delta tile behind the 2-slot weight ring
+constexpr int FB_SLOT = FB_ROWS * FB_ROWB;         // 32 KB: a block of activation rows
+constexpr int FB_NSLOT = 3;
+constexpr int FB_OFF_SLOT = FB_OFF_DBUF + FB_ROWS * FB_ROWB;
+constexpr int FB_OFF_HEADS = FB_OFF_SLOT + FB_NSLOT * FB_SLOT;
+constexpr int FB_LDS = FB_OFF_HEADS + 1024;        // 148 480 B: one workgroup per CU
+constexpr int FB_MAXL = 8;
+// one workgroup's partial, in floats: [dir x feat 32x64][dir x enc_d 32x64][feat][xyz 0..6][skip][layer1] then the bias sums
+constexpr int FB_P_DIRF = 0, FB_P_DIRE = 2048, FB_P_FEAT = 4096, FB_P_XYZ = 8192, FB_P_SKIP = FB_P_XYZ + (FB_MAXL - 1) * 4096,
+              FB_P_L1 = FB_P_SKIP + 4096, FB_P_BIAS = FB_P_L1 + 4096;
+constexpr int FB_B_DIR = 0, FB_B_FEAT = 64, FB_B_XYZ = 128, FB_B_L1 = FB_B_XYZ + (FB_MAXL - 1) * 64;
+constexpr int FB_PART = FB_P_BIAS + FB_B_L1 + 64;
+
+struct FusedBwdArgs {
+    const float* tape_h;      // (L, n, 64)
+    const float* tape_feat;   // (n, 64)
+    const float* enc_x;       // (n, 64)
+    const float* enc_d;       // (n, 64)
+    float* partial;           // (grid, FB_PART)
+    int32_t skip_layer;       // i of the one layers_xyz[i] that takes cat(x, xyz), -1: none
+};
+
+// 128 rows of 256 B -> one LDS slot: 32 pieces of 1 KiB, 4 per wave (every wave issues the same count: the waits count them)
+__device__ __forceinline__ void fb_dma_rows(const float* rows, char* dst, int wave) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rows), (short)16, 0x7fffffff, 1 << 23);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave + 8 * j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, piece * 1024, 0, 0);
+    }
+}
+
+// this lane's rows of a delta (D layout: tile nt, register r = feature 16 nt + 4 g + r of sample `col` of the wave's tile) into
+// the LDS delta tile: chunk c = 4 nt + g of row s lands at chunk c ^ (s & 15)
+template <int NT>
+__device__ __forceinline__ void fb_write_delta(char* dbuf, const float (&v)[4 * NT], int wave, int g, int col) {
+    char* row = dbuf + (wave * 16 + col) * FB_ROWB;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 v4 = {v[4 * nt], v[4 * nt + 1], v[4 * nt + 2], v[4 * nt + 3]};
+        *reinterpret_cast<f32x4*>(row + (((4 * nt + g) ^ col) << 4)) = v4;
+    }
+}
+
+// KS k-steps of a 4-tile stage out of one ring slot (operands of the next k-step in flight, as gemm_stage's PIPE); no barrier
+template <int KS, int B0, int NB>
+__device__ __forceinline__ void fb_chunk(f32x4 (&acc)[4], const float (&b)[NB], const char* buf) {
+    f32x4 a_next = *reinterpret_cast<const f32x4*>(buf);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 a = a_next;
+        if (ks + 1 < KS) a_next = *reinterpret_cast<const f32x4*>(buf + (ks + 1) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[B0 + ks], acc[q], 0, 0, 0);
+    }
+}
+
+// One weight-gradient product of this wave over the 128 samples of the delta tile: TB = 2 tiles (64 x 64 products) or 1 (the
+// 32 x 64 view-layer products).  a_ptr: this lane's A address for k-groups = 0 (mod 4) -- the swizzle of k-group ks is an XOR of
+// bits 6..7 with ks & 3 --, b_ptr: this lane's B address in the slot.  Operands are fetched 4 k-groups ahead of their MFMAs.
+template <int TB>
+__device__ __forceinline__ void fb_dw_step(f32x4 (&acc)[TB], float& bsum, const char* lds, const unsigned a_off, const char* b_ptr) {
+    constexpr int PF = 4, NBATCH = (FB_ROWS / 4) / PF;
+    float a[2][PF];
+    f32x2 b[2][PF];
+    auto fetch = [&](int kb, int buf) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            a[buf][j] = *reinterpret_cast<const float*>(lds + ((a_off ^ (unsigned)(j << 6)) + kb * (PF * 1024) + j * 1024));
+            if constexpr (TB == 2) b[buf][j] = *reinterpret_cast<const f32x2*>(b_ptr + kb * (PF * 1024) + j * 1024);
+            else b[buf][j][0] = *reinterpret_cast<const float*>(b_ptr + kb * (PF * 1024) + j * 1024);
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < NBATCH; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < NBATCH) fetch(kb + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+#pragma unroll
+            for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][j], b[cur][j][t], acc[t], 0, 0, 0);
+            bsum += a[cur][j];      // column sums of delta = the bias gradient (used from the waves that own column tile 0)
+        }
+    }
+}
+
+__device__ __forceinline__ void fb_wait_barrier(int pieces_in_flight) {
+    // everything but the newest `pieces_in_flight` DMA pieces (the rows of the NEXT delta) has landed; those stay in flight
+    if (pieces_in_flight >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (pieces_in_flight >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// MAXL: the num_layers an instantiation holds accumulators for (4: 56 registers per wave, 8: 88); the partial layout is MAXL 8's
+template <int MAXL>
+__global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdArgs args, const FusedBwdArgs fa, const int L) {
+    constexpr int H = 64, KH = 16, KD = 8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_walpha = reinterpret_cast<float*>(lds + FB_OFF_HEADS);   // [4][H/4]
+    float* lds_wrgb = lds_walpha + H;                                   // [3][4][H/8]
+    for (int i = threadIdx.x; i < H; i += 512) lds_walpha[i] = args.walpha[i];
+    for (int i = threadIdx.x; i < 3 * H / 2; i += 512) lds_wrgb[i] = args.wrgb[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    char* const dbuf = lds + FB_OFF_DBUF;
+
+    // ---- this wave's output tiles and the operand addresses that go with them
+    const int qa = wave >> 1, qb0 = 2 * (wave & 1);        // 64 x 64: tiles (qa, qb0), (qa, qb0 + 1); tile q row i = feature 4 i + q
+    const int qa2 = wave >> 2, qb2 = wave & 3;             // 32 x 64: tile (qa2, qb2); A row i = feature 2 i + qa2
+    // A of k-group ks: sample 4 ks + g, whose swizzle is 4 (ks & 3) + g: chunk c ^ g here, bits 2..3 of the chunk by ks in fb_dw_step
+    const unsigned a_off64 = FB_OFF_DBUF + g * FB_ROWB + ((col ^ g) << 4) + qa * 4;
+    const unsigned a_off32 = FB_OFF_DBUF + g * FB_ROWB + (((col >> 1) ^ g) << 4) + (2 * (col & 1) + qa2) * 4;
+    const int b_off64 = g * FB_ROWB + col * 16 + qb0 * 4;
+    const int b_off32 = g * FB_ROWB + col * 16 + qb2 * 4;
+    const bool bias64 = (wave & 1) == 0, bias32 = qb2 == 0;
+
+    f32x4 acc_dirf[1] = {{0.f, 0.f, 0.f, 0.f}}, acc_dire[1] = {{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc_feat[2], acc_skip[2], acc_l1[2], acc_xyz[MAXL - 1][2];
+    float bs_dir = 0.f, bs_feat = 0.f, bs_l1 = 0.f, bs_xyz[MAXL - 1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        acc_feat[t] = acc_skip[t] = acc_l1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MAXL - 1; ++i) acc_xyz[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MAXL - 1; ++i) bs_xyz[i] = 0.f;
+
+    const int64_t wg_iters = args.n / FB_ROWS;             // n % 128 == 0 (the host checks)
+    const int64_t mstride = args.tiles * 64;
+    const int sk = fa.skip_layer;
+    int par = 0;            // ring slot of the weight chunk the next gemm phase consumes
+    int bslot = 0;          // activation slot of the next product
+    int bissue = 0;         // activation slot the next DMA goes to
+    auto slot_ptr = [&](int s) { return lds + FB_OFF_SLOT + s * FB_SLOT; };
+    auto next_slot = [](int s) { return s == FB_NSLOT - 1 ? 0 : s + 1; };
+    auto issue_rows = [&](const float* rows) { fb_dma_rows(rows, slot_ptr(bissue), wave); bissue = next_slot(bissue); };
+
+    int64_t it = blockIdx.x;
+    f32x4 go = {0.f, 0.f, 0.f, 0.f}, y = go;
+    uint64_t mv = 0;
+    auto fetch_head = [&](int64_t iter) {
+        const int64_t s = (iter * 8 + wave) * 16 + col;
+        go = *reinterpret_cast<const f32x4*>(args.grad_out + 4 * s);
+        y = *reinterpret_cast<const f32x4*>(args.radiance + 4 * s);
+        mv = args.mask_v[(iter * 8 + wave) * 64 + lane];
+    };
+    if (it < wg_iters) {
+        fetch_head(it);
+        stream_to_lds<8>(args.wstream, lds, FB_CHUNK, wave, lane);                 // layers_dir.0^T: one chunk
+        issue_rows(fa.tape_feat + it * (FB_ROWS * 64));
+        issue_rows(fa.enc_d + it * (FB_ROWS * 64));
+    }
+    fb_wait_barrier(8);     // the head weights in LDS and the first weight chunk (older than the 8 row pieces) are everybody's now
+
+    for (; it < wg_iters; it += gridDim.x) {
+        const bool has_next = it + gridDim.x < wg_iters;
+        const int64_t tile = it * 8 + wave;
+        const int64_t sample = tile * 16 + col;
+        const int64_t row0 = it * FB_ROWS;                 // first sample of the workgroup's block
+        const uint64_t* mrow = args.mask_h + tile * 64 + lane;
+        const char* gw = args.wstream;
+
+        // ================= delta 0: at layers_dir[0]'s pre-activation (sigmoid', fc_rgb^T on the VALU; models.py:74-75)
+        float drgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) drgb[ch] = go[ch] * (y[ch] * (1.0f - y[ch]));
+        const float dsigma = go[3];
+        if (g == 0) {
+            const f32x4 o4 = {drgb[0], drgb[1], drgb[2], dsigma};
+            *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = o4;
+        }
+        float dv[KD];
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            float a = lds_wrgb[(0 * 4 + g) * KD + s] * drgb[0];
+            a = fmaf(lds_wrgb[(1 * 4 + g) * KD + s], drgb[1], a);
+            a = fmaf(lds_wrgb[(2 * 4 + g) * KD + s], drgb[2], a);
+            dv[s] = ((mv >> s) & 1u) ? a : 0.0f;
+        }
+        f32x4 acc[4];
+        float in[KH];
+        // ---- phase A0: delta_v -> LDS; layers_dir.0^T (hidden columns), one chunk
+        {
+            const uint64_t m = mrow[(int64_t)(L - 1) * mstride];
+            fb_write_delta<2>(dbuf, dv, wave, g, col);
+            stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);      // fc_feat^T chunk 0
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fb_chunk<KD, 0, KD>(acc, dv, lds + par * FB_CHUNK + lane * 16);
+            fb_wait_barrier(0);
+            par ^= 1;
+            gw += FB_CHUNK;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) in[4 * nt + r] = ((m >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+        }
+        // ---- phase B0: grad(layers_dir.0) = delta_v^T @ [feat | view encoding] (models.py:72-73)
+        {
+            issue_rows(fa.tape_h + ((int64_t)(L - 1) * args.n + row0) * 64);
+            fb_dw_step<1>(acc_dirf, bs_dir, lds, a_off32, slot_ptr(bslot) + b_off32);
+            bslot = next_slot(bslot);
+            float unused = 0.f;
+            fb_dw_step<1>(acc_dire, unused, lds, a_off32, slot_ptr(bslot) + b_off32);
+            bslot = next_slot(bslot);
+            fb_wait_barrier(4);
+        }
+        // ================= delta 1: at fc_feat's pre-activation; fc_feat^T + fc_alpha^T (models.py:70-71)
+        {
+            const uint64_t m = mrow[(int64_t)(L - 2) * mstride];
+            // ---- phase A1
+            fb_write_delta<4>(dbuf, in, wave, g, col);
+            stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
+            const float* wa = lds_walpha + g * (H / 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
+                acc[nt] = f32x4{w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
+            }
+            fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+            fb_wait_barrier(0);
+            par ^= 1;
+            // ---- phase B1: the first chunk of layers_xyz[L-2]^T (or, for a one-layer trunk, of the next iteration) | rows of delta 2
+            const bool more = L >= 2;
+            if (more || has_next) stream_to_lds<8>(more ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
+            int flying = 4;
+            if (more) {
+                issue_rows(fa.tape_h + ((int64_t)(L - 2) * args.n + row0) * 64);
+                if (sk == L - 2) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
+            } else {
+                issue_rows(fa.enc_x + row0 * 64);
+            }
+            fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+            fb_dw_step<2>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
+            bslot = next_slot(bslot);
+            fb_wait_barrier(flying);
+            par ^= 1;
+            gw += 2 * FB_CHUNK;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) in[4 * nt + r] = ((m >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+        }
+        // ================= deltas 2 .. L: at layers_xyz[i]'s pre-activation, i = L-2 .. 0; layers_xyz[i]^T (models.py:63-69)
+#pragma unroll
+        for (int i = MAXL - 2; i >= 0; --i) {
+            if (i <= L - 2) {
+                uint64_t m = ~uint64_t(0);
+                if (i > 0) m = mrow[(int64_t)(i - 1) * mstride];
+                // ---- phase A
+                fb_write_delta<4>(dbuf, in, wave, g, col);
+                stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+                fb_wait_barrier(0);
+                par ^= 1;
+                // ---- phase B
+                if (i > 0 || has_next) stream_to_lds<8>(i > 0 ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
+                int flying = 4;
+                if (i > 0) {
+                    issue_rows(fa.tape_h + ((int64_t)(i - 1) * args.n + row0) * 64);
+                    if (sk == i - 1) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
+                } else {
+                    issue_rows(fa.enc_x + row0 * 64);                      // layer1 contracts with the encoding rows
+                }
+                fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+                fb_dw_step<2>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
+                bslot = next_slot(bslot);
+                if (sk == i) {                                             // cat(x, xyz): the encoding columns (models.py:64-65)
+                    float unused = 0.f;
+                    fb_dw_step<2>(acc_skip, unused, lds, a_off64, slot_ptr(bslot) + b_off64);
+                    bslot = next_slot(bslot);
+                }
+                fb_wait_barrier(flying);
+                par ^= 1;
+                gw += 2 * FB_CHUNK;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) in[4 * nt + r] = ((m >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+            }
+        }
+        // ================= delta L+1: at layer1's output (no activation, models.py:62): grad(layer1) = delta^T @ xyz encoding
+        fb_write_delta<4>(dbuf, in, wave, g, col);
+        fb_wait_barrier(0);
+        int flying = 0;
+        if (has_next) {
+            fetch_head(it + gridDim.x);
+            issue_rows(fa.tape_feat + (it + gridDim.x) * (FB_ROWS * 64));
+            issue_rows(fa.enc_d + (it + gridDim.x) * (FB_ROWS * 64));
+            flying = 8;
+        }
+        fb_dw_step<2>(acc_l1, bs_l1, lds, a_off64, slot_ptr(bslot) + b_off64);
+        bslot = next_slot(bslot);
+        fb_wait_barrier(flying);
+    }
+
+    // ---- this workgroup's partial.  Tile (qa, qb), lane (g, col), register r: dW[4 (4 g + r) + qa][4 col + qb] (32-row products:
+    //      row 2 (4 g + r) + qa2); bias sums: fold the 4 lane groups (samples = g mod 4), feature 4 col + qa (2 col + qa2)
+    float* out = fa.partial + (int64_t)blockIdx.x * FB_PART;
+    auto store64 = [&](float* p, const f32x4 (&a)[2]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
+            *reinterpret_cast<f32x2a*>(p + (4 * (4 * g + r) + qa) * 64 + 4 * col + qb0) = f32x2a{a[0][r], a[1][r]};
+        }
+    };
+    auto store32 = [&](float* p, const f32x4 (&a)[1]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[(2 * (4 * g + r) + qa2) * 64 + 4 * col + qb2] = a[0][r];
+    };
+    auto fold = [&](float v) {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    };
+    store32(out + FB_P_DIRF, acc_dirf);
+    store32(out + FB_P_DIRE, acc_dire);
+    store64(out + FB_P_FEAT, acc_feat);
+#pragma unroll
+    for (int i = 0; i < MAXL - 1; ++i)
+        if (i <= L - 2) store64(out + FB_P_XYZ + i * 4096, acc_xyz[i]);
+    if (sk >= 0) store64(out + FB_P_SKIP, acc_skip);
+    store64(out + FB_P_L1, acc_l1);
+    float* ob = out + FB_P_BIAS;
+    {
+        const float v = fold(bs_dir);
+        if (bias32 && g == 0) ob[FB_B_DIR + 2 * col + qa2] = v;
+    }
+    {
+        const float v = fold(bs_feat);
+        if (bias64 && g == 0) ob[FB_B_FEAT + 4 * col + qa] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXL - 1; ++i) {
+        const float v = fold(bs_xyz[i]);
+        if (i <= L - 2 && bias64 && g == 0) ob[FB_B_XYZ + i * 64 + 4 * col + qa] = v;
+    }
+    {
+        const float v = fold(bs_l1);
+        if (bias64 && g == 0) ob[FB_B_L1 + 4 * col + qa] = v;
+    }
+}
+
+// out[o * out_ld + col0 + c] = sum_p partial[p][off + o * 64 + c] (c < cols), parts in index order; blockIdx.y = job.  The jobs
+// behind `first_bias` are bias vectors (rows entries at partial[p][off + o]).
+struct FbReduceJob { int32_t off, rows, cols, out_ld, out_col0; float* out; };
+constexpr int FB_MAX_JOBS = 2 * (FB_MAXL + 3);
+struct FbReduce { FbReduceJob job[FB_MAX_JOBS]; int32_t first_bias; };
+__global__ __launch_bounds__(256) void fb_reduce_kernel(const float* __restrict__ partial, const FbReduce rb, const int parts) {
+    const FbReduceJob j = rb.job[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool is_bias = (int)blockIdx.y >= rb.first_bias;
+    const int elems = is_bias ? j.rows : j.rows * j.cols;
+    if (t >= elems) return;
+    const int o = is_bias ? t : t / j.cols, c = is_bias ? 0 : t - o * j.cols;
+    const float* p = partial + j.off + (is_bias ? o : o * 64 + c);
+    float s = 0.0f;
+    int k = 0;
+    for (; k + 16 <= parts; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(k + u) * FB_PART];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; k < parts; ++k) s += p[(int64_t)k * FB_PART];
+    j.out[is_bias ? o : (int64_t)o * j.out_ld + j.out_col0 + c] = s;
+}
+
+static int fb_skip_layer(const nm_mlp* m, bool* ok) {
+    // the one trunk layer that takes cat(x, xyz) (bit i of skip_mask, i <= L - 2); *ok = 0 when there are several
+    int sk = -1, count = 0;
+    for (int i = 0; i <= m->desc.num_layers - 2; ++i)
+        if ((m->base.skip_mask >> i) & 1u) { sk = i; ++count; }
+    *ok = count <= 1;
+    return sk;
+}
+
+}  // namespace nm
+
+using namespace nm;
+
+extern "C" {
+
+int nm_mlp_backward_fused_supported(const nm_mlp* m, int64_t n) {
+    if (!m || m->lw || m->plan->generic_nt != 0 || m->precision != NM_PREC_F32) return 0;
+    if (const char* v = getenv("NM_FUSED_BACKWARD"))           // A/B hook of the tools and tests (read per call)
+        if (atoi(v) == 0) return 0;
+    const nm_mlp_desc& d = m->desc;
+    bool one_skip = false;
+    fb_skip_layer(m, &one_skip);
+    return d.hidden_size == 64 && d.use_viewdirs && d.num_layers >= 2 && d.num_layers <= FB_MAXL && one_skip && n > 0 &&
+           n % FB_ROWS == 0 && nm_mlp_tapes_encodings(m);
+}
+
+int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* m) {
+    return m ? (int64_t)(m->num_cus > 0 ? m->num_cus : 256) * FB_PART * 4 : 0;
+}
+
+int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance, const float* d_grad_radiance,
+                          float* d_last, const nm_mlp_param_grads* grads, void* d_workspace, void* stream_) {
+    NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && d_last && grads && d_workspace, "bad argument");
+    NM_REQUIRE(nm_mlp_backward_fused_supported(m, n), "this handle / sample count is not served by the fused backward (ask nm_mlp_backward_fused_supported)");
+    NM_REQUIRE(tape->d_h && tape->d_feat && tape->d_mask_h && tape->d_mask_v && tape->d_enc_xyz && tape->d_enc_dir, "incomplete tape");
+    const nm_mlp_desc& d = m->desc;
+    const int L = d.num_layers;
+    NM_REQUIRE(grads->layer1_weight && grads->layer1_bias && grads->feat_weight && grads->feat_bias && grads->dir_weight && grads->dir_bias,
+               "incomplete gradient buffers");
+    for (int i = 0; i <= L - 2; ++i) NM_REQUIRE(grads->xyz_weight[i] && grads->xyz_bias[i], "incomplete gradient buffers");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MlpBwdArgs a = m->bwd;
+    a.radiance = d_radiance; a.grad_out = d_grad_radiance;
+    a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
+    a.n = n; a.tiles = (n + 15) / 16;
+    a.d_last = d_last;
+    bool one_skip = false;
+    FusedBwdArgs fa;
+    fa.tape_h = tape->d_h; fa.tape_feat = tape->d_feat; fa.enc_x = tape->d_enc_xyz; fa.enc_d = tape->d_enc_dir;
+    fa.partial = static_cast<float*>(d_workspace);
+    fa.skip_layer = fb_skip_layer(m, &one_skip);
+    const int cus = m->num_cus > 0 ? m->num_cus : 256;
+    const int64_t wg_iters = n / FB_ROWS;
+    const int grid = (int)(wg_iters < cus ? wg_iters : cus);
+    const auto kernel = L <= 4 ? &mlp_backward_dw64_kernel<4> : &mlp_backward_dw64_kernel<FB_MAXL>;
+    if (int rc = ensure_dynamic_lds((const void*)kernel, FB_LDS)) return rc;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), FB_LDS, stream, a, fa, L);
+    // ---- the order-fixed reduction of the per-workgroup partials into the gradient tensors
+    const int dx = 6 * d.num_encoding_fn_xyz + (d.include_input_xyz ? 3 : 0), dd = 6 * d.num_encoding_fn_dir + (d.include_input_dir ? 3 : 0);
+    FbReduce rb;
+    int nj = 0;
+    auto job = [&](int off, int rows, int cols, int ld, int col0, float* out) { rb.job[nj++] = FbReduceJob{off, rows, cols, ld, col0, out}; };
+    job(FB_P_DIRF, 32, 64, 64 + dd, 0, grads->dir_weight);
+    if (dd > 0) job(FB_P_DIRE, 32, dd, 64 + dd, 64, grads->dir_weight);
+    job(FB_P_FEAT, 64, 64, 64, 0, grads->feat_weight);
+    for (int i = 0; i <= L - 2; ++i) {
+        const bool skip = i == fa.skip_layer;
+        job(FB_P_XYZ + i * 4096, 64, 64, skip ? 64 + dx : 64, 0, grads->xyz_weight[i]);
+        if (skip) job(FB_P_SKIP, 64, dx, 64 + dx, 64, grads->xyz_weight[i]);
+    }
+    job(FB_P_L1, 64, dx, dx, 0, grads->layer1_weight);
+    rb.first_bias = nj;
+    job(FB_P_BIAS + FB_B_DIR, 32, 1, 1, 0, grads->dir_bias);
+    job(FB_P_BIAS + FB_B_FEAT, 64, 1, 1, 0, grads->feat_bias);
+    for (int i = 0; i <= L - 2; ++i) job(FB_P_BIAS + FB_B_XYZ + i * 64, 64, 1, 1, 0, grads->xyz_bias[i]);
+    job(FB_P_BIAS + FB_B_L1, 64, 1, 1, 0, grads->layer1_bias);
+    hipLaunchKernelGGL(fb_reduce_kernel, dim3(16, nj), dim3(256), 0, stream, fa.partial, rb, grid);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib, hip_ops
-from ._lib import BundleGrads, MlpDeltas, MlpTape, MlpWeights, WeightGradJob, check
+from ._lib import BundleGrads, MlpDeltas, MlpParamGrads, MlpTape, MlpWeights, WeightGradJob, check
 from .hip_ops import _dev32, _ptr, _stream
 
 
@@ -234,6 +234,8 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     n = radiance.numel() // 4
     f32 = dict(dtype=torch.float32, device=mlp.device)
     flat = not d.get("use_viewdirs", True)
+    if tape.get("enc_x") is not None and tape.get("enc_d") is not None and lib.nm_mlp_backward_fused_supported(mlp.handle, n):
+        return _backward_fused(mlp, tape, radiance, grad_radiance, n)
     dh, dlast = torch.empty(L, n, H, **f32), torch.empty(n, 4, **f32)
     dfeat, dv = (None, None) if flat else (torch.empty(n, H, **f32), torch.empty(n, H // 2, **f32))
     ct = _tape_struct(tape)
@@ -296,6 +298,40 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         g["fc_out.weight"], g["fc_out.bias"] = _head_grad(mlp, dlast, h[L - 1], bias=True)
         return g
     (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, h[L - 1], bias=True), _head_grad(mlp, dlast, v)
+    g["fc_alpha.weight"], g["fc_alpha.bias"] = gh[3:4], last_sums[3:4]
+    g["fc_rgb.weight"], g["fc_rgb.bias"] = gv[:3], last_sums[:3]
+    return g
+
+
+def _backward_fused(mlp, tape, radiance, grad_radiance, n):
+    """The 64-wide networks (BASELINE config 1's 4x64): delta chain and every trunk / view-layer weight gradient in ONE kernel
+    (nm_mlp_backward_fused, nerf_bwd_fused.hip) -- no delta row is written, the tape is read once --, then the two 4-row heads
+    from d_last as on the general path."""
+    lib = _lib.load()
+    d = mlp.desc
+    L, H, skip_step = int(d["num_layers"]), int(d["hidden_size"]), int(d["skip_step"])
+    f32 = dict(dtype=torch.float32, device=mlp.device)
+    dx = 6 * int(d["num_encoding_fn_xyz"]) + (3 if d.get("include_input_xyz", True) else 0)
+    dd = 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
+    is_skip = lambda i: i % skip_step == 0 and i > 0 and i != L - 1   # noqa: E731  (cat(x, xyz): models.py:64-65)
+    g = {"layer1.weight": torch.empty(H, dx, **f32), "layer1.bias": torch.empty(H, **f32),
+         "fc_feat.weight": torch.empty(H, H, **f32), "fc_feat.bias": torch.empty(H, **f32),
+         "layers_dir.0.weight": torch.empty(H // 2, H + dd, **f32), "layers_dir.0.bias": torch.empty(H // 2, **f32)}
+    pg = MlpParamGrads()
+    for i in range(L - 1):
+        g[f"layers_xyz.{i}.weight"] = torch.empty(H, H + (dx if is_skip(i) else 0), **f32)
+        g[f"layers_xyz.{i}.bias"] = torch.empty(H, **f32)
+        pg.xyz_weight[i], pg.xyz_bias[i] = _ptr(g[f"layers_xyz.{i}.weight"]), _ptr(g[f"layers_xyz.{i}.bias"])
+    pg.layer1_weight, pg.layer1_bias = _ptr(g["layer1.weight"]), _ptr(g["layer1.bias"])
+    pg.feat_weight, pg.feat_bias = _ptr(g["fc_feat.weight"]), _ptr(g["fc_feat.bias"])
+    pg.dir_weight, pg.dir_bias = _ptr(g["layers_dir.0.weight"]), _ptr(g["layers_dir.0.bias"])
+    dlast = torch.empty(n, 4, **f32)
+    ws = _workspace(mlp, "fused_bwd", int(lib.nm_mlp_backward_fused_workspace_bytes(mlp.handle)))
+    ct = _tape_struct(tape)
+    with _stage("delta"):        # delta chain + weight gradients: one launch + one reduction
+        check(lib.nm_mlp_backward_fused(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), _ptr(dlast), C.byref(pg),
+                                        _ptr(ws), _stream()), "nm_mlp_backward_fused")
+    (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, tape["h"][L - 1], bias=True), _head_grad(mlp, dlast, tape["v"])
     g["fc_alpha.weight"], g["fc_alpha.bias"] = gh[3:4], last_sums[3:4]
     g["fc_rgb.weight"], g["fc_rgb.bias"] = gv[:3], last_sums[:3]
     return g

@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
-    assert lib.nm_abi_version() == 5
+    assert lib.nm_abi_version() == 6
 
 
 def test_no_cpu_fallback_in_product():
