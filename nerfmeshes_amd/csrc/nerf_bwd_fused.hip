@@ -13,8 +13,8 @@
 // Dataflow of one workgroup iteration (128 samples = 8 waves x one 16-sample MFMA tile):
 //   * the delta chain as in mlp_backward_kernel: a wave's tile stays in registers (D layout of stage k == B layout of stage
 //     k + 1), the transposed weights stream L2 -> LDS through the 2-slot ring of mlp_device.h, ReLU' from the taped bit masks;
-//   * each delta, once masked, is ALSO written to an LDS tile [sample][feature] (16-byte chunks XOR-swizzled by the sample so
-//     that the 16 lanes of a store hit 16 different bank groups);
+//   * each delta, once masked, is ALSO written to an LDS tile [sample][feature] (planar and swizzled: fb_write_delta -- the
+//     weight-gradient products' 4-byte operand reads are conflict-free);
 //   * the activation rows that delta contracts with (tape_h[i] / tape_feat / the encoding rows: 128 consecutive 256-byte rows =
 //     one contiguous 32 KB run) are DMA'd HBM -> LDS by scalar-addressed buffer_load ... lds one delta ahead into a 3-slot ring;
 //   * every wave owns 2 of the 16 output tiles of each 64 x 64 product (1 of the 8 tiles of the 32 x 64 view-layer products)
@@ -69,16 +69,27 @@ __device__ __forceinline__ void fb_dma_rows(const float* rows, char* dst, int wa
     }
 }
 
-// this lane's rows of a delta (D layout: tile nt, register r = feature 16 nt + 4 g + r of sample `col` of the wave's tile) into
-// the LDS delta tile: chunk c = 4 nt + g of row s lands at chunk c ^ (s & 15)
+// The LDS delta tile, [sample][64 words], is PLANAR: word position of feature f of sample s =
+//     (plane << 4 | index) ^ swz(s),   swz(s) = (s & 1) << 4 | ((s >> 1) & 7) << 1,
+// with plane = f & 3, index = f >> 2 for a 64-wide delta (plane = f & 1, index = f >> 1 for the 32-wide view delta): the 16 rows
+// of an A tile (features 4 i + q, resp. 2 i + q) are 16 consecutive words, and the samples 4 ks + k a ds_read_b32's lane groups
+// fetch together (k = 0, 1 | 2, 3) land in different halves of the 32 banks -- the reads are conflict-free (the row-major tile
+// of the first version cost 4 LDS cycles per lane group: bank = word mod 32 for 4-byte accesses, MI355X_MICROARCH.md, LDS).
+// A lane of the chain holds features 16 nt + 4 g + r of sample `col` of its wave's tile (D layout): 16 (8) ds_write_b32, whose
+// 32-lane groups (g & 1, col) cover all 32 banks.
+__device__ __forceinline__ unsigned fb_swz(int s) { return ((s & 1) << 4) | (((s >> 1) & 7) << 1); }
+
 template <int NT>
 __device__ __forceinline__ void fb_write_delta(char* dbuf, const float (&v)[4 * NT], int wave, int g, int col) {
-    char* row = dbuf + (wave * 16 + col) * FB_ROWB;
+    float* row = reinterpret_cast<float*>(dbuf + (wave * 16 + col) * FB_ROWB);
+    const unsigned sw = fb_swz(col);                                  // s & 15 == col
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 v4 = {v[4 * nt], v[4 * nt + 1], v[4 * nt + 2], v[4 * nt + 3]};
-        *reinterpret_cast<f32x4*>(row + (((4 * nt + g) ^ col) << 4)) = v4;
-    }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned pos = NT == 4 ? (unsigned)((r << 4) | (4 * nt + g)) : (unsigned)(((r & 1) << 4) | (8 * nt + 2 * g + (r >> 1)));
+            row[pos ^ sw] = v[4 * nt + r];
+        }
 }
 
 // KS k-steps of a 4-tile stage out of one ring slot (operands of the next k-step in flight, as gemm_stage's PIPE); no barrier
@@ -96,9 +107,9 @@ __device__ __forceinline__ void fb_chunk(f32x4 (&acc)[4], const float (&b)[NB], 
 }
 
 // One weight-gradient product of this wave over the 128 samples of the delta tile: TB = 2 tiles (64 x 64 products) or 1 (the
-// 32 x 64 view-layer products).  a_ptr: this lane's A address for k-groups = 0 (mod 4) -- the swizzle of k-group ks is an XOR of
-// bits 6..7 with ks & 3 --, b_ptr: this lane's B address in the slot.  Operands are fetched 4 k-groups ahead of their MFMAs.
-template <int TB>
+// 32 x 64 view-layer products).  a_off: this lane's A address for k-groups = 0 (mod 4) -- the swizzle of k-group ks adds an XOR of
+// word bits 2..3 with ks & 3 --, b_ptr: this lane's B address in the slot.  Operands are fetched 4 k-groups ahead of their MFMAs.
+template <int TB, int ABL = 0>
 __device__ __forceinline__ void fb_dw_step(f32x4 (&acc)[TB], float& bsum, const char* lds, const unsigned a_off, const char* b_ptr) {
     constexpr int PF = 4, NBATCH = (FB_ROWS / 4) / PF;
     float a[2][PF];
@@ -106,8 +117,10 @@ __device__ __forceinline__ void fb_dw_step(f32x4 (&acc)[TB], float& bsum, const 
     auto fetch = [&](int kb, int buf) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            a[buf][j] = *reinterpret_cast<const float*>(lds + ((a_off ^ (unsigned)(j << 6)) + kb * (PF * 1024) + j * 1024));
-            if constexpr (TB == 2) b[buf][j] = *reinterpret_cast<const f32x2*>(b_ptr + kb * (PF * 1024) + j * 1024);
+            if constexpr (ABL & 32) a[buf][j] = 1.0f + kb;
+            else a[buf][j] = *reinterpret_cast<const float*>(lds + ((a_off ^ (unsigned)(j << 4)) + kb * (PF * 1024) + j * 1024));
+            if constexpr (ABL & 16) b[buf][j] = f32x2{a[buf][j], 2.0f};
+            else if constexpr (TB == 2) b[buf][j] = *reinterpret_cast<const f32x2*>(b_ptr + kb * (PF * 1024) + j * 1024);
             else b[buf][j][0] = *reinterpret_cast<const float*>(b_ptr + kb * (PF * 1024) + j * 1024);
         }
     };
@@ -136,7 +149,8 @@ __device__ __forceinline__ void fb_wait_barrier(int pieces_in_flight) {
 }
 
 // MAXL: the num_layers an instantiation holds accumulators for (4: 56 registers per wave, 8: 88); the partial layout is MAXL 8's
-template <int MAXL>
+// ABL: timing ablations of tests/tools/probes/fb_probe.hip (1: no dW products, 2: no row DMA, 4: no chain MFMAs, 8: no delta tile, 16 / 32: no B / A operand reads); 0 in the library
+template <int MAXL, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdArgs args, const FusedBwdArgs fa, const int L) {
     constexpr int H = 64, KH = 16, KD = 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -152,9 +166,9 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     // ---- this wave's output tiles and the operand addresses that go with them
     const int qa = wave >> 1, qb0 = 2 * (wave & 1);        // 64 x 64: tiles (qa, qb0), (qa, qb0 + 1); tile q row i = feature 4 i + q
     const int qa2 = wave >> 2, qb2 = wave & 3;             // 32 x 64: tile (qa2, qb2); A row i = feature 2 i + qa2
-    // A of k-group ks: sample 4 ks + g, whose swizzle is 4 (ks & 3) + g: chunk c ^ g here, bits 2..3 of the chunk by ks in fb_dw_step
-    const unsigned a_off64 = FB_OFF_DBUF + g * FB_ROWB + ((col ^ g) << 4) + qa * 4;
-    const unsigned a_off32 = FB_OFF_DBUF + g * FB_ROWB + (((col >> 1) ^ g) << 4) + (2 * (col & 1) + qa2) * 4;
+    // A of k-group ks: sample 4 ks + g, word (q << 4 | col) ^ swz(4 ks + g); swz = (g & 1) << 4 | (g >> 1) << 1 here, (ks & 3) << 2 in fb_dw_step
+    const unsigned a_off64 = FB_OFF_DBUF + g * FB_ROWB + 4 * ((unsigned)((qa << 4) | col) ^ (unsigned)(((g & 1) << 4) | ((g >> 1) << 1)));
+    const unsigned a_off32 = FB_OFF_DBUF + g * FB_ROWB + 4 * ((unsigned)((qa2 << 4) | col) ^ (unsigned)(((g & 1) << 4) | ((g >> 1) << 1)));
     const int b_off64 = g * FB_ROWB + col * 16 + qb0 * 4;
     const int b_off32 = g * FB_ROWB + col * 16 + qb2 * 4;
     const bool bias64 = (wave & 1) == 0, bias32 = qb2 == 0;
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     int bissue = 0;         // activation slot the next DMA goes to
     auto slot_ptr = [&](int s) { return lds + FB_OFF_SLOT + s * FB_SLOT; };
     auto next_slot = [](int s) { return s == FB_NSLOT - 1 ? 0 : s + 1; };
-    auto issue_rows = [&](const float* rows) { fb_dma_rows(rows, slot_ptr(bissue), wave); bissue = next_slot(bissue); };
+    auto issue_rows = [&](const float* rows) { if constexpr (!(ABL & 2)) fb_dma_rows(rows, slot_ptr(bissue), wave); bissue = next_slot(bissue); };
 
     int64_t it = blockIdx.x;
     f32x4 go = {0.f, 0.f, 0.f, 0.f}, y = go;
@@ -228,11 +242,11 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
         // ---- phase A0: delta_v -> LDS; layers_dir.0^T (hidden columns), one chunk
         {
             const uint64_t m = mrow[(int64_t)(L - 1) * mstride];
-            fb_write_delta<2>(dbuf, dv, wave, g, col);
+            if constexpr (!(ABL & 8)) fb_write_delta<2>(dbuf, dv, wave, g, col);
             stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);      // fc_feat^T chunk 0
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            fb_chunk<KD, 0, KD>(acc, dv, lds + par * FB_CHUNK + lane * 16);
+            if constexpr (!(ABL & 4)) fb_chunk<KD, 0, KD>(acc, dv, lds + par * FB_CHUNK + lane * 16);
             fb_wait_barrier(0);
             par ^= 1;
             gw += FB_CHUNK;
@@ -244,10 +258,10 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
         // ---- phase B0: grad(layers_dir.0) = delta_v^T @ [feat | view encoding] (models.py:72-73)
         {
             issue_rows(fa.tape_h + ((int64_t)(L - 1) * args.n + row0) * 64);
-            fb_dw_step<1>(acc_dirf, bs_dir, lds, a_off32, slot_ptr(bslot) + b_off32);
+            if constexpr (!(ABL & 1)) fb_dw_step<1, ABL>(acc_dirf, bs_dir, lds, a_off32, slot_ptr(bslot) + b_off32);
             bslot = next_slot(bslot);
             float unused = 0.f;
-            fb_dw_step<1>(acc_dire, unused, lds, a_off32, slot_ptr(bslot) + b_off32);
+            if constexpr (!(ABL & 1)) fb_dw_step<1, ABL>(acc_dire, unused, lds, a_off32, slot_ptr(bslot) + b_off32);
             bslot = next_slot(bslot);
             fb_wait_barrier(4);
         }
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
         {
             const uint64_t m = mrow[(int64_t)(L - 2) * mstride];
             // ---- phase A1
-            fb_write_delta<4>(dbuf, in, wave, g, col);
+            if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
             stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
             const float* wa = lds_walpha + g * (H / 4);
 #pragma unroll
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(wa + 4 * nt);
                 acc[nt] = f32x4{w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
             }
-            fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+            if constexpr (!(ABL & 4)) fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             fb_wait_barrier(0);
             par ^= 1;
             // ---- phase B1: the first chunk of layers_xyz[L-2]^T (or, for a one-layer trunk, of the next iteration) | rows of delta 2
@@ -276,8 +290,8 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             } else {
                 issue_rows(fa.enc_x + row0 * 64);
             }
-            fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
-            fb_dw_step<2>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
+            if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+            if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
             bslot = next_slot(bslot);
             fb_wait_barrier(flying);
             par ^= 1;
@@ -294,11 +308,11 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 uint64_t m = ~uint64_t(0);
                 if (i > 0) m = mrow[(int64_t)(i - 1) * mstride];
                 // ---- phase A
-                fb_write_delta<4>(dbuf, in, wave, g, col);
+                if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
                 stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+                if constexpr (!(ABL & 4)) fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
                 fb_wait_barrier(0);
                 par ^= 1;
                 // ---- phase B
@@ -310,12 +324,12 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 } else {
                     issue_rows(fa.enc_x + row0 * 64);                      // layer1 contracts with the encoding rows
                 }
-                fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
-                fb_dw_step<2>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
+                if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+                if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
                 bslot = next_slot(bslot);
                 if (sk == i) {                                             // cat(x, xyz): the encoding columns (models.py:64-65)
                     float unused = 0.f;
-                    fb_dw_step<2>(acc_skip, unused, lds, a_off64, slot_ptr(bslot) + b_off64);
+                    if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_skip, unused, lds, a_off64, slot_ptr(bslot) + b_off64);
                     bslot = next_slot(bslot);
                 }
                 fb_wait_barrier(flying);
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             }
         }
         // ================= delta L+1: at layer1's output (no activation, models.py:62): grad(layer1) = delta^T @ xyz encoding
-        fb_write_delta<4>(dbuf, in, wave, g, col);
+        if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
         fb_wait_barrier(0);
         int flying = 0;
         if (has_next) {
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             issue_rows(fa.enc_d + (it + gridDim.x) * (FB_ROWS * 64));
             flying = 8;
         }
-        fb_dw_step<2>(acc_l1, bs_l1, lds, a_off64, slot_ptr(bslot) + b_off64);
+        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_l1, bs_l1, lds, a_off64, slot_ptr(bslot) + b_off64);
         bslot = next_slot(bslot);
         fb_wait_barrier(flying);
     }
@@ -415,6 +429,7 @@ __global__ __launch_bounds__(256) void fb_reduce_kernel(const float* __restrict_
     j.out[is_bias ? o : (int64_t)o * j.out_ld + j.out_col0 + c] = s;
 }
 
+#ifndef NM_FB_KERNEL_ONLY
 static int fb_skip_layer(const nm_mlp* m, bool* ok) {
     // the one trunk layer that takes cat(x, xyz) (bit i of skip_mask, i <= L - 2); *ok = 0 when there are several
     int sk = -1, count = 0;
@@ -497,3 +512,6 @@ int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const f
 }
 
 }  // extern "C"
+#else
+}  // namespace nm
+#endif  // NM_FB_KERNEL_ONLY (tests/tools/probes/fb_probe.hip includes the kernels alone)
