@@ -264,6 +264,11 @@ typedef struct nm_mlp_tape {
      * Columns beyond the encoding's width are not written. */
     float* d_enc_xyz;    /* (n, 64) or NULL                                                         */
     float* d_enc_dir;    /* (n, 64) or NULL                                                         */
+    /* ABI v6: floats between consecutive rows of d_v; 0 = H/2 (contiguous rows).  Tuned-family handles only.  The 64-wide
+     * networks' fused backward wants the 32-float rows of d_v INSIDE the direction-encoding rows -- d_v = d_enc_dir + 32,
+     * v_stride = 64: an encoding row is 27 floats of its 64 -- so that one block of rows feeds both layers_dir[0]'s and fc_rgb's
+     * weight gradients (nm_mlp_backward_fused). */
+    int32_t v_stride;
 } nm_mlp_tape;
 /* 1 when nm_mlp_forward_train on this handle fills d_enc_xyz / d_enc_dir (when given), 0 when the caller still needs
  * nm_encode_samples_strided. */
@@ -294,8 +299,10 @@ int nm_mlp_backward(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float
  * nm_mlp_backward AND the weight / bias gradients of layer1, layers_xyz[*], fc_feat and layers_dir[0] -- what loss.backward()
  * leaves in the .grad of those parameters under NeRFModel.training_step (src/models/model_nerf.py:88-151, through
  * FlexibleNeRFModel.forward, src/nerf/models.py:60-80) -- without a delta row ever reaching HBM (the tape is read once, the
- * per-workgroup partials of all products are added up by one order-fixed reduction: deterministic).  What is left to the
- * caller are the two 4-row heads: d_last (n, 4) is written as by nm_mlp_backward; fc_alpha / fc_rgb = nm_head_grad_ex of it.
+ * per-workgroup partials of all products are added up by one order-fixed reduction: deterministic).  The two 4-row heads
+ * (fc_alpha, fc_rgb) are products of the same kernel: their delta d_last (n, 4) is staged in LDS next to the layers' deltas; it
+ * is also written to d_last when that is not NULL (as nm_mlp_backward does).  The tape must hold the view layer's activation
+ * rows inside the direction-encoding rows (nm_mlp_tape.v_stride: d_v = d_enc_dir + 32, v_stride = 64).
  * Served: tuned-family fp32 handles with hidden_size 64, use_viewdirs = 1, 2 <= num_layers <= 8, at most one skip layer, that
  * tape their encodings (nm_mlp_tapes_encodings; tape->d_enc_xyz / d_enc_dir must be given), n a multiple of 128 -- ask
  * nm_mlp_backward_fused_supported; everything else takes nm_mlp_backward + nm_weight_grad_batch.  Wider networks do not fit:
@@ -312,6 +319,10 @@ typedef struct nm_mlp_param_grads {
     float* feat_bias;
     float* dir_weight;
     float* dir_bias;
+    float* alpha_weight;                      /* fc_alpha (1, H), (1,) */
+    float* alpha_bias;
+    float* rgb_weight;                        /* fc_rgb (3, H / 2), (3,) */
+    float* rgb_bias;
 } nm_mlp_param_grads;
 int nm_mlp_backward_fused_supported(const nm_mlp* mlp, int64_t n);
 int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* mlp);

@@ -35,7 +35,7 @@ class BundleOut(C.Structure):
 
 
 class MlpTape(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v", "d_enc_xyz", "d_enc_dir")]
+    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v", "d_enc_xyz", "d_enc_dir")] + [("v_stride", C.c_int32)]
 
 
 class MlpDeltas(C.Structure):
@@ -44,7 +44,8 @@ class MlpDeltas(C.Structure):
 
 class MlpParamGrads(C.Structure):          # nm_mlp_param_grads (ABI v6: nm_mlp_backward_fused)
     _fields_ = [("layer1_weight", c_void_p), ("layer1_bias", c_void_p), ("xyz_weight", c_void_p * 8), ("xyz_bias", c_void_p * 8),
-                ("feat_weight", c_void_p), ("feat_bias", c_void_p), ("dir_weight", c_void_p), ("dir_bias", c_void_p)]
+                ("feat_weight", c_void_p), ("feat_bias", c_void_p), ("dir_weight", c_void_p), ("dir_bias", c_void_p),
+                ("alpha_weight", c_void_p), ("alpha_bias", c_void_p), ("rgb_weight", c_void_p), ("rgb_bias", c_void_p)]
 
 
 class WeightGradJob(C.Structure):

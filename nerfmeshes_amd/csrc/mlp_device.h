@@ -486,7 +486,7 @@ __global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kern
         gw = args.wstream;
         acc_to_operand<N::NTD, true>(accd, v);
         if constexpr (TAPE) {
-            store_rows<N::NTD>(args.tape_v, H / 2, sample, valid, v, g);
+            store_rows<N::NTD>(args.tape_v, args.tape_v_ld, sample, valid, v, g);
             if (tile < args.tiles) args.mask_v[tile * 64 + lane] = positive_mask(v);
         }
 

@@ -42,13 +42,17 @@ constexpr int FB_SLOT = FB_ROWS * FB_ROWB;         // 32 KB: a block of activati
 constexpr int FB_NSLOT = 3;
 constexpr int FB_OFF_SLOT = FB_OFF_DBUF + FB_ROWS * FB_ROWB;
 constexpr int FB_OFF_HEADS = FB_OFF_SLOT + FB_NSLOT * FB_SLOT;
-constexpr int FB_LDS = FB_OFF_HEADS + 1024;        // 148 480 B: one workgroup per CU
+constexpr int FB_OFF_DL = FB_OFF_HEADS + 1024;     // the heads' delta tile: 128 rows of 16 floats (rgb x3, sigma, twelve zeros)
+constexpr int FB_LDS = FB_OFF_DL + FB_ROWS * 64;   // 156 672 B: one workgroup per CU
 constexpr int FB_MAXL = 8;
 // one workgroup's partial, in floats: [dir x feat 32x64][dir x enc_d 32x64][feat][xyz 0..6][skip][layer1] then the bias sums
 constexpr int FB_P_DIRF = 0, FB_P_DIRE = 2048, FB_P_FEAT = 4096, FB_P_XYZ = 8192, FB_P_SKIP = FB_P_XYZ + (FB_MAXL - 1) * 4096,
               FB_P_L1 = FB_P_SKIP + 4096, FB_P_BIAS = FB_P_L1 + 4096;
 constexpr int FB_B_DIR = 0, FB_B_FEAT = 64, FB_B_XYZ = 128, FB_B_L1 = FB_B_XYZ + (FB_MAXL - 1) * 64;
-constexpr int FB_PART = FB_P_BIAS + FB_B_L1 + 64;
+// the two 4-row heads: [column tile][4 rows][16 columns] -- fc_rgb over the columns 32..63 of the direction rows (2 tiles), fc_alpha
+// over the 64 columns of h[L-1] (4 tiles) --, then the column sums of d_last [4]; the waves' k-parts are added up in LDS first
+constexpr int FB_P_HEAD = FB_P_BIAS + FB_B_L1 + 64, FB_H_RGB = 0, FB_H_ALPHA = 128, FB_H_BIAS = 384;
+constexpr int FB_PART = FB_P_HEAD + FB_H_BIAS + 16;
 
 struct FusedBwdArgs {
     const float* tape_h;      // (L, n, 64)
@@ -82,7 +86,8 @@ __device__ __forceinline__ unsigned fb_swz(int s) { return ((s & 1) << 4) | (((s
 template <int NT>
 __device__ __forceinline__ void fb_write_delta(char* dbuf, const float (&v)[4 * NT], int wave, int g, int col) {
     float* row = reinterpret_cast<float*>(dbuf + (wave * 16 + col) * FB_ROWB);
-    const unsigned sw = fb_swz(col);                                  // s & 15 == col
+    unsigned sw = fb_swz(col);                                        // s & 15 == col
+    asm volatile("" : "+v"(sw));      // the 16 word offsets below are recomputed per call (one v_xor each), not kept in 16 registers
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -111,30 +116,63 @@ __device__ __forceinline__ void fb_chunk(f32x4 (&acc)[4], const float (&b)[NB], 
 // word bits 2..3 with ks & 3 --, b_ptr: this lane's B address in the slot.  Operands are fetched 4 k-groups ahead of their MFMAs.
 template <int TB, int ABL = 0>
 __device__ __forceinline__ void fb_dw_step(f32x4 (&acc)[TB], float& bsum, const char* lds, const unsigned a_off, const char* b_ptr) {
+    // Batches of 4 k-groups, two per trip of a REAL loop (fully unrolled, the compiler issued all 32 operand reads of a product
+    // up front: 60 registers more than the two batches in flight here, and the kernel spilled).
     constexpr int PF = 4, NBATCH = (FB_ROWS / 4) / PF;
-    float a[2][PF];
-    f32x2 b[2][PF];
-    auto fetch = [&](int kb, int buf) {
+    static_assert(NBATCH % 2 == 0, "two batches per trip");
+    float a0[PF], a1[PF];
+    f32x2 b0[PF], b1[PF];
+    const char* ap[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) ap[j] = lds + (a_off ^ (unsigned)(j << 4)) + j * 1024;     // k-group 4 kb + j: swizzle term j << 2 words
+    auto fetch = [&](float (&a)[PF], f32x2 (&b)[PF], int byte_off) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            if constexpr (ABL & 32) a[buf][j] = 1.0f + kb;
-            else a[buf][j] = *reinterpret_cast<const float*>(lds + ((a_off ^ (unsigned)(j << 4)) + kb * (PF * 1024) + j * 1024));
-            if constexpr (ABL & 16) b[buf][j] = f32x2{a[buf][j], 2.0f};
-            else if constexpr (TB == 2) b[buf][j] = *reinterpret_cast<const f32x2*>(b_ptr + kb * (PF * 1024) + j * 1024);
-            else b[buf][j][0] = *reinterpret_cast<const float*>(b_ptr + kb * (PF * 1024) + j * 1024);
+            if constexpr (ABL & 32) a[j] = 1.0f + j;
+            else a[j] = *reinterpret_cast<const float*>(ap[j] + byte_off);
+            if constexpr (ABL & 16) b[j] = f32x2{a[j], 2.0f};
+            else if constexpr (TB == 2) b[j] = *reinterpret_cast<const f32x2*>(b_ptr + byte_off + j * 1024);
+            else b[j][0] = *reinterpret_cast<const float*>(b_ptr + byte_off + j * 1024);
         }
     };
-    fetch(0, 0);
-#pragma unroll
-    for (int kb = 0; kb < NBATCH; ++kb) {
-        const int cur = kb & 1;
-        if (kb + 1 < NBATCH) fetch(kb + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
+    auto mfmas = [&](const float (&a)[PF], const f32x2 (&b)[PF]) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
 #pragma unroll
-            for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][j], b[cur][j][t], acc[t], 0, 0, 0);
-            bsum += a[cur][j];      // column sums of delta = the bias gradient (used from the waves that own column tile 0)
+            for (int t = 0; t < TB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][t], acc[t], 0, 0, 0);
+            bsum += a[j];      // column sums of delta = the bias gradient (used from the waves that own column tile 0)
+        }
+    };
+    fetch(a0, b0, 0);
+#pragma unroll 1
+    for (int off = 0; off < NBATCH * PF * 1024; off += 2 * PF * 1024) {
+        fetch(a1, b1, off + PF * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a0, b0);
+        if (off + 2 * PF * 1024 < NBATCH * PF * 1024) fetch(a0, b0, off + 2 * PF * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a1, b1);
+    }
+}
+
+// A 4-row head product (fc_rgb / fc_alpha, models.py:71,75): A = the heads' delta tile (row s = 16 floats, 4 live), B = 16 natural
+// columns of a row block; this wave takes the k-groups kpar, kpar + KS, ...: 32 / KS MFMAs on one accumulator.  a_ptr / b_ptr: this
+// lane's operand addresses of k-group kpar.
+template <int KS>
+__device__ __forceinline__ void fb_head_step(f32x4& acc, float& bsum, const char* a_ptr, const char* b_ptr) {
+    constexpr int N = (FB_ROWS / 4) / KS;
+#pragma unroll
+    for (int q0 = 0; q0 < N; q0 += 4) {
+        float a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = *reinterpret_cast<const float*>(a_ptr + (q0 + q) * (KS * 256));
+            b[q] = *reinterpret_cast<const float*>(b_ptr + (q0 + q) * (KS * 1024));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc, 0, 0, 0);
+            bsum += a[q];
         }
     }
 }
@@ -158,6 +196,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     float* lds_wrgb = lds_walpha + H;                                   // [3][4][H/8]
     for (int i = threadIdx.x; i < H; i += 512) lds_walpha[i] = args.walpha[i];
     for (int i = threadIdx.x; i < 3 * H / 2; i += 512) lds_wrgb[i] = args.wrgb[i];
+    for (int i = threadIdx.x; i < FB_ROWS * 16; i += 512) reinterpret_cast<float*>(lds + FB_OFF_DL)[i] = 0.0f;   // columns 4..15 stay zero
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, col = lane & 15;
@@ -172,6 +211,12 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     const int b_off64 = g * FB_ROWB + col * 16 + qb0 * 4;
     const int b_off32 = g * FB_ROWB + col * 16 + qb2 * 4;
     const bool bias64 = (wave & 1) == 0, bias32 = qb2 == 0;
+    // the heads: fc_rgb = natural column tile 2 + (wave & 1) of the direction rows, k-groups = wave >> 1 (mod 4); fc_alpha = column tile
+    // wave & 3 of h[L-1], k-groups = wave >> 2 (mod 2).  A: row 4 ks + g of the heads' delta tile, word col
+    const int hr_t = 2 + (wave & 1), hr_k = wave >> 1, ha_t = wave & 3, ha_k = wave >> 2;
+    const char* const dl_lane = lds + FB_OFF_DL + g * 64 + col * 4;
+    f32x4 acc_rgb = {0.f, 0.f, 0.f, 0.f}, acc_alpha = acc_rgb;
+    float bs_head = 0.f;
 
     f32x4 acc_dirf[1] = {{0.f, 0.f, 0.f, 0.f}}, acc_dire[1] = {{0.f, 0.f, 0.f, 0.f}};
     f32x4 acc_feat[2], acc_skip[2], acc_l1[2], acc_xyz[MAXL - 1][2];
@@ -227,7 +272,8 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
         const float dsigma = go[3];
         if (g == 0) {
             const f32x4 o4 = {drgb[0], drgb[1], drgb[2], dsigma};
-            *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = o4;
+            if (args.d_last) *reinterpret_cast<f32x4*>(args.d_last + 4 * sample) = o4;
+            *reinterpret_cast<f32x4*>(lds + FB_OFF_DL + (wave * 16 + col) * 64) = o4;      // visible behind phase A0's barrier
         }
         float dv[KD];
 #pragma unroll
@@ -262,6 +308,8 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             bslot = next_slot(bslot);
             float unused = 0.f;
             if constexpr (!(ABL & 1)) fb_dw_step<1, ABL>(acc_dire, unused, lds, a_off32, slot_ptr(bslot) + b_off32);
+            // grad(fc_rgb) = d_last^T @ v: the view layer's activation rows are the columns 32..63 of the direction rows (models.py:75)
+            if constexpr (!(ABL & 1)) fb_head_step<4>(acc_rgb, unused, dl_lane + hr_k * 256, slot_ptr(bslot) + hr_k * 1024 + g * FB_ROWB + (16 * hr_t + col) * 4);
             bslot = next_slot(bslot);
             fb_wait_barrier(4);
         }
@@ -292,6 +340,8 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             }
             if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
+            // grad(fc_alpha) = d_last^T @ h[L-1] (row 3; models.py:71), and the column sums of d_last = both heads' bias gradients
+            if constexpr (!(ABL & 1)) fb_head_step<2>(acc_alpha, bs_head, dl_lane + ha_k * 256, slot_ptr(bslot) + ha_k * 1024 + g * FB_ROWB + (16 * ha_t + col) * 4);
             bslot = next_slot(bslot);
             fb_wait_barrier(flying);
             par ^= 1;
@@ -401,12 +451,35 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
         const float v = fold(bs_l1);
         if (bias64 && g == 0) ob[FB_B_L1 + 4 * col + qa] = v;
     }
+    // the heads: D rows 0..3 (the live rows of the delta tile) are registers 0..3 of lane group 0.  The waves that split a tile's
+    // k-groups between them add their accumulators up through LDS, in k-part order (deterministic): one partial per workgroup
+    float* oh = out + FB_P_HEAD;
+    float* red = reinterpret_cast<float*>(lds);          // [4 k-parts][2 tiles][4][16] | [2 k-parts][4 tiles][4][16] | [2][4]
+    fb_wait_barrier(0);
+    {
+        const float v = fold(bs_head);
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[((hr_k * 2 + (hr_t - 2)) * 4 + r) * 16 + col] = acc_rgb[r];
+                red[512 + ((ha_k * 4 + ha_t) * 4 + r) * 16 + col] = acc_alpha[r];
+            }
+            if (ha_t == 0 && col < 4) red[1024 + ha_k * 4 + col] = v;
+        }
+    }
+    fb_wait_barrier(0);
+    const int e = threadIdx.x;
+    if (e < 128) oh[FB_H_RGB + e] = ((red[e] + red[128 + e]) + red[256 + e]) + red[384 + e];
+    if (e < 256) oh[FB_H_ALPHA + e] = red[512 + e] + red[768 + e];
+    if (e < 4) oh[FB_H_BIAS + e] = red[1024 + e] + red[1028 + e];
 }
 
-// out[o * out_ld + col0 + c] = sum_p partial[p][off + o * 64 + c] (c < cols), parts in index order; blockIdx.y = job.  The jobs
-// behind `first_bias` are bias vectors (rows entries at partial[p][off + o]).
-struct FbReduceJob { int32_t off, rows, cols, out_ld, out_col0; float* out; };
-constexpr int FB_MAX_JOBS = 2 * (FB_MAXL + 3);
+// out[o * out_ld + col0 + c] = sum over the parts p (index order) and a job's k-parts of
+//     partial[p][off + (c >> 4) * tile_stride + o * row_stride + (c & 15) + k * kstride],   c < cols;   blockIdx.y = job.
+// The layers' products are rows of 64 floats (row_stride 64, tile_stride 16, one k-part), the heads' [k-part][tile][row][16].
+// The jobs behind `first_bias` are vectors: `rows` entries at partial[p][off + o + k * kstride].
+struct FbReduceJob { int32_t off, rows, cols, out_ld, out_col0, row_stride, tile_stride, ksplit, kstride; float* out; };
+constexpr int FB_MAX_JOBS = 2 * (FB_MAXL + 5);
 struct FbReduce { FbReduceJob job[FB_MAX_JOBS]; int32_t first_bias; };
 __global__ __launch_bounds__(256) void fb_reduce_kernel(const float* __restrict__ partial, const FbReduce rb, const int parts) {
     const FbReduceJob j = rb.job[blockIdx.y];
@@ -415,17 +488,23 @@ __global__ __launch_bounds__(256) void fb_reduce_kernel(const float* __restrict_
     const int elems = is_bias ? j.rows : j.rows * j.cols;
     if (t >= elems) return;
     const int o = is_bias ? t : t / j.cols, c = is_bias ? 0 : t - o * j.cols;
-    const float* p = partial + j.off + (is_bias ? o : o * 64 + c);
+    const float* p = partial + j.off + (is_bias ? o : (c >> 4) * j.tile_stride + o * j.row_stride + (c & 15));
+    // addend e = part * ksplit + k-part, in index order; 16 loads in flight (bandwidth- rather than latency-bound)
     float s = 0.0f;
-    int k = 0;
-    for (; k + 16 <= parts; k += 16) {
+    const int total = parts * j.ksplit;
+    auto addend = [&](int e) -> const float* {
+        const int part = j.ksplit == 1 ? e : e / j.ksplit;
+        return p + (int64_t)part * FB_PART + (e - part * j.ksplit) * j.kstride;
+    };
+    int e = 0;
+    for (; e + 16 <= total; e += 16) {
         float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(k + u) * FB_PART];
+        for (int u = 0; u < 16; ++u) v[u] = *addend(e + u);
 #pragma unroll
         for (int u = 0; u < 16; ++u) s += v[u];
     }
-    for (; k < parts; ++k) s += p[(int64_t)k * FB_PART];
+    for (; e < total; ++e) s += *addend(e);
     j.out[is_bias ? o : (int64_t)o * j.out_ld + j.out_col0 + c] = s;
 }
 
@@ -453,7 +532,7 @@ int nm_mlp_backward_fused_supported(const nm_mlp* m, int64_t n) {
     bool one_skip = false;
     fb_skip_layer(m, &one_skip);
     return d.hidden_size == 64 && d.use_viewdirs && d.num_layers >= 2 && d.num_layers <= FB_MAXL && one_skip && n > 0 &&
-           n % FB_ROWS == 0 && nm_mlp_tapes_encodings(m);
+           n % FB_ROWS == 0 && nm_mlp_tapes_encodings(m) && 6 * d.num_encoding_fn_dir + (d.include_input_dir ? 3 : 0) <= 32;
 }
 
 int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* m) {
@@ -462,13 +541,15 @@ int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* m) {
 
 int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance, const float* d_grad_radiance,
                           float* d_last, const nm_mlp_param_grads* grads, void* d_workspace, void* stream_) {
-    NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && d_last && grads && d_workspace, "bad argument");
+    NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && grads && d_workspace, "bad argument");
     NM_REQUIRE(nm_mlp_backward_fused_supported(m, n), "this handle / sample count is not served by the fused backward (ask nm_mlp_backward_fused_supported)");
     NM_REQUIRE(tape->d_h && tape->d_feat && tape->d_mask_h && tape->d_mask_v && tape->d_enc_xyz && tape->d_enc_dir, "incomplete tape");
+    NM_REQUIRE(tape->d_v == tape->d_enc_dir + 32 && tape->v_stride == 64,
+               "the fused backward reads the view layer's activation rows out of the direction-encoding rows: tape the forward with d_v = d_enc_dir + 32, v_stride = 64");
     const nm_mlp_desc& d = m->desc;
     const int L = d.num_layers;
-    NM_REQUIRE(grads->layer1_weight && grads->layer1_bias && grads->feat_weight && grads->feat_bias && grads->dir_weight && grads->dir_bias,
-               "incomplete gradient buffers");
+    NM_REQUIRE(grads->layer1_weight && grads->layer1_bias && grads->feat_weight && grads->feat_bias && grads->dir_weight && grads->dir_bias &&
+               grads->alpha_weight && grads->alpha_bias && grads->rgb_weight && grads->rgb_bias, "incomplete gradient buffers");
     for (int i = 0; i <= L - 2; ++i) NM_REQUIRE(grads->xyz_weight[i] && grads->xyz_bias[i], "incomplete gradient buffers");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MlpBwdArgs a = m->bwd;
@@ -491,7 +572,7 @@ int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const f
     const int dx = 6 * d.num_encoding_fn_xyz + (d.include_input_xyz ? 3 : 0), dd = 6 * d.num_encoding_fn_dir + (d.include_input_dir ? 3 : 0);
     FbReduce rb;
     int nj = 0;
-    auto job = [&](int off, int rows, int cols, int ld, int col0, float* out) { rb.job[nj++] = FbReduceJob{off, rows, cols, ld, col0, out}; };
+    auto job = [&](int off, int rows, int cols, int ld, int col0, float* out) { rb.job[nj++] = FbReduceJob{off, rows, cols, ld, col0, 64, 16, 1, 0, out}; };
     job(FB_P_DIRF, 32, 64, 64 + dd, 0, grads->dir_weight);
     if (dd > 0) job(FB_P_DIRE, 32, dd, 64 + dd, 64, grads->dir_weight);
     job(FB_P_FEAT, 64, 64, 64, 0, grads->feat_weight);
@@ -501,11 +582,15 @@ int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const f
         if (skip) job(FB_P_SKIP, 64, dx, 64 + dx, 64, grads->xyz_weight[i]);
     }
     job(FB_P_L1, 64, dx, dx, 0, grads->layer1_weight);
+    rb.job[nj++] = FbReduceJob{FB_P_HEAD + FB_H_RGB, 3, 32, 32, 0, 16, 64, 1, 0, grads->rgb_weight};            // rows 0..2 of d_last^T @ v
+    rb.job[nj++] = FbReduceJob{FB_P_HEAD + FB_H_ALPHA + 3 * 16, 1, 64, 64, 0, 16, 64, 1, 0, grads->alpha_weight};   // row 3 of d_last^T @ h[L-1]
     rb.first_bias = nj;
     job(FB_P_BIAS + FB_B_DIR, 32, 1, 1, 0, grads->dir_bias);
     job(FB_P_BIAS + FB_B_FEAT, 64, 1, 1, 0, grads->feat_bias);
     for (int i = 0; i <= L - 2; ++i) job(FB_P_BIAS + FB_B_XYZ + i * 64, 64, 1, 1, 0, grads->xyz_bias[i]);
     job(FB_P_BIAS + FB_B_L1, 64, 1, 1, 0, grads->layer1_bias);
+    rb.job[nj++] = FbReduceJob{FB_P_HEAD + FB_H_BIAS, 3, 1, 1, 0, 0, 0, 1, 0, grads->rgb_bias};
+    rb.job[nj++] = FbReduceJob{FB_P_HEAD + FB_H_BIAS + 3, 1, 1, 1, 0, 0, 0, 1, 0, grads->alpha_bias};
     hipLaunchKernelGGL(fb_reduce_kernel, dim3(16, nj), dim3(256), 0, stream, fa.partial, rb, grid);
     NM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -312,6 +312,8 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     const bool generic = m->plan->generic_nt != 0 || m->lw;   // generic-shape family / layer-wise path: activation rows only, no ReLU masks
     NM_REQUIRE(tape->d_h && (generic || tape->d_mask_h) && (flat || (tape->d_feat && tape->d_v && (generic || tape->d_mask_v))), "incomplete tape");
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
+    NM_REQUIRE(tape->v_stride >= 0 && (tape->v_stride == 0 || tape->v_stride >= d.hidden_size / 2), "nm_mlp_tape.v_stride is smaller than a row of d_v");
+    NM_REQUIRE(!generic || tape->v_stride == 0 || tape->v_stride == d.hidden_size / 2, "only the tuned family writes d_v with a row stride (v_stride)");
     if (m->lw) {             // beyond the fused families: layer by layer (nerf_layerwise.hip); the tape is rows, no masks
         MlpArgs a = m->base;
         a.mode = MODE_RAYS;
@@ -357,6 +359,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     a.n = rays * samples; a.out = d_radiance;
     if (a.n == 0) return 0;
     a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
+    a.tape_v_ld = tape->v_stride > 0 ? tape->v_stride : d.hidden_size / 2;
     a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
     a.tiles = (a.n + 15) / 16;
     if (nm_mlp_tapes_encodings(m)) {       // the encoding rows the weight gradients contract with, straight from the registers

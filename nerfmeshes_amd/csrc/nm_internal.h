@@ -112,12 +112,13 @@ struct MlpArgs {
     // training tape (nm_mlp_forward_train only; see nm_mlp_tape in the public header)
     float* tape_h;           // (L, n, H): layer1 output, then the post-ReLU output of every layers_xyz[i]
     float* tape_feat;        // (n, H)  relu(fc_feat(x))
-    float* tape_v;           // (n, H/2)
+    float* tape_v;           // (n, H/2), rows tape_v_ld floats apart
     uint64_t* mask_h;        // (L, tiles, 64): layers_xyz[0..L-2] then fc_feat; per lane, bit 4*tile+reg = activation > 0
     uint64_t* mask_v;        // (tiles, 64)
     int64_t tiles;           // ceil(n / 16)
     float* tape_encx;        // (n, 64) or null: the positional-encoding row of every sample point, reference column order
     float* tape_encd;        // (n, 64) or null: likewise for the view direction (tuned family only: nm_mlp_tape.d_enc_*)
+    int32_t tape_v_ld;       // floats per row of tape_v (nm_mlp_tape.v_stride; H/2 when the caller left it 0)
     RayGen gen;              // VIEW: rays generated from the pose (c = t as in RAYS; a, b unused)
     // generic-shape kernels only (mlp_device_g.h): the encodings' run-time description
     const void* g_tab;       // device: GEncArg[2][96] (xyz, dir; two parts of 48): coordinate and frequency band of every encoding argument

@@ -121,8 +121,7 @@ def forward_train(mlp, origins, dirs, t):
         raise _lib.HipLibraryError(
             f"the training tape of {rays} rays x {samples} samples needs {tape_bytes / 2**30:.0f} GiB (+ as much for the "
             "deltas): use a smaller ray chunk, or torch.no_grad() if this is inference")
-    tape = dict(h=torch.empty(L, n, H, **f32), feat=None if flat else torch.empty(n, H, **f32),
-                v=None if flat else torch.empty(n, H // 2, **f32),
+    tape = dict(h=torch.empty(L, n, H, **f32), feat=None if flat else torch.empty(n, H, **f32), v=None,
                 mask_h=None if generic else torch.empty(L, tiles, 64, dtype=torch.int64, device=mlp.device),
                 mask_v=None if flat or generic else torch.empty(tiles, 64, dtype=torch.int64, device=mlp.device),
                 enc_x=None, enc_d=None)
@@ -131,6 +130,12 @@ def forward_train(mlp, origins, dirs, t):
         # them in registers); the backward then skips its nm_encode_samples_strided pass
         tape["enc_x"] = torch.empty(n, 64, **f32)
         tape["enc_d"] = None if flat else torch.empty(n, 64, **f32)
+        if lib.nm_mlp_backward_fused_supported(mlp.handle, n):
+            # 64-wide networks: the view layer's 32-float activation rows live in the unused half of the direction-encoding rows
+            # (27 floats of 64), so that one block of rows feeds layers_dir[0]'s and fc_rgb's gradients in nm_mlp_backward_fused
+            tape["v"] = tape["enc_d"][:, 32:]
+    if tape["v"] is None and not flat:
+        tape["v"] = torch.empty(n, H // 2, **f32)
     out = torch.empty(rays, samples, 4, **f32)
     ct = _tape_struct(tape)
     with _stage("taping_forward"):
@@ -141,8 +146,9 @@ def forward_train(mlp, origins, dirs, t):
 
 def _tape_struct(tape):
     opt = lambda x: None if x is None else _ptr(x)   # noqa: E731
-    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(tape["v"]), opt(tape["mask_h"]), opt(tape["mask_v"]),
-                   opt(tape.get("enc_x")), opt(tape.get("enc_d")))
+    v = tape["v"]
+    return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(v), opt(tape["mask_h"]), opt(tape["mask_v"]),
+                   opt(tape.get("enc_x")), opt(tape.get("enc_d")), 0 if v is None else int(v.stride(0)))
 
 
 def encode_samples(mlp, origins, dirs, t):
@@ -234,7 +240,8 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     n = radiance.numel() // 4
     f32 = dict(dtype=torch.float32, device=mlp.device)
     flat = not d.get("use_viewdirs", True)
-    if tape.get("enc_x") is not None and tape.get("enc_d") is not None and lib.nm_mlp_backward_fused_supported(mlp.handle, n):
+    if (tape.get("enc_d") is not None and tape["v"] is not None and tape["v"].data_ptr() == tape["enc_d"].data_ptr() + 128
+            and lib.nm_mlp_backward_fused_supported(mlp.handle, n)):
         return _backward_fused(mlp, tape, radiance, grad_radiance, n)
     dh, dlast = torch.empty(L, n, H, **f32), torch.empty(n, 4, **f32)
     dfeat, dv = (None, None) if flat else (torch.empty(n, H, **f32), torch.empty(n, H // 2, **f32))
@@ -305,8 +312,7 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
 
 def _backward_fused(mlp, tape, radiance, grad_radiance, n):
     """The 64-wide networks (BASELINE config 1's 4x64): delta chain and every trunk / view-layer weight gradient in ONE kernel
-    (nm_mlp_backward_fused, nerf_bwd_fused.hip) -- no delta row is written, the tape is read once --, then the two 4-row heads
-    from d_last as on the general path."""
+    (nm_mlp_backward_fused, nerf_bwd_fused.hip), the two 4-row heads included: no delta row is written, the tape is read once."""
     lib = _lib.load()
     d = mlp.desc
     L, H, skip_step = int(d["num_layers"]), int(d["hidden_size"]), int(d["skip_step"])
@@ -325,15 +331,15 @@ def _backward_fused(mlp, tape, radiance, grad_radiance, n):
     pg.layer1_weight, pg.layer1_bias = _ptr(g["layer1.weight"]), _ptr(g["layer1.bias"])
     pg.feat_weight, pg.feat_bias = _ptr(g["fc_feat.weight"]), _ptr(g["fc_feat.bias"])
     pg.dir_weight, pg.dir_bias = _ptr(g["layers_dir.0.weight"]), _ptr(g["layers_dir.0.bias"])
-    dlast = torch.empty(n, 4, **f32)
+    g.update({"fc_alpha.weight": torch.empty(1, H, **f32), "fc_alpha.bias": torch.empty(1, **f32),
+              "fc_rgb.weight": torch.empty(3, H // 2, **f32), "fc_rgb.bias": torch.empty(3, **f32)})
+    pg.alpha_weight, pg.alpha_bias = _ptr(g["fc_alpha.weight"]), _ptr(g["fc_alpha.bias"])
+    pg.rgb_weight, pg.rgb_bias = _ptr(g["fc_rgb.weight"]), _ptr(g["fc_rgb.bias"])
     ws = _workspace(mlp, "fused_bwd", int(lib.nm_mlp_backward_fused_workspace_bytes(mlp.handle)))
     ct = _tape_struct(tape)
-    with _stage("delta"):        # delta chain + weight gradients: one launch + one reduction
-        check(lib.nm_mlp_backward_fused(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), _ptr(dlast), C.byref(pg),
+    with _stage("delta"):        # delta chain + all weight gradients, the heads included: one launch + one reduction
+        check(lib.nm_mlp_backward_fused(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), None, C.byref(pg),
                                         _ptr(ws), _stream()), "nm_mlp_backward_fused")
-    (gh, last_sums), (gv, _) = _head_grad(mlp, dlast, tape["h"][L - 1], bias=True), _head_grad(mlp, dlast, tape["v"])
-    g["fc_alpha.weight"], g["fc_alpha.bias"] = gh[3:4], last_sums[3:4]
-    g["fc_rgb.weight"], g["fc_rgb.bias"] = gv[:3], last_sums[:3]
     return g
 
 
