@@ -34,6 +34,18 @@
 
 namespace nm {
 
+// ReLU' from a lane's taped bit mask: acc where bit (4 nt + r) is set, +0.0f elsewhere -- v_bfe_i32 (the bit, sign-extended: 0 or ~0)
+// and v_and_b32 on the value's bits: two VALU instructions per value (and / compare / select is three; VALU issue time adds to
+// matrix time in these kernels)
+__device__ __forceinline__ void fb_apply_mask(float (&in)[16], const f32x4 (&acc)[4], const uint64_t m) {
+    const int lo = (int)(unsigned)m;                 // 16 tile registers: bits 0..15
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            in[4 * nt + r] = __int_as_float(__float_as_int(acc[nt][r]) & __builtin_amdgcn_sbfe(lo, 4 * nt + r, 1));
+}
+
 constexpr int FB_ROWS = 128;                       // samples per workgroup iteration
 constexpr int FB_ROWB = 256;                       // bytes per 64-float row
 constexpr int FB_CHUNK = 8192;                     // one weight chunk: 8 k-steps x 4 tiles x 256 B
@@ -114,25 +126,27 @@ __device__ __forceinline__ void fb_chunk(f32x4 (&acc)[4], const float (&b)[NB], 
 // One weight-gradient product of this wave over the 128 samples of the delta tile: TB = 2 tiles (64 x 64 products) or 1 (the
 // 32 x 64 view-layer products).  a_off: this lane's A address for k-groups = 0 (mod 4) -- the swizzle of k-group ks adds an XOR of
 // word bits 2..3 with ks & 3 --, b_ptr: this lane's B address in the slot.  Operands are fetched 4 k-groups ahead of their MFMAs.
-template <int TB, int ABL = 0>
+template <int TB, int ABL = 0, int PF = 4>
 __device__ __forceinline__ void fb_dw_step(f32x4 (&acc)[TB], float& bsum, const char* lds, const unsigned a_off, const char* b_ptr) {
     // Batches of 4 k-groups, two per trip of a REAL loop (fully unrolled, the compiler issued all 32 operand reads of a product
     // up front: 60 registers more than the two batches in flight here, and the kernel spilled).
-    constexpr int PF = 4, NBATCH = (FB_ROWS / 4) / PF;
-    static_assert(NBATCH % 2 == 0, "two batches per trip");
+    constexpr int NBATCH = (FB_ROWS / 4) / PF;                 // PF: 4 (2 for the 8-layer instantiation: 12 registers it does not have)
+    static_assert(NBATCH % 2 == 0 && (2 * PF) % 4 == 0, "two batches per trip, whole groups of 4 k-groups");
     float a0[PF], a1[PF];
     f32x2 b0[PF], b1[PF];
-    const char* ap[PF];
+    const char* ap[4];
 #pragma unroll
-    for (int j = 0; j < PF; ++j) ap[j] = lds + (a_off ^ (unsigned)(j << 4)) + j * 1024;     // k-group 4 kb + j: swizzle term j << 2 words
-    auto fetch = [&](float (&a)[PF], f32x2 (&b)[PF], int byte_off) {
+    for (int j = 0; j < 4; ++j) ap[j] = lds + (a_off ^ (unsigned)(j << 4)) + j * 1024;      // k-group = j (mod 4): swizzle term j << 2 words
+    // batch `ph` (0 / 1) of the trip at byte offset trip_off (a multiple of 4 k-groups): k-group q = ph * PF + j of the trip
+    auto fetch = [&](float (&a)[PF], f32x2 (&b)[PF], const int ph, const int trip_off) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
+            const int q = ph * PF + j, jj = q & 3;
             if constexpr (ABL & 32) a[j] = 1.0f + j;
-            else a[j] = *reinterpret_cast<const float*>(ap[j] + byte_off);
+            else a[j] = *reinterpret_cast<const float*>(ap[jj] + trip_off + (q - jj) * 1024);
             if constexpr (ABL & 16) b[j] = f32x2{a[j], 2.0f};
-            else if constexpr (TB == 2) b[j] = *reinterpret_cast<const f32x2*>(b_ptr + byte_off + j * 1024);
-            else b[j][0] = *reinterpret_cast<const float*>(b_ptr + byte_off + j * 1024);
+            else if constexpr (TB == 2) b[j] = *reinterpret_cast<const f32x2*>(b_ptr + trip_off + q * 1024);
+            else b[j][0] = *reinterpret_cast<const float*>(b_ptr + trip_off + q * 1024);
         }
     };
     auto mfmas = [&](const float (&a)[PF], const f32x2 (&b)[PF]) {
@@ -143,13 +157,13 @@ __device__ __forceinline__ void fb_dw_step(f32x4 (&acc)[TB], float& bsum, const 
             bsum += a[j];      // column sums of delta = the bias gradient (used from the waves that own column tile 0)
         }
     };
-    fetch(a0, b0, 0);
+    fetch(a0, b0, 0, 0);
 #pragma unroll 1
     for (int off = 0; off < NBATCH * PF * 1024; off += 2 * PF * 1024) {
-        fetch(a1, b1, off + PF * 1024);
+        fetch(a1, b1, 1, off);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(a0, b0);
-        if (off + 2 * PF * 1024 < NBATCH * PF * 1024) fetch(a0, b0, off + 2 * PF * 1024);
+        fetch(a0, b0, 0, off + 2 * PF * 1024);   // (the last trip reads the rows behind the block: inside the LDS allocation, never used)
         __builtin_amdgcn_sched_barrier(0);
         mfmas(a1, b1);
     }
@@ -177,8 +191,12 @@ __device__ __forceinline__ void fb_head_step(f32x4& acc, float& bsum, const char
     }
 }
 
-__device__ __forceinline__ void fb_wait_barrier(int pieces_in_flight) {
+template <int ABL = 0>
+__device__ __forceinline__ void fb_wait_barrier(int pieces_in_flight, bool phase_a = false) {
     // everything but the newest `pieces_in_flight` DMA pieces (the rows of the NEXT delta) has landed; those stay in flight
+    if constexpr (ABL & 128) return;                     // probe: neither waits nor barriers
+    if constexpr (ABL & 64) { if (phase_a) return; }     // probe: no barrier between the two phases of a delta
+    if constexpr (ABL & 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); return; }   // probe: barriers, no DMA waits
     if (pieces_in_flight >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (pieces_in_flight >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -187,10 +205,11 @@ __device__ __forceinline__ void fb_wait_barrier(int pieces_in_flight) {
 }
 
 // MAXL: the num_layers an instantiation holds accumulators for (4: 56 registers per wave, 8: 88); the partial layout is MAXL 8's
-// ABL: timing ablations of tests/tools/probes/fb_probe.hip (1: no dW products, 2: no row DMA, 4: no chain MFMAs, 8: no delta tile, 16 / 32: no B / A operand reads); 0 in the library
+// ABL: timing ablations of tests/tools/probes/fb_probe.hip (1: no dW products, 2: no row DMA, 4: no chain MFMAs, 8: no delta tile, 16 / 32: no B / A operand reads, 64: no barrier between a delta's phases, 128: no waits or barriers, 256: barriers but no DMA waits); 0 in the library
 template <int MAXL, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdArgs args, const FusedBwdArgs fa, const int L) {
     constexpr int H = 64, KH = 16, KD = 8;
+    constexpr int DPF = MAXL > 4 ? 2 : 4;                  // operand batches of the dW products (registers: fb_dw_step)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_walpha = reinterpret_cast<float*>(lds + FB_OFF_HEADS);   // [4][H/4]
     float* lds_wrgb = lds_walpha + H;                                   // [3][4][H/8]
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
         issue_rows(fa.tape_feat + it * (FB_ROWS * 64));
         issue_rows(fa.enc_d + it * (FB_ROWS * 64));
     }
-    fb_wait_barrier(8);     // the head weights in LDS and the first weight chunk (older than the 8 row pieces) are everybody's now
+    fb_wait_barrier<ABL>(8);     // the head weights in LDS and the first weight chunk (older than the 8 row pieces) are everybody's now
 
     for (; it < wg_iters; it += gridDim.x) {
         const bool has_next = it + gridDim.x < wg_iters;
@@ -293,25 +312,22 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (!(ABL & 4)) fb_chunk<KD, 0, KD>(acc, dv, lds + par * FB_CHUNK + lane * 16);
-            fb_wait_barrier(0);
+            fb_wait_barrier<ABL>(0, true);
             par ^= 1;
             gw += FB_CHUNK;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) in[4 * nt + r] = ((m >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+            fb_apply_mask(in, acc, m);
         }
         // ---- phase B0: grad(layers_dir.0) = delta_v^T @ [feat | view encoding] (models.py:72-73)
         {
             issue_rows(fa.tape_h + ((int64_t)(L - 1) * args.n + row0) * 64);
-            if constexpr (!(ABL & 1)) fb_dw_step<1, ABL>(acc_dirf, bs_dir, lds, a_off32, slot_ptr(bslot) + b_off32);
+            if constexpr (!(ABL & 1)) fb_dw_step<1, ABL, DPF>(acc_dirf, bs_dir, lds, a_off32, slot_ptr(bslot) + b_off32);
             bslot = next_slot(bslot);
             float unused = 0.f;
-            if constexpr (!(ABL & 1)) fb_dw_step<1, ABL>(acc_dire, unused, lds, a_off32, slot_ptr(bslot) + b_off32);
+            if constexpr (!(ABL & 1)) fb_dw_step<1, ABL, DPF>(acc_dire, unused, lds, a_off32, slot_ptr(bslot) + b_off32);
             // grad(fc_rgb) = d_last^T @ v: the view layer's activation rows are the columns 32..63 of the direction rows (models.py:75)
             if constexpr (!(ABL & 1)) fb_head_step<4>(acc_rgb, unused, dl_lane + hr_k * 256, slot_ptr(bslot) + hr_k * 1024 + g * FB_ROWB + (16 * hr_t + col) * 4);
             bslot = next_slot(bslot);
-            fb_wait_barrier(4);
+            fb_wait_barrier<ABL>(4);
         }
         // ================= delta 1: at fc_feat's pre-activation; fc_feat^T + fc_alpha^T (models.py:70-71)
         {
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 acc[nt] = f32x4{w4[0] * dsigma, w4[1] * dsigma, w4[2] * dsigma, w4[3] * dsigma};
             }
             if constexpr (!(ABL & 4)) fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
-            fb_wait_barrier(0);
+            fb_wait_barrier<ABL>(0, true);
             par ^= 1;
             // ---- phase B1: the first chunk of layers_xyz[L-2]^T (or, for a one-layer trunk, of the next iteration) | rows of delta 2
             const bool more = L >= 2;
@@ -339,17 +355,14 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 issue_rows(fa.enc_x + row0 * 64);
             }
             if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
-            if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
+            if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
             // grad(fc_alpha) = d_last^T @ h[L-1] (row 3; models.py:71), and the column sums of d_last = both heads' bias gradients
             if constexpr (!(ABL & 1)) fb_head_step<2>(acc_alpha, bs_head, dl_lane + ha_k * 256, slot_ptr(bslot) + ha_k * 1024 + g * FB_ROWB + (16 * ha_t + col) * 4);
             bslot = next_slot(bslot);
-            fb_wait_barrier(flying);
+            fb_wait_barrier<ABL>(flying);
             par ^= 1;
             gw += 2 * FB_CHUNK;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) in[4 * nt + r] = ((m >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+            fb_apply_mask(in, acc, m);
         }
         // ================= deltas 2 .. L: at layers_xyz[i]'s pre-activation, i = L-2 .. 0; layers_xyz[i]^T (models.py:63-69)
 #pragma unroll
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (!(ABL & 4)) fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
-                fb_wait_barrier(0);
+                fb_wait_barrier<ABL>(0, true);
                 par ^= 1;
                 // ---- phase B
                 if (i > 0 || has_next) stream_to_lds<8>(i > 0 ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
@@ -375,25 +388,22 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                     issue_rows(fa.enc_x + row0 * 64);                      // layer1 contracts with the encoding rows
                 }
                 if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
-                if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
+                if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
                 bslot = next_slot(bslot);
                 if (sk == i) {                                             // cat(x, xyz): the encoding columns (models.py:64-65)
                     float unused = 0.f;
-                    if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_skip, unused, lds, a_off64, slot_ptr(bslot) + b_off64);
+                    if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_skip, unused, lds, a_off64, slot_ptr(bslot) + b_off64);
                     bslot = next_slot(bslot);
                 }
-                fb_wait_barrier(flying);
+                fb_wait_barrier<ABL>(flying);
                 par ^= 1;
                 gw += 2 * FB_CHUNK;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) in[4 * nt + r] = ((m >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+                fb_apply_mask(in, acc, m);
             }
         }
         // ================= delta L+1: at layer1's output (no activation, models.py:62): grad(layer1) = delta^T @ xyz encoding
         if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
-        fb_wait_barrier(0);
+        fb_wait_barrier<ABL>(0, true);
         int flying = 0;
         if (has_next) {
             fetch_head(it + gridDim.x);
@@ -401,9 +411,9 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             issue_rows(fa.enc_d + (it + gridDim.x) * (FB_ROWS * 64));
             flying = 8;
         }
-        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL>(acc_l1, bs_l1, lds, a_off64, slot_ptr(bslot) + b_off64);
+        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_l1, bs_l1, lds, a_off64, slot_ptr(bslot) + b_off64);
         bslot = next_slot(bslot);
-        fb_wait_barrier(flying);
+        fb_wait_barrier<ABL>(flying);
     }
 
     // ---- this workgroup's partial.  Tile (qa, qb), lane (g, col), register r: dW[4 (4 g + r) + qa][4 col + qb] (32-row products:
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     // k-groups between them add their accumulators up through LDS, in k-part order (deterministic): one partial per workgroup
     float* oh = out + FB_P_HEAD;
     float* red = reinterpret_cast<float*>(lds);          // [4 k-parts][2 tiles][4][16] | [2 k-parts][4 tiles][4][16] | [2][4]
-    fb_wait_barrier(0);
+    fb_wait_barrier<ABL>(0);
     {
         const float v = fold(bs_head);
         if (g == 0) {
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             if (ha_t == 0 && col < 4) red[1024 + ha_k * 4 + col] = v;
         }
     }
-    fb_wait_barrier(0);
+    fb_wait_barrier<ABL>(0);
     const int e = threadIdx.x;
     if (e < 128) oh[FB_H_RGB + e] = ((red[e] + red[128 + e]) + red[256 + e]) + red[384 + e];
     if (e < 256) oh[FB_H_ALPHA + e] = red[512 + e] + red[768 + e];

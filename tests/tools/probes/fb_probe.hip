@@ -1,7 +1,8 @@
 // Where does the fused 64-wide backward kernel (nerfmeshes_amd/csrc/nerf_bwd_fused.hip) spend its time?  The kernel itself, included
 // as it is, on synthetic operands of config 1's size (262 144 samples, 4 layers, skip at 2), with parts of it compiled out:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tests/tools/probes/fb_probe tests/tools/probes/fb_probe.hip && tests/tools/probes/fb_probe
-// ABL bits: 1 no dW products (reads + MFMAs), 2 no activation-row DMA, 4 no chain MFMAs, 8 no delta tile writes, 16 / 32 no B / A operand reads in the dW products.  Results of the
+// ABL bits: 1 no dW products (reads + MFMAs), 2 no activation-row DMA, 4 no chain MFMAs, 8 no delta tile writes, 16 / 32 no B / A operand reads in the dW products, 64 no barrier between a delta's
+// two phases, 128 no waits and no barriers at all.  Results of the
 // ablated variants are wrong on purpose; only the times mean something.
 #define NM_FB_KERNEL_ONLY
 #include "../../../nerfmeshes_amd/csrc/nerf_bwd_fused.hip"
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
         uint64_t* d; CK(hipMalloc(&d, h.size() * 8)); CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
         a.mask_h = d; a.mask_v = d + (size_t)L * a.tiles * 64;
     }
-    float* dlast; CK(hipMalloc(&dlast, 16 * n)); a.d_last = dlast;
+    a.d_last = nullptr;          // as train_ops calls it (the heads are products of this kernel); a store here would sit in the DMA wait queue
     FusedBwdArgs fa{};
     fa.tape_h = dev_random<float>((size_t)L * n * 64, 6, 0.f, 1.f);
     fa.tape_feat = dev_random<float>((size_t)n * 64, 7, 0.f, 1.f);
@@ -78,5 +79,13 @@ int main(int argc, char** argv) {
     RUN(4, 6 + 16, "dW products alone, B operands not read")
     RUN(4, 6 + 32, "dW products alone, A operands not read")
     RUN(4, 6 + 48, "dW products alone, no operand reads (MFMAs + barriers)")
+    RUN(4, 64, "everything, without the barrier between a delta's two phases")
+    RUN(4, 2 + 128, "no row DMA, no waits, no barriers (the instruction streams alone)")
+    RUN(4, 128, "row DMA issued but nothing waits for it: no waits, no barriers")
+    RUN(4, 256, "row + weight DMA issued, barriers kept, no DMA waits at all")
+    RUN(4, 256 + 2, "barriers kept, no row DMA, no DMA waits")
+    RUN(4, 2 + 4 + 128, "dW products alone, no waits, no barriers")
+    RUN(4, 2 + 4 + 48 + 128, "dW MFMAs alone: no operand reads, no waits, no barriers")
+    RUN(4, 1 + 2 + 128, "the delta chain alone, no waits, no barriers")
     return 0;
 }
