@@ -492,30 +492,36 @@ struct FbReduceJob { int32_t off, rows, cols, out_ld, out_col0, row_stride, tile
 constexpr int FB_MAX_JOBS = 2 * (FB_MAXL + 5);
 struct FbReduce { FbReduceJob job[FB_MAX_JOBS]; int32_t first_bias; };
 __global__ __launch_bounds__(256) void fb_reduce_kernel(const float* __restrict__ partial, const FbReduce rb, const int parts) {
+    // four lanes per output element, each adds a quarter of the parts (index order, 16 loads in flight), then the four sums are
+    // added in lane order: a fixed grouping -- deterministic -- whose dependent chain is a quarter as long (one thread per element
+    // took 17 us behind a 260 us kernel: 256 dependent additions at HBM latency per batch of 16)
     const FbReduceJob j = rb.job[blockIdx.y];
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     const bool is_bias = (int)blockIdx.y >= rb.first_bias;
     const int elems = is_bias ? j.rows : j.rows * j.cols;
-    if (t >= elems) return;
-    const int o = is_bias ? t : t / j.cols, c = is_bias ? 0 : t - o * j.cols;
+    const bool live = t < elems;
+    const int tt = live ? t : 0;
+    const int o = is_bias ? tt : tt / j.cols, c = is_bias ? 0 : tt - o * j.cols;
     const float* p = partial + j.off + (is_bias ? o : (c >> 4) * j.tile_stride + o * j.row_stride + (c & 15));
-    // addend e = part * ksplit + k-part, in index order; 16 loads in flight (bandwidth- rather than latency-bound)
-    float s = 0.0f;
     const int total = parts * j.ksplit;
+    const int per = (total + 3) / 4;
+    const int e0 = sub * per, e1 = e0 + per < total ? e0 + per : total;
     auto addend = [&](int e) -> const float* {
         const int part = j.ksplit == 1 ? e : e / j.ksplit;
         return p + (int64_t)part * FB_PART + (e - part * j.ksplit) * j.kstride;
     };
-    int e = 0;
-    for (; e + 16 <= total; e += 16) {
+    float s = 0.0f;
+    int e = e0;
+    for (; e + 16 <= e1; e += 16) {
         float v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) v[u] = *addend(e + u);
 #pragma unroll
         for (int u = 0; u < 16; ++u) s += v[u];
     }
-    for (; e < total; ++e) s += *addend(e);
-    j.out[is_bias ? o : (int64_t)o * j.out_ld + j.out_col0 + c] = s;
+    for (; e < e1; ++e) s += *addend(e);
+    const float s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2), s3 = __shfl_down(s, 3);
+    if (live && sub == 0) j.out[is_bias ? o : (int64_t)o * j.out_ld + j.out_col0 + c] = ((s + s1) + s2) + s3;
 }
 
 #ifndef NM_FB_KERNEL_ONLY
@@ -601,7 +607,7 @@ int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const f
     job(FB_P_BIAS + FB_B_L1, 64, 1, 1, 0, grads->layer1_bias);
     rb.job[nj++] = FbReduceJob{FB_P_HEAD + FB_H_BIAS, 3, 1, 1, 0, 0, 0, 1, 0, grads->rgb_bias};
     rb.job[nj++] = FbReduceJob{FB_P_HEAD + FB_H_BIAS + 3, 1, 1, 1, 0, 0, 0, 1, 0, grads->alpha_bias};
-    hipLaunchKernelGGL(fb_reduce_kernel, dim3(16, nj), dim3(256), 0, stream, fa.partial, rb, grid);
+    hipLaunchKernelGGL(fb_reduce_kernel, dim3(64, nj), dim3(256), 0, stream, fa.partial, rb, grid);
     NM_HIP_CHECK(hipGetLastError());
     return 0;
 }
