@@ -22,4 +22,16 @@ cd $R
 # round 6: the narrow shapes' training iterations with their stage tables, and the drop-in report (call traces of the unmodified scripts)
 python tests/tools/bench_train_shapes.py --iters 10 --only "4x64 (config 1: 32 coarse, no fine),8x64,8x128,8x256" > gpurun_out/train_shapes_$tag.txt 2>/dev/null
 python -m pytest tests/test_gpu_script_traces.py -q > gpurun_out/script_traces_$tag.txt 2>&1
+# round 6, second half: the 64-wide networks' fused backward -- the kernel with parts compiled out (probe), its counters on a real tape,
+# and config 1's iteration A/B against the separate kernels
+tests/tools/probes/fb_probe 4 > gpurun_out/fb_probe_${tag}_L4.txt 2>&1
+tests/tools/probes/fb_probe 8 524288 > gpurun_out/fb_probe_${tag}_L8.txt 2>&1
+NM_FUSED_BACKWARD=0 python tests/tools/bench_tiny_train.py --shapes > gpurun_out/tiny_train_separate_$tag.json 2>/dev/null
+python tests/tools/bench_tiny_train.py --shapes > gpurun_out/tiny_train_fused_$tag.json 2>/dev/null
+for group in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "FETCH_SIZE" "WRITE_SIZE"; do
+  name=$(echo $group | cut -d' ' -f1)
+  bash scripts/pmc_run.sh fb_${tag}_$name "$group" "mlp_backward_dw64" python $R/tests/tools/fused_bwd_one.py > gpurun_out/pmc_fb_${tag}_$name.txt 2>&1
+done
+python tests/tools/fused_bwd_one.py > gpurun_out/fused_bwd_one_$tag.txt 2>&1
+bash scripts/trace_iteration.sh trace_$tag "4x64 (config 1: 32 coarse, no fine)" "8x64" > /dev/null 2>&1
 ls $R/gpurun_out/prof_$tag $R/gpurun_out/pmc_$tag

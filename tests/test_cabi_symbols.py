@@ -2,6 +2,8 @@
 import os
 import re
 
+import pytest
+
 from nerfmeshes_amd import _lib, build
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -64,3 +66,27 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.nm_export_obj(None, 3, None, 0, None, 0, None, 0, b"/nonexistent-dir/x.obj") == 2 and "null array" in err()
     ok = (C.c_float * 3)(1.0, 2.0, 3.0)
     assert lib.nm_export_obj(ok, 1, None, 0, None, 0, None, 0, b"/nonexistent-dir/x.obj") == 6 and "cannot open" in err()
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of the structs that cross the boundary by pointer (nerfmeshes_amd/_lib.py) against what a C compiler makes
+    of include/nerfmeshes_hip.h: sizes and the offsets of the members added last (nm_mlp_tape.v_stride and nm_mlp_param_grads, ABI
+    v6: the 64-wide networks' fused backward)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from nerfmeshes_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nerfmeshes_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nm_mlp_tape), offsetof(nm_mlp_tape, v_stride), '
+                   'sizeof(nm_mlp_param_grads), offsetof(nm_mlp_param_grads, xyz_bias), offsetof(nm_mlp_param_grads, rgb_bias), '
+                   'sizeof(nm_mlp_deltas), sizeof(nm_weight_grad_job)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(_lib.MlpTape), _lib.MlpTape.v_stride.offset, C.sizeof(_lib.MlpParamGrads), _lib.MlpParamGrads.xyz_bias.offset,
+            _lib.MlpParamGrads.rgb_bias.offset, C.sizeof(_lib.MlpDeltas), C.sizeof(_lib.WeightGradJob)]
+    assert got == want, (got, want)
