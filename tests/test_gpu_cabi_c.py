@@ -41,7 +41,7 @@ def test_c_program_through_the_c_abi(tmp_path):
     res = subprocess.run([str(exe), str(tmp_path / "weights.bin"), str(tmp_path / "points.bin"), str(n), str(tmp_path / "out.bin")],
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
-    assert "abi 5" in res.stdout
+    assert "abi 6" in res.stdout
     blob = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     mlp_part = n * (4 + 4 + 64 + 4)
     rest = blob[mlp_part:]
