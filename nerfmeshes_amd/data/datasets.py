@@ -12,8 +12,8 @@ A sample is ONE image: `__getitem__` returns `DataBundle.serialize(filters)` -- 
 * otherwise the whole split lives in memory with rays for every pose.
 
 `load_dataset()` is the file reader.  `BlenderDataset` reads the NeRF-synthetic layout (`transforms_<split>.json` + PNGs,
-`loaders/load_blender.py`); the LLFF / COLMAP readers are outside the scope table --
-`ColmapDataset` works from an existing ray cache and says so otherwise.
+`loaders/load_blender.py`), `ColmapDataset` the LLFF layout (`poses_bounds.npy` + `images_<factor>/`, `loaders/load_llff.py`:
+recentred / spherified poses, bounds scaled to the nearest depth, hold-out split) -- both also work from an existing ray cache.
 """
 import glob
 import os
@@ -197,8 +197,9 @@ class BlenderDataset(CachingDataset):
 
 
 class ColmapDataset(CachingDataset):
-    """datasets.py:317-361.  The LLFF / COLMAP image + pose readers (`load_llff_data`) are host-side file parsing outside
-    the hot path: this class serves an existing ray cache (e.g. one the reference wrote); without one it raises."""
+    """datasets.py:317-357: LLFF / COLMAP forward-facing (or, `spherify`, inward-facing) captures; one sample = one full image.
+    `dataset.basedir` holds poses_bounds.npy + images[_<llff_downsample_factor>]/ (loaders/load_llff.py); with
+    `dataset.caching.use_caching` an existing ray cache is served as it is, whatever wrote it."""
 
     def __init__(self, cfg, spherify=True, type=DatasetType.TRAIN):
         self.downscale_factor = cfg.dataset.llff_downsample_factor
@@ -207,10 +208,22 @@ class ColmapDataset(CachingDataset):
         print("Loading Colmap Data...")
 
     def load_dataset(self):
-        raise NotImplementedError(
-            "ColmapDataset: the LLFF/COLMAP readers are not part of nerfmeshes_amd (SURVEY.md section 8, out of scope). "
-            f"Point dataset.caching.cache_dir at a ray cache (use_caching: True; looked in {self.path}) -- the files the "
-            "reference's CachingDataset writes are read as they are.")
+        from .loaders.load_llff import load_llff_data
+        if not (Path(self.dataset_path) / "poses_bounds.npy").exists():
+            raise FileNotFoundError(
+                f"{Path(self.dataset_path) / 'poses_bounds.npy'}: dataset.basedir must hold an LLFF scene (poses_bounds.npy + "
+                f"images_{self.downscale_factor}/); alternatively point dataset.caching.cache_dir at a ray cache "
+                f"(use_caching: True; looked in {self.path}) -- the files the reference's CachingDataset writes are read as they are.")
+        images, pose_mats, bounds, _render_poses, i_test = load_llff_data(str(self.dataset_path), factor=self.downscale_factor,
+                                                                           spherify_poses=self.spherify)
+        # hold out every llff_hold_step-th view for validation, or only the one closest to the average pose (datasets.py:330-338)
+        every = self.cfg.dataset.llff_hold_step
+        held = np.arange(images.shape[0])[::every] if every > 0 else np.array([i_test])
+        kept = np.array([i for i in np.arange(images.shape[0]) if i not in held])
+        pick = kept if self.type == DatasetType.TRAIN else held
+        pose_mats = torch.from_numpy(pose_mats[pick, ...])
+        return DataBundle(ray_targets=torch.from_numpy(images[pick, ...]), ray_bounds=torch.from_numpy(bounds[pick, ...]),
+                          poses=pose_mats[:, :3, :4], hwf=tuple(pose_mats[0, :3, -1].long().tolist()), size=len(pick))
 
 
 class CachedRayDataset(CachingDataset):

@@ -1,5 +1,8 @@
 """Host-side data feed: DataBundle round trips and the per-image `.data` ray cache
 (datasets.py:136-283) -- CPU only."""
+import os
+
+import pytest
 import torch
 
 from nerfmeshes_amd import synthetic as S
@@ -218,3 +221,69 @@ def test_an_optimizer_step_marks_the_modules_whose_parameters_it_holds_and_no_ot
     assert "fused" not in train_ops.make_optimizer("Adam", lin.parameters(), 0.1).defaults or \
         not train_ops.make_optimizer("Adam", lin.parameters(), 0.1).defaults["fused"], "host parameters: torch's default implementation"
     assert train_ops.make_optimizer("SGD", lin.parameters(), 0.1, momentum=0.9).defaults["momentum"] == 0.9
+
+
+# ---- LLFF / COLMAP scenes (ColmapDataset.load_dataset: /root/reference/src/data/datasets.py:325-357 over loaders/load_llff.py)
+def _llff_scene(tmp_path):
+    import numpy as np
+    from PIL import Image
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llff_scene.npz"))
+    np.save(tmp_path / "poses_bounds.npy", gold["poses_bounds"])
+    views, fh, fw, _ = gold["images_full_shape"]
+    for name, stack in (("images", np.zeros((views, fh, fw, 3), np.uint8)), ("images_4", gold["images_4"])):
+        (tmp_path / name).mkdir()
+        for i, img in enumerate(stack):
+            Image.fromarray(img).save(tmp_path / name / f"view_{i:03d}.png")
+    return gold
+
+
+@pytest.mark.parametrize("mode", ["forward", "spherify"])
+def test_llff_reader_equals_the_unmodified_reference(tmp_path, mode):
+    """poses_bounds.npy + images_4/ -> images, recentred (spherified) poses, rescaled bounds, the 120 render poses and the hold-out
+    view, against what the unmodified reference's load_llff_data returned for the same folder (tests/golden/make_llff_golden.py)."""
+    import numpy as np
+    from nerfmeshes_amd.data.loaders.load_llff import load_llff_data
+    gold = _llff_scene(tmp_path)
+    images, poses, bounds, render_poses, i_test = load_llff_data(str(tmp_path), factor=4, spherify_poses=mode == "spherify")
+    assert i_test == int(gold[f"{mode}_i_test"])
+    for name, got in (("images", images), ("poses", poses), ("bounds", bounds), ("render_poses", render_poses)):
+        want = gold[f"{mode}_{name}"]
+        assert got.shape == want.shape and got.dtype == want.dtype, name
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6, err_msg=name)
+    assert np.array_equal(images, gold[f"{mode}_images"])                    # decoding + / 255 is exact
+    assert tuple(poses[0, :, 4]) == (6.0, 8.0, 30.0)                         # hwf follows the down-scaled images
+
+
+def test_llff_reader_reports_what_is_missing(tmp_path):
+    from nerfmeshes_amd.data.loaders.load_llff import load_llff_data
+    _llff_scene(tmp_path)
+    with pytest.raises(FileNotFoundError, match="mogrify"):
+        load_llff_data(str(tmp_path), factor=8)                               # images_8/ was never made
+    os.remove(tmp_path / "images_4" / "view_000.png")
+    with pytest.raises(ValueError, match="8 images .* 9 poses"):
+        load_llff_data(str(tmp_path), factor=4)
+
+
+def test_colmap_dataset_splits_an_llff_scene_as_the_reference_does(tmp_path):
+    """ColmapDataset over a scene folder (no ray cache): every llff_hold_step-th view is validation, the rest training
+    (datasets.py:330-341); a sample of the validation split is one whole image with its own bounds."""
+    import numpy as np
+    from nerfmeshes_amd import synthetic as S
+    from nerfmeshes_amd.data import ColmapDataset, DatasetType
+    from nerfmeshes_amd.nerf import CfgNode
+    gold = _llff_scene(tmp_path)
+    hp = S.hparams(dataset_type="colmap", near=0.0, far=1.0)
+    hp.update({"dataset.basedir": str(tmp_path), "dataset.llff_downsample_factor": 4, "dataset.llff_hold_step": 4,
+               "dataset.caching.use_caching": False})
+    cfg = CfgNode(nest_dict(hp, sep="."))
+
+    def reader(split):          # the constructor would go on to generate every view's rays on the GPU: the file reader alone here
+        ds = ColmapDataset.__new__(ColmapDataset)
+        ds.cfg, ds.type, ds.downscale_factor, ds.spherify, ds.path = cfg, split, 4, False, str(tmp_path / "cache")
+        return ds.load_dataset()
+
+    val, train = reader(DatasetType.VALIDATION), reader(DatasetType.TRAIN)
+    assert val.size == 3 and train.size == 6 and val.hwf == (6, 8, 30)
+    np.testing.assert_allclose(val.poses.numpy(), gold["forward_poses"][[0, 4, 8], :3, :4], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(train.ray_bounds.numpy(), gold["forward_bounds"][[1, 2, 3, 5, 6, 7]], rtol=2e-6)
+    assert tuple(val.ray_targets.shape) == (3, 6, 8, 3)
