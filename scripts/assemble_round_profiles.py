@@ -40,6 +40,9 @@ json.dump({
     "start_of_the_round_same_tool": {k: {kk: v[kk] for kk in ("ms_per_iteration", "frac_of_fp32_mfma_peak_whole_iteration", "stage_ms")}
                                       for k, v in before.items()},
     "bench_line_objects": {"train.shapes": full.get("train", {}).get("shapes"), "tiny.train": full.get("tiny", {}).get("train")},
+    "fused_backward": "the 64-wide rows (4x64, 8x64) run the whole backward in ONE kernel since the second half of the round (nerf_bwd_fused.hip: their "
+                      "'delta' stage is delta chain + all weight gradients, there is no weight_gradients / head_gradients stage); the separate kernels on the "
+                      "same box: profiles/%s_pmc_fused_backward.json: iteration_ab_same_box" % tag,
     "what_changed": "one partial per workgroup (k-split waves add up in LDS), a tuned 64x64 weight-gradient kernel, 32-row chunks for the "
                     "<= 128-wide products, the encoding rows written by the taping forward (no separate encode pass: the 'encodings' stage is "
                     "gone) -- DESIGN.md section 3.5, round-6 paragraph",
@@ -60,5 +63,62 @@ json.dump({
     "shipped_shapes": json.load(open(os.path.join(G, "script_traces_shipped.json"))),
     "tiny_shapes": json.load(open(os.path.join(G, "script_traces_tiny.json"))),
 }, open(os.path.join(P, f"{tag}_reference_scripts_on_hip.json"), "w"), indent=1)
+# ---- second half of round 6: the 64-wide networks' fused backward (nerf_bwd_fused.hip)
+def _load(path):
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
+
+
+raw = os.path.join(P, f"{tag}_raw")
+probe = ""
+for name in (f"fb_probe_{tag}_L4.txt", f"fb_probe_{tag}_L8.txt", f"fused_bwd_one_{tag}.txt"):
+    if os.path.exists(os.path.join(G, name)):
+        probe += f"==== {name}\n" + open(os.path.join(G, name)).read() + "\n"
+if probe:
+    open(os.path.join(raw, "fused_backward_probe.txt"), "w").write(
+        "tests/tools/probes/fb_probe.hip: the fused backward kernel itself with parts compiled out, on DENSE RANDOM operands (which clock\n"
+        "about 12 % lower than a real iteration's ReLU-sparse rows: compare the last block, a real tape); 262 144 samples of a 4x64 network\n"
+        "(config 1's iteration) / 524 288 of an 8x64 one.  Times of ablated variants mean nothing but time.\n\n" + probe)
+for name in (f"trace_{tag}/trace1.txt", f"trace_{tag}/trace2.txt"):
+    if os.path.exists(os.path.join(G, name)):
+        shutil.copy(os.path.join(G, name), os.path.join(raw, "iteration_kernels_" + ("config1" if name.endswith("1.txt") else "8x64") + ".txt"))
+counters = {}
+for f in sorted(os.listdir(G)):
+    if f.startswith(f"pmc_fb_{tag}_") and f.endswith(".txt"):
+        for line in open(os.path.join(G, f)):
+            parts = line.split()
+            if len(parts) == 2 and parts[0].isupper():
+                try:
+                    counters[parts[0]] = float(parts[1])
+                except ValueError:
+                    pass
+            elif "matrix pipe busy" in line or "fractions of SQ_WAVE_CYCLES" in line:
+                counters.setdefault("derived", []).append(line.strip())
+ab = {"separate_kernels": _load(os.path.join(G, f"tiny_train_separate_{tag}.json")), "fused_backward": _load(os.path.join(G, f"tiny_train_fused_{tag}.json"))}
+if counters or ab["fused_backward"]:
+    wc, busy, gui = counters.get("SQ_WAVE_CYCLES"), counters.get("SQ_VALU_MFMA_BUSY_CYCLES"), counters.get("GRBM_GUI_ACTIVE")
+    json.dump({
+        "what": "nm::mlp_backward_dw64_kernel<4> (the 64-wide networks' whole backward: delta chain + every weight gradient, nerf_bwd_fused.hip) "
+                "on a REAL tape of config 1's size (4x64, 8192 rays x 32 samples; tests/tools/fused_bwd_one.py): rocprofv3 --pmc passes, one "
+                "counter group per run (scripts/pmc_run.sh), averages over the launches; and the same-box A/B of whole iterations "
+                "(tests/tools/bench_tiny_train.py, NM_FUSED_BACKWARD=0/1: bench.py's tiny.train and train.shapes probes)",
+        "counters_per_launch": counters,
+        "matrix_pipe_busy_over_wave_resident_time": (busy / (wc * 4 / 2)) if wc and busy else None,
+        "clock_GHz_during_the_kernel": (gui / 8 / 265e-6 / 1e9) if gui else None,
+        "hbm_bytes_fetched_per_launch": counters.get("FETCH_SIZE", 0) * 1024 * 2 or None,     # FETCH_SIZE counts 64-byte halves on gfx950 (guide, HBM section)
+        "reading": "fetched = the tape once (2 KB per sample: 537 MB) -- no delta row is ever written or re-read; the matrix pipe is busy 0.68 of "
+                   "the wave-resident time at 2.3 GHz (not clock-bound, unlike the 128-wide weight gradients); executed MFMA work is 1.13 x the "
+                   "algorithmic FLOP (encoding products padded to 64 columns): 0.68 x 0.96 x 0.88 = 0.57 of the fp32 MFMA peak, the measured "
+                   "0.52 - 0.55.  2.2 VALU instructions per MFMA (mask application, delta-tile stores, bias sums, operand addressing) on two "
+                   "lock-stepped waves per SIMD; a quarter of the wave time waits (barriers, DMA); 38 % of the LDS-active cycles are 2-way "
+                   "conflicts of the 8-byte row-block reads, which the operand-read ablations of the probe show not to matter",
+        "algorithmic": {"samples": 262144, "flop_delta_plus_weight_gradients": 262144 * (36864 + 48896), "tape_bytes_read_once": 262144 * 2048,
+                        "mfma_issue_floor_us_at_2.4GHz": 157.0},
+        "iteration_ab_same_box": ab,
+        "probe": f"profiles/{tag}_raw/fused_backward_probe.txt", "kernel_traces": f"profiles/{tag}_raw/iteration_kernels_*.txt",
+    }, open(os.path.join(P, f"{tag}_pmc_fused_backward.json"), "w"), indent=1)
+
 print("headline", full["value"], "rays/s, frac", full["roofline"]["frac"], "| train", full["train"]["ms_per_iteration"], "ms",
       "| 8x128", full["train"]["shapes"]["8x128"]["ms_per_iteration"], "| tiny.train replay", full["tiny"]["train"]["ms_per_iteration_graph_replay"])

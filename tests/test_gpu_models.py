@@ -638,3 +638,36 @@ def test_validation_steps_against_the_reference_golden(pkg):
             assert got.shape == r.shape and got.dtype == np.uint8, (tag, k)
             diff = np.abs(got.astype(int) - r.astype(int))
             assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (tag, k, int(diff.max()), float((diff > 0).mean()))
+
+
+def test_config5_from_an_llff_scene_folder(pkg, tmp_path):
+    """BASELINE config 5's front end without a ray cache: an LLFF folder (poses_bounds.npy + images_4/) -> ColmapDataset.load_dataset
+    (loaders/load_llff.py) -> every view's rays on the GPU (nm_ray_bundle, then nm_ndc_rays: per-pixel origins) -> one validation
+    sample through BuFFModel.query.  The view's rays equal get_ray_bundle + ndc_rays of its recentred pose."""
+    from PIL import Image
+    from nerfmeshes_amd.data import ColmapDataset, DataBundle, DatasetType
+    from nerfmeshes_amd.nerf.nerf_helpers import get_ray_bundle, ndc_rays
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llff_scene.npz"))
+    np.save(tmp_path / "poses_bounds.npy", gold["poses_bounds"])
+    views, fh, fw, _ = gold["images_full_shape"]
+    for name, stack in (("images", np.zeros((views, fh, fw, 3), np.uint8)), ("images_4", gold["images_4"])):
+        (tmp_path / name).mkdir()
+        for i, img in enumerate(stack):
+            Image.fromarray(img).save(tmp_path / name / f"view_{i:03d}.png")
+    hp = S.hparams(model="BuFFModel", use_fine=False, num_coarse=48, num_fine=64, near=0.0, far=1.0, dataset_type="colmap")
+    hp.update({"dataset.basedir": str(tmp_path), "dataset.llff_downsample_factor": 4, "dataset.llff_hold_step": 4,
+               "dataset.caching.use_caching": False, "dataset.use_ndc": True})
+    model = pkg["models"].BuFFModel(hp).cuda().eval()
+    ds = ColmapDataset(model.cfg, spherify=False, type=DatasetType.VALIDATION)
+    assert len(ds) == 3
+    sample = DataBundle.deserialize(ds[1])                                  # view 4 of the scene
+    pose = torch.from_numpy(gold["forward_poses"][4, :3, :4])
+    o, d = get_ray_bundle(6, 8, 30.0, pose)
+    o, d = ndc_rays(6, 8, 30.0, 1.0, o[None, None, :], d)
+    assert torch.allclose(sample.ray_directions.cpu(), d.cpu(), atol=1e-5) and torch.allclose(
+        sample.ray_origins.cpu().reshape(d.shape), o.cpu().reshape(d.shape), atol=1e-5)
+    assert torch.equal(sample.ray_targets, torch.from_numpy(gold["forward_images"][4]))
+    batch = sample.to("cuda").to_ray_batch()
+    with torch.no_grad():
+        out = model.query((batch.ray_origins, batch.ray_directions, batch.ray_bounds))
+    assert out.rgb_map.shape == (48, 3) and bool(torch.isfinite(out.rgb_map).all())
