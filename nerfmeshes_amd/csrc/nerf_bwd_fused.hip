@@ -1,7 +1,7 @@
 // Back-propagation of the 64-wide networks (BASELINE config 1's 4x64, 8x64) in ONE kernel for gfx950: the delta chain of
 // nerf_train.hip's mlp_backward_kernel AND every weight / bias gradient of
 //   /root/reference/src/nerf/models.py:60-80 (what autograd's addmm backward computes for layer1, layers_xyz[*], fc_feat,
-//   layers_dir[0]) under /root/reference/src/models/model_nerf.py:88-151 (training_step + loss.backward()),
+//   layers_dir[0], fc_alpha, fc_rgb) under /root/reference/src/models/model_nerf.py:88-151 (training_step + loss.backward()),
 // so that no delta row is ever written to HBM and the tape is read exactly once.
 //
 // Why only 64 wide.  dW = delta^T @ act contracts over the samples: its accumulators must stay resident while a workgroup walks
@@ -20,11 +20,17 @@
 //   * every wave owns 2 of the 16 output tiles of each 64 x 64 product (1 of the 8 tiles of the 32 x 64 view-layer products)
 //     and contracts them over all 128 samples: v_mfma_f32_16x16x4_f32 with the sample index as the instruction's contraction
 //     index, A = one float of the delta tile, B = two floats of the activation row per lane and k-group (dw_kernel's feature
-//     permutation: tile q row i stands for feature 4 i + q);  bias gradients are the column sums of the A operands.
+//     permutation: tile q row i stands for feature 4 i + q);  bias gradients are the column sums of the A operands;
+//   * the two 4-row heads ride along: d_last is a small LDS tile of its own, fc_alpha = d_last^T h[L-1] on the row block of
+//     fc_feat's product, fc_rgb = d_last^T v on the columns 32..63 of the direction-encoding rows, where the taping forward puts
+//     the view layer's activation rows for these networks (nm_mlp_tape.v_stride).
 // Phases (one barrier each), for delta k:  A_k = [write delta_k to LDS | first weight chunk of stage k],  B_k = [second chunk |
 // the dW products of delta_k | DMA of the rows delta_k+1 needs].  Waits are COUNTED (s_waitcnt vmcnt(n) in front of a bare
 // s_barrier): the activation rows come from HBM and get a whole stage (~3 us) to land.
 // At the end a workgroup writes ONE partial of every product; fb_reduce_kernel adds the partials in index order (deterministic).
+// Where the time goes, and what was measured and dropped (deeper DMA prefetch, DMA from inline assembly, ReLU' off the LDS rows,
+// a row-major delta tile, the fully unrolled operand loop): DESIGN.md 3.5; tests/tools/probes/fb_probe.hip compiles parts of this
+// kernel out (the ABL template parameter) and times the rest.
 //
 // Roofline: MFMA (delta chain + weight gradients: 2 x the forward's FLOP); HBM traffic = the tape once (2 KB / sample).
 #include <cstdlib>
