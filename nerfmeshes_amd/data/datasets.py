@@ -104,9 +104,11 @@ class CachingDataset(SynthesizableDataset):
             self.data_bundle = self.load_dataset()
             self.init_sampling(self.data_bundle.hwf)
             o, d = convert_poses_to_rays(self.data_bundle.poses, *self.data_bundle.hwf)
-            self.data_bundle.ray_origins, self.data_bundle.ray_directions = o.cpu(), d.cpu()
+            self.data_bundle.ray_origins, self.data_bundle.ray_directions = o, d
             if cfg.dataset.use_ndc:
-                self._ndc_all(self.data_bundle)
+                self._ndc_all(self.data_bundle)            # on the GPU, where the rays were generated; leaves host tensors
+            else:
+                self.data_bundle.ray_origins, self.data_bundle.ray_directions = o.cpu(), d.cpu()
             print(f"Load whole dataset into the memory {time.time() - start}s seconds...")
 
     @staticmethod

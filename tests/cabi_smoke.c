@@ -189,6 +189,49 @@ int main(int argc, char** argv) {
         }
     }
     fclose(f);
+
+    /* ---- the 64-wide networks' WHOLE backward from plain C (ABI v6, nm_mlp_backward_fused): what loss.backward() leaves in the
+     *      .grad of every Linear of FlexibleNeRFModel (src/nerf/models.py:60-80) for sum(radiance) over the first 896 = 7 x 128
+     *      points as one-sample rays.  The tape holds the view layer's activation rows inside the direction-encoding rows
+     *      (d_v = d_enc_dir + 32, v_stride = 64).  Written to <out.bin>.fused: fc_feat.weight, layer1.bias, fc_rgb.weight,
+     *      fc_alpha.weight, layers_dir.0.weight */
+    {
+        const long m = 896;
+        char path[4096];
+        snprintf(path, sizeof path, "%s.fused", argv[4]);
+        FILE* g = fopen(path, "wb");
+        if (n >= m && nm_mlp_backward_fused_supported(mlp, m)) {
+            const size_t mt = (size_t)m / 16;
+            nm_mlp_tape t2 = {0};
+            float *d_rad3, *d_ones;
+            hipMalloc((void**)&t2.d_h, (size_t)L * m * H * 4); hipMalloc((void**)&t2.d_feat, (size_t)m * H * 4);
+            hipMalloc((void**)&t2.d_mask_h, (size_t)L * mt * 64 * 8); hipMalloc((void**)&t2.d_mask_v, mt * 64 * 8);
+            hipMalloc((void**)&t2.d_enc_xyz, (size_t)m * 64 * 4); hipMalloc((void**)&t2.d_enc_dir, (size_t)m * 64 * 4);
+            t2.d_v = t2.d_enc_dir + 32; t2.v_stride = 64;
+            hipMalloc((void**)&d_rad3, (size_t)m * 16); hipMalloc((void**)&d_ones, (size_t)m * 16);
+            hipMemcpy(d_ones, ones, (size_t)m * 16, hipMemcpyHostToDevice);
+            if (nm_mlp_forward_train(mlp, d_pts, 1, d_dirs, d_t, m, 1, &t2, d_rad3, NULL)) { fprintf(stderr, "forward_train (fused tape): %s\n", nm_last_error()); return 16; }
+            nm_mlp_param_grads pg = {0};
+            const size_t sizes[6] = {(size_t)H * DX, (size_t)H * H, (size_t)(H / 2) * (H + DD), H, 3 * (H / 2), H};
+            hipMalloc((void**)&pg.layer1_weight, sizes[0] * 4); hipMalloc((void**)&pg.layer1_bias, H * 4);
+            for (int i = 0; i < L - 1; ++i) { hipMalloc((void**)&pg.xyz_weight[i], sizes[1] * 4); hipMalloc((void**)&pg.xyz_bias[i], H * 4); }
+            hipMalloc((void**)&pg.feat_weight, sizes[1] * 4); hipMalloc((void**)&pg.feat_bias, H * 4);
+            hipMalloc((void**)&pg.dir_weight, sizes[2] * 4); hipMalloc((void**)&pg.dir_bias, (H / 2) * 4);
+            hipMalloc((void**)&pg.alpha_weight, H * 4); hipMalloc((void**)&pg.alpha_bias, 4);
+            hipMalloc((void**)&pg.rgb_weight, sizes[4] * 4); hipMalloc((void**)&pg.rgb_bias, 3 * 4);
+            void* d_fws;
+            hipMalloc(&d_fws, (size_t)nm_mlp_backward_fused_workspace_bytes(mlp));
+            if (nm_mlp_backward_fused(mlp, m, &t2, d_rad3, d_ones, NULL, &pg, d_fws, NULL)) { fprintf(stderr, "backward_fused: %s\n", nm_last_error()); return 17; }
+            const float* src[5] = {pg.feat_weight, pg.layer1_bias, pg.rgb_weight, pg.alpha_weight, pg.dir_weight};
+            const size_t cnt[5] = {sizes[1], H, sizes[4], H, sizes[2]};
+            float* host = (float*)malloc(sizes[2] * 4 > sizes[1] * 4 ? sizes[2] * 4 : sizes[1] * 4);
+            for (int k = 0; k < 5; ++k) {
+                if (hipMemcpy(host, src[k], cnt[k] * 4, hipMemcpyDeviceToHost) != hipSuccess) return 9;
+                fwrite(host, 4, cnt[k], g);
+            }
+        }
+        fclose(g);
+    }
     printf("abi %d flops/sample %lld ok\n", nm_abi_version(), (long long)nm_mlp_flops_per_sample(mlp, 0));
     nm_mlp_destroy(mlp);
     return 0;

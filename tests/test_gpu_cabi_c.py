@@ -88,3 +88,13 @@ def test_c_program_through_the_c_abi(tmp_path):
     assert rv.shape == (nv, 3) and rf.shape == (nf, 3)
     assert v.tobytes() == rv.tobytes() and f.view(np.int32).tobytes() == rf.astype(np.int32).tobytes()
     assert nrm.tobytes() == rn.tobytes() and val.tobytes() == rval.tobytes()
+    # ---- nm_mlp_backward_fused from C (ABI v6): the whole backward of the 4x64 network over the first 896 points in one call
+    fused = np.fromfile(str(tmp_path / "out.bin") + ".fused", dtype=np.float32)
+    m, Hh, dd = 896, 64, 27
+    assert fused.size == Hh * Hh + Hh + 3 * (Hh // 2) + Hh + (Hh // 2) * (Hh + dd), "the C program did not take the fused backward"
+    w64 = {k: torch.as_tensor(v, dtype=torch.float64).requires_grad_(True) for k, v in w.items()}
+    O.mlp_forward(w64, O.MLPSpec(**kw), torch.from_numpy(pts[:m]).double(), torch.from_numpy(dirs[:m]).double(), keep_graph=True).sum().backward()
+    parts = np.split(fused, np.cumsum([Hh * Hh, Hh, 3 * (Hh // 2), Hh]))
+    for name, ours in zip(("fc_feat.weight", "layer1.bias", "fc_rgb.weight", "fc_alpha.weight", "layers_dir.0.weight"), parts):
+        ref_g = w64[name].grad.numpy()
+        assert np.abs(ours.reshape(ref_g.shape) - ref_g).max() <= 2e-4 * np.abs(ref_g).max(), name
