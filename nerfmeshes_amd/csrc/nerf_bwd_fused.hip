@@ -236,6 +236,11 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     const int b_off64 = g * FB_ROWB + col * 16 + qb0 * 4;
     const int b_off32 = g * FB_ROWB + col * 16 + qb2 * 4;
     const bool bias64 = (wave & 1) == 0, bias32 = qb2 == 0;
+    // the two waves of a SIMD (waves w and w + 4) take a phase B in opposite orders -- one runs the chain's second weight chunk
+    // (matrix-dense, one LDS read per 4 MFMAs) while the other runs the products (an operand pair per 2 MFMAs + the bias sums).
+    // Measured: no faster than both in the same order (0.531 ms either way; split by wave & 1 instead: 0.548), but the allocator
+    // needs 18 registers less, which frees the 8-layer instantiation of its last spill
+    const bool dw_first = (wave & 4) != 0;
     // the heads: fc_rgb = natural column tile 2 + (wave & 1) of the direction rows, k-groups = wave >> 1 (mod 4); fc_alpha = column tile
     // wave & 3 of h[L-1], k-groups = wave >> 2 (mod 2).  A: row 4 ks + g of the heads' delta tile, word col
     const int hr_t = 2 + (wave & 1), hr_k = wave >> 1, ha_t = wave & 3, ha_k = wave >> 2;
@@ -360,10 +365,11 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             } else {
                 issue_rows(fa.enc_x + row0 * 64);
             }
-            if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+            if constexpr (!(ABL & 4)) if (!dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
             // grad(fc_alpha) = d_last^T @ h[L-1] (row 3; models.py:71), and the column sums of d_last = both heads' bias gradients
             if constexpr (!(ABL & 1)) fb_head_step<2>(acc_alpha, bs_head, dl_lane + ha_k * 256, slot_ptr(bslot) + ha_k * 1024 + g * FB_ROWB + (16 * ha_t + col) * 4);
+            if constexpr (!(ABL & 4)) if (dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             bslot = next_slot(bslot);
             fb_wait_barrier<ABL>(flying);
             par ^= 1;
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 } else {
                     issue_rows(fa.enc_x + row0 * 64);                      // layer1 contracts with the encoding rows
                 }
-                if constexpr (!(ABL & 4)) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
+                if constexpr (!(ABL & 4)) if (!dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
                 if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
                 bslot = next_slot(bslot);
                 if (sk == i) {                                             // cat(x, xyz): the encoding columns (models.py:64-65)
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                     if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_skip, unused, lds, a_off64, slot_ptr(bslot) + b_off64);
                     bslot = next_slot(bslot);
                 }
+                if constexpr (!(ABL & 4)) if (dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
                 fb_wait_barrier<ABL>(flying);
                 par ^= 1;
                 gw += 2 * FB_CHUNK;
