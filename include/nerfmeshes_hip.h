@@ -36,6 +36,11 @@ extern "C" {
  * every layer shape, row stride and sample count; nm_weight_grad / nm_head_grad forward to them (their shape and n % 16
  * restrictions are gone), nm_encode_samples_strided writes whole rows for any stride.  No signature changed; everything in
  * version 3 is unchanged.  nm_mlp_create accepts hidden sizes above 512 and up to 32 encoding functions (layer-wise path). */
+/* 5 (round 6): + nm_mlp_refresh_count / nm_mlp_weights_current (the stale-parameter guard), nm_mlp_tape.d_enc_xyz / d_enc_dir
+ * (optional: the encoding rows written by the taping forward) + nm_mlp_tapes_encodings.  nm_mlp_tape grew at its end; a
+ * zero-initialised struct of the old size keeps its meaning. */
+/* 6 (round 6): + nm_mlp_backward_fused (+ _supported, _workspace_bytes, nm_mlp_param_grads): the 64-wide networks' whole
+ * backward in one kernel; nm_mlp_tape.v_stride (0 = contiguous rows of d_v, as before).  No signature changed. */
 #define NM_ABI_VERSION 6
 
 const char* nm_last_error(void);
