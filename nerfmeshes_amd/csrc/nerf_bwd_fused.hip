@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
 
     f32x4 acc_dirf[1] = {{0.f, 0.f, 0.f, 0.f}}, acc_dire[1] = {{0.f, 0.f, 0.f, 0.f}};
     f32x4 acc_feat[2], acc_skip[2], acc_l1[2], acc_xyz[MAXL - 1][2];
-    float bs_dir = 0.f, bs_feat = 0.f, bs_l1 = 0.f, bs_xyz[MAXL - 1];
+    float bs_dir = 0.f, bs_feat = 0.f, bs_xyz[MAXL - 1];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         acc_feat[t] = acc_skip[t] = acc_l1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -355,16 +355,13 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             if constexpr (!(ABL & 4)) fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             fb_wait_barrier<ABL>(0, true);
             par ^= 1;
-            // ---- phase B1: the first chunk of layers_xyz[L-2]^T (or, for a one-layer trunk, of the next iteration) | rows of delta 2
-            const bool more = L >= 2;
-            if (more || has_next) stream_to_lds<8>(more ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
+            // ---- phase B1: the first chunk of the next chain stage -- layers_xyz[L-2]^T, or (L = 2: layers_xyz[0]^T is never applied,
+            //      see the last delta) of this workgroup's next iteration | rows of delta 2
+            const bool next_chain = L >= 3;
+            if (next_chain || has_next) stream_to_lds<8>(next_chain ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
             int flying = 4;
-            if (more) {
-                issue_rows(fa.tape_h + ((int64_t)(L - 2) * args.n + row0) * 64);
-                if (sk == L - 2) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
-            } else {
-                issue_rows(fa.enc_x + row0 * 64);
-            }
+            issue_rows(fa.tape_h + ((int64_t)(L - 2) * args.n + row0) * 64);
+            if (sk == L - 2) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
             if constexpr (!(ABL & 4)) if (!dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
             // grad(fc_alpha) = d_last^T @ h[L-1] (row 3; models.py:71), and the column sums of d_last = both heads' bias gradients
@@ -376,12 +373,11 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             gw += 2 * FB_CHUNK;
             fb_apply_mask(in, acc, m);
         }
-        // ================= deltas 2 .. L: at layers_xyz[i]'s pre-activation, i = L-2 .. 0; layers_xyz[i]^T (models.py:63-69)
+        // ================= deltas 2 .. L-1: at layers_xyz[i]'s pre-activation, i = L-2 .. 1; layers_xyz[i]^T (models.py:63-69)
 #pragma unroll
-        for (int i = MAXL - 2; i >= 0; --i) {
+        for (int i = MAXL - 2; i >= 1; --i) {
             if (i <= L - 2) {
-                uint64_t m = ~uint64_t(0);
-                if (i > 0) m = mrow[(int64_t)(i - 1) * mstride];
+                const uint64_t m = mrow[(int64_t)(i - 1) * mstride];
                 // ---- phase A
                 if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
                 stream_to_lds<8>(gw + FB_CHUNK, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
@@ -390,15 +386,11 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 if constexpr (!(ABL & 4)) fb_chunk<8, 0, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
                 fb_wait_barrier<ABL>(0, true);
                 par ^= 1;
-                // ---- phase B
-                if (i > 0 || has_next) stream_to_lds<8>(i > 0 ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
+                // ---- phase B: first chunk of layers_xyz[i-1]^T -- or, behind layers_xyz[1]^T, of the next iteration | rows of the next delta
+                if (i > 1 || has_next) stream_to_lds<8>(i > 1 ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
                 int flying = 4;
-                if (i > 0) {
-                    issue_rows(fa.tape_h + ((int64_t)(i - 1) * args.n + row0) * 64);
-                    if (sk == i - 1) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
-                } else {
-                    issue_rows(fa.enc_x + row0 * 64);                      // layer1 contracts with the encoding rows
-                }
+                issue_rows(fa.tape_h + ((int64_t)(i - 1) * args.n + row0) * 64);
+                if (sk == i - 1) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
                 if constexpr (!(ABL & 4)) if (!dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
                 if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
                 bslot = next_slot(bslot);
@@ -414,9 +406,18 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 fb_apply_mask(in, acc, m);
             }
         }
-        // ================= delta L+1: at layer1's output (no activation, models.py:62): grad(layer1) = delta^T @ xyz encoding
+        // ================= the last delta: at layers_xyz[0]'s pre-activation.  layer1 has NO activation (models.py:62), so the delta at its
+        // output is LINEAR in this one -- W0^T delta per sample -- and its weight gradient is W0^T applied to a sum over the samples:
+        //     grad(layer1.weight) = W0^T (delta^T @ xyz encoding),      grad(layer1.bias) = W0^T (column sums of delta),
+        // with W0 = layers_xyz[0]'s hidden columns.  The chain stops here: layers_xyz[0]^T is applied ONCE per workgroup, in the
+        // epilogue, to the 64 x 64 product this delta accumulates with the encoding rows -- a chain stage, a delta tile and a barrier
+        // less per iteration (64 of 352 chain MFMAs at 4 layers).
         if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
         fb_wait_barrier<ABL>(0, true);
+        issue_rows(fa.enc_x + row0 * 64);
+        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_xyz[0], bs_xyz[0], lds, a_off64, slot_ptr(bslot) + b_off64);
+        bslot = next_slot(bslot);
+        fb_wait_barrier<ABL>(4);
         int flying = 0;
         if (has_next) {
             fetch_head(it + gridDim.x);
@@ -424,7 +425,10 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             issue_rows(fa.enc_d + (it + gridDim.x) * (FB_ROWS * 64));
             flying = 8;
         }
-        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_l1, bs_l1, lds, a_off64, slot_ptr(bslot) + b_off64);
+        {
+            float unused = 0.f;
+            if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_l1, unused, lds, a_off64, slot_ptr(bslot) + b_off64);    // delta^T @ xyz encoding
+        }
         bslot = next_slot(bslot);
         fb_wait_barrier<ABL>(flying);
     }
@@ -455,7 +459,39 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     for (int i = 0; i < MAXL - 1; ++i)
         if (i <= L - 2) store64(out + FB_P_XYZ + i * 4096, acc_xyz[i]);
     if (sk >= 0) store64(out + FB_P_SKIP, acc_skip);
-    store64(out + FB_P_L1, acc_l1);
+    // layer1 = layers_xyz[0]^T applied to this workgroup's (delta^T @ encoding) -- tile-distributed in acc_l1 -- and, as column 63 (the
+    // encoding is at most 63 wide), to the column sums of that delta: the 64 x 64 product goes through LDS into the chain's B-operand
+    // layout (a "sample" = a column), the transposed weights come from the stream as for any chain stage: 32 MFMAs per wave
+    {
+        stream_to_lds<8>(args.wstream + (2 * L - 1) * FB_CHUNK, lds, 2 * FB_CHUNK, wave, lane);      // layers_xyz[0]^T, both chunks
+        float* mt = reinterpret_cast<float*>(lds + FB_OFF_DBUF);                                     // [k][64]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mt[(4 * (4 * g + r) + qa) * 64 + 4 * col + qb0 + t] = acc_l1[t][r];
+        fb_wait_barrier<ABL>(0);
+        const float colsum = fold(bs_xyz[0]);
+        if (bias64 && g == 0) mt[(4 * col + qa) * 64 + 63] = colsum;
+        fb_wait_barrier<ABL>(0);
+        const int jt = wave & 3;
+        const bool upper = (wave & 4) != 0;                       // row tiles 2, 3 (else 0, 1)
+        f32x4 o2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float b = mt[(16 * (ks >> 2) + 4 * g + (ks & 3)) * 64 + 16 * jt + col];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + ks * 1024 + lane * 16);
+            o2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(upper ? a[2] : a[0], b, o2[0], 0, 0, 0);
+            o2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(upper ? a[3] : a[1], b, o2[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ((upper ? 2 : 0) + t) + 4 * g + r;
+                out[FB_P_L1 + row * 64 + 16 * jt + col] = o2[t][r];
+                if (jt == 3 && col == 15) out[FB_P_BIAS + FB_B_L1 + row] = o2[t][r];
+            }
+    }
     float* ob = out + FB_P_BIAS;
     {
         const float v = fold(bs_dir);
@@ -469,10 +505,6 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     for (int i = 0; i < MAXL - 1; ++i) {
         const float v = fold(bs_xyz[i]);
         if (i <= L - 2 && bias64 && g == 0) ob[FB_B_XYZ + i * 64 + 4 * col + qa] = v;
-    }
-    {
-        const float v = fold(bs_l1);
-        if (bias64 && g == 0) ob[FB_B_L1 + 4 * col + qa] = v;
     }
     // the heads: D rows 0..3 (the live rows of the delta tile) are registers 0..3 of lane group 0.  The waves that split a tile's
     // k-groups between them add their accumulators up through LDS, in k-part order (deterministic): one partial per workgroup
