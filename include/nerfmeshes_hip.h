@@ -40,7 +40,8 @@ extern "C" {
  * (optional: the encoding rows written by the taping forward) + nm_mlp_tapes_encodings.  nm_mlp_tape grew at its end; a
  * zero-initialised struct of the old size keeps its meaning. */
 /* 6 (round 6): + nm_mlp_backward_fused (+ _supported, _workspace_bytes, nm_mlp_param_grads): the 64-wide networks' whole
- * backward in one kernel; nm_mlp_tape.v_stride (0 = contiguous rows of d_v, as before).  No signature changed. */
+ * backward in one kernel; nm_mlp_tape.v_stride (0 = contiguous rows of d_v, as before); nm_mlp_backward_ex (flags),
+ * nm_mlp_export_xyz_weight.  No signature changed. */
 #define NM_ABI_VERSION 6
 
 const char* nm_last_error(void);
@@ -299,6 +300,20 @@ int nm_mlp_forward_train(nm_mlp* mlp, const float* d_origins, int origins_per_ra
  * backward lists all of them; tests/cabi_smoke.c does one from plain C). */
 int nm_mlp_backward(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
                     const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream);
+
+/* ABI v6.  nm_mlp_backward with flags.  NM_BACKWARD_STOP_AT_XYZ0: the chain ends at layers_xyz[0]'s pre-activation -- d_h[1] is
+ * the last delta written, d_h[0] is NOT produced, one of the L + 1 transposed layers is never applied (an eighth of the kernel at
+ * 8 layers).  layer1 has no activation (src/nerf/models.py:62), so the delta at its output is linear in d_h[1] and its gradients
+ * follow from sums over the samples:  grad(layer1.weight) = W0^T (d_h[1]^T @ encoding rows),  grad(layer1.bias) = W0^T (column
+ * sums of d_h[1]),  W0 = layers_xyz[0].weight's hidden columns -- two calls of nm_weight_grad_ex, the second over H rows
+ * (nerfmeshes_amd/train_ops.py: backward).  Tuned-family handles with num_layers >= 3 (nm_mlp_backward_stops_at_xyz0).
+ * nm_mlp_export_xyz_weight writes layers_xyz[layer].weight, (H, H) or (H, H + dx) row-major, out of the handle's PACKED image --
+ * the values the kernels of this forward / backward pair used, whatever happened to the live tensors since. */
+#define NM_BACKWARD_STOP_AT_XYZ0 1
+int nm_mlp_backward_stops_at_xyz0(const nm_mlp* mlp);
+int nm_mlp_backward_ex(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
+                       const float* d_grad_radiance, const nm_mlp_deltas* deltas, int32_t flags, void* stream);
+int nm_mlp_export_xyz_weight(nm_mlp* mlp, int32_t layer, float* d_out, void* stream);
 
 /* ABI v6.  The whole back-propagation of a 64-wide network in ONE kernel (nerf_bwd_fused.hip): the delta chain of
  * nm_mlp_backward AND the weight / bias gradients of layer1, layers_xyz[*], fc_feat and layers_dir[0] -- what loss.backward()

@@ -369,6 +369,16 @@ __global__ __launch_bounds__(256) void gather_parameters(const int32_t* __restri
     if (threadIdx.x == 0) atomicAdd(check, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// the inverse of the gather for one tensor: out[element] = blob[i] wherever index[i] names that tensor (a parameter element sits in
+// the packed image at least once -- forward stream, transposed stream --, always with the same value)
+__global__ __launch_bounds__(256) void scatter_tensor(const int32_t* __restrict__ index, const float* __restrict__ blob, int64_t count,
+                                                      int tensor, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t s = index[i];
+    if (s >= 0 && (s >> 24) == tensor) out[s & 0xffffff] = blob[i];
+}
+
 static bool is_skip(const nm_mlp_desc& d, int i) {   // models.py:37,63
     return i % d.skip_step == 0 && i > 0 && i != d.num_layers - 1;
 }
@@ -753,6 +763,17 @@ int nm_mlp_refresh(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream) {
 }
 
 int64_t nm_mlp_refresh_count(const nm_mlp* m) { return m ? m->refresh_count : -1; }
+
+int nm_mlp_export_xyz_weight(nm_mlp* m, int32_t layer, float* d_out, void* stream_) {
+    NM_REQUIRE(m && d_out, "null argument");
+    NM_REQUIRE(!m->lw, "the layer-wise path keeps no index map of its packed image");
+    NM_REQUIRE(layer >= 0 && layer <= m->desc.num_layers - 2, "no such layers_xyz");
+    const int64_t n = (int64_t)m->blob_floats;        // (launched on the caller's stream, which belongs to the handle's device)
+    hipLaunchKernelGGL(scatter_tensor, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->d_index,
+                       static_cast<const float*>(m->d_blob), n, (int)(T_XYZ0 + 2 * layer), d_out);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int nm_mlp_weights_current(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream_, int32_t* differs) {
     NM_REQUIRE(m && d_weights && differs, "null argument");

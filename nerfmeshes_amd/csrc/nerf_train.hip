@@ -11,6 +11,7 @@
 //   * weight gradients dW = delta^T @ activation are plain (H x n) @ (n x H) GEMMs over those rows: library work
 //     (rocBLAS through torch.mm in hip_ops.py), per the "library GEMMs only for plain GEMMs" rule.
 // Roofline: MFMA.  557 056 MAC / sample for the 8x256 net (vs 593 408 forward).
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -139,23 +140,27 @@ __global__ __launch_bounds__(NW * 64, H <= 128 ? 4 : 2) void mlp_backward_kernel
             masked_operand<N::NT>(acc, m, in);
         }
         }
-        // ---- layers_xyz[i]^T, i = L-2 .. 0: delta at the input of layers_xyz[i] (x[i-1] post-ReLU, or layer1's output)
+        // ---- layers_xyz[i]^T, i = L-2 .. 0: delta at the input of layers_xyz[i] (x[i-1] post-ReLU, or layer1's output).
+        //      stop_at_xyz0: layers_xyz[0]^T is left out -- layer1 has no activation (models.py:62), so the caller gets its gradient
+        //      from the delta at layers_xyz[0] by linearity (train_ops.backward: W0^T applied once to delta^T @ encoding) -- and the
+        //      chain ends with d_h[1]
+        const int last_i = args.stop_at_xyz0 ? 1 : 0;
 #pragma unroll 1
-        for (int i = L - 2; i >= 0; --i) {
+        for (int i = L - 2; i >= last_i; --i) {
 #pragma unroll
             for (int nt = 0; nt < N::NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             uint64_t m = ~uint64_t(0);
             if (i > 0) m = tile_ok ? mrow[(int64_t)(i - 1) * mstride] : 0;
             const char* tsrc = gw + N::KH * N::STEP;
             int tbytes = N::LDSBUF;
-            if (i == 0) { tsrc = args.wstream; tbytes = has_next ? FIRST : 0; }
+            if (i == last_i) { tsrc = args.wstream; tbytes = has_next ? FIRST : 0; }
             gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, true, false, 0, true>(
                 acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane,
                 d_row ? d_row + (int64_t)(i + 1) * args.n * H : nullptr);   // the delta this stage consumes
             gw += N::KH * N::STEP;
             masked_operand<N::NT>(acc, m, in);
         }
-        store_rows<N::NT>(args.d_h, H, sample, valid, in, g);               // delta at layer1's output: nothing follows
+        store_rows<N::NT>(args.d_h + (int64_t)last_i * args.n * H, H, sample, valid, in, g);   // the chain's last delta: nothing follows
         gw = args.wstream;
     }
 }
@@ -380,7 +385,20 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
 
 int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
                     const float* d_grad_radiance, const nm_mlp_deltas* deltas, void* stream) {
+    return nm_mlp_backward_ex(m, n, tape, d_radiance, d_grad_radiance, deltas, 0, stream);
+}
+
+int nm_mlp_backward_stops_at_xyz0(const nm_mlp* m) {
+    // NM_BACKWARD_STOP_AT_XYZ0 is served by the tuned delta kernels of networks with at least two layers_xyz
+    return m && !m->lw && m->plan->generic_nt == 0 && m->desc.num_layers >= 3 && !(getenv("NM_BACKWARD_LINEAR_LAYER1") && atoi(getenv("NM_BACKWARD_LINEAR_LAYER1")) == 0);
+}
+
+int nm_mlp_backward_ex(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
+                       const float* d_grad_radiance, const nm_mlp_deltas* deltas, int32_t flags, void* stream) {
     NM_REQUIRE(m && tape && d_radiance && d_grad_radiance && deltas && n >= 0, "bad argument");
+    NM_REQUIRE((flags & ~NM_BACKWARD_STOP_AT_XYZ0) == 0, "unknown flag");
+    NM_REQUIRE(!(flags & NM_BACKWARD_STOP_AT_XYZ0) || (!m->lw && m->plan->generic_nt == 0 && m->desc.num_layers >= 3),
+               "NM_BACKWARD_STOP_AT_XYZ0 needs a tuned-family handle with num_layers >= 3 (ask nm_mlp_backward_stops_at_xyz0)");
     const nm_mlp_desc& d = m->desc;
     const bool flat = d.use_viewdirs == 0;
     const bool generic = m->plan->generic_nt != 0 || m->lw;
@@ -416,6 +434,7 @@ int nm_mlp_backward(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* 
     a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
     a.n = n; a.tiles = (n + 15) / 16;
     a.d_h = deltas->d_h; a.d_feat = deltas->d_feat; a.d_v = deltas->d_v; a.d_last = deltas->d_last;
+    a.stop_at_xyz0 = (flags & NM_BACKWARD_STOP_AT_XYZ0) ? 1 : 0;
     const int H = d.hidden_size;
     const int lds_bytes = 2 * KC * (H / 16) * 256 + (((H + (flat ? 3 * H : 3 * H / 2)) * 4 + 255) & ~255);
     const auto kernel = flat ? plan->backward_flat : plan->backward;

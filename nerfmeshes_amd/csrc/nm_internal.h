@@ -146,6 +146,7 @@ struct MlpBwdArgs {
     const float* tape_feat;  // (n, H)
     const float* tape_v;     // (n, H / 2)
     int32_t g_h, g_hd;       // real widths (row strides)
+    int32_t stop_at_xyz0;    // tuned delta kernel: do not apply layers_xyz[0]^T (d_h[0] is not produced; NM_BACKWARD_STOP_AT_XYZ0)
 };
 
 // Flat addressing of the trainable tensors (index maps of the packed blob: tensor id << 24 | element)

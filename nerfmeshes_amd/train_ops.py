@@ -166,6 +166,7 @@ def encode_samples(mlp, origins, dirs, t):
 
 
 _dw_ws = {}
+LINEAR_LAYER1_MIN_WORK = 4e9      # samples x hidden^2 from which backward() takes layer1's gradient by linearity (tests set it to 0)
 
 
 def _workspace(mlp, tag, need):
@@ -247,9 +248,14 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     dfeat, dv = (None, None) if flat else (torch.empty(n, H, **f32), torch.empty(n, H // 2, **f32))
     ct = _tape_struct(tape)
     cd = MlpDeltas(_ptr(dh), None if flat else _ptr(dfeat), None if flat else _ptr(dv), _ptr(dlast))
+    # layer1 has no activation (models.py:62): the delta at its output is W0^T times the delta at layers_xyz[0], so its gradient is
+    # W0^T applied ONCE to sums over the samples -- the tuned delta kernels then stop one transposed layer early (an eighth of the
+    # kernel at 8 layers) and d_h[0] is never produced
+    # (worth it from ~60 us of saved matrix work on: the path costs five small launches -- n H^2 > 4e9)
+    linear_l1 = bool(lib.nm_mlp_backward_stops_at_xyz0(mlp.handle)) and n * H * H > LINEAR_LAYER1_MIN_WORK
     with _stage("delta"):
-        check(lib.nm_mlp_backward(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), _stream()),
-              "nm_mlp_backward")
+        check(lib.nm_mlp_backward_ex(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), 1 if linear_l1 else 0,
+                                     _stream()), "nm_mlp_backward_ex")
     h, feat, v = tape["h"], tape["feat"], tape["v"]
     dx = 6 * int(d["num_encoding_fn_xyz"]) + (3 if d.get("include_input_xyz", True) else 0)
     dd = 0 if flat else 6 * int(d["num_encoding_fn_dir"]) + (3 if d.get("include_input_dir", True) else 0)
@@ -281,7 +287,11 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
             g[name + ".bias"] = db
         g[name + ".weight"] = out
 
-    product("layer1", dh[0], enc_x, dx)
+    if linear_l1:
+        l1_sums = torch.empty(H, dx + 1, **f32)           # [ d_h[1]^T @ encoding | column sums of d_h[1] ]
+        jobs.append((dh[1], enc_x, dx, l1_sums, 0, None))
+    else:
+        product("layer1", dh[0], enc_x, dx)
     for i in range(L - 1):
         delta = dh[1 + i]
         if is_skip(i):                                                                  # cat(x, xyz): models.py:64-65
@@ -297,6 +307,14 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         if dd:
             product("layers_dir.0", dv, enc_d, dd, out=gw, col0=H, bias=False)
     _weight_grad_batch(mlp, jobs)
+    if linear_l1:
+        # grad(layer1) = W0^T @ [ d_h[1]^T enc | sum d_h[1] ]: the same weight-gradient kernel over H "samples" (rows of W0 as it
+        # sits in the handle's packed image -- what the forward of this step used)
+        l1_sums[:, dx].copy_(g["layers_xyz.0.bias"])
+        w0 = torch.empty(H, H, **f32)
+        check(lib.nm_mlp_export_xyz_weight(mlp.handle, 0, _ptr(w0), _stream()), "nm_mlp_export_xyz_weight")
+        both, _ = _weight_grad(mlp, w0, l1_sums, dx + 1, bias=False)
+        g["layer1.weight"], g["layer1.bias"] = both[:, :dx].contiguous(), both[:, dx].contiguous()
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
     if flat:

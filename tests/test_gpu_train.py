@@ -887,3 +887,32 @@ def test_weight_grad_batch_vs_fp64(out_f, in_f, jobs, n, general, monkeypatch):
             assert float((b.double().cpu() - deltas[j].double().sum(0)).abs().max()) <= 2e-6 * float(deltas[j].abs().sum(0).max() + 1)
             assert torch.equal(b, b1)
     assert bool((wide[:, :7] == 5.0).all()), "wrote outside its column window"
+
+
+@pytest.mark.parametrize("kw", SHAPES + FLAT_SHAPES, ids=["4x64", "8x256", "3x128", "4x64-flat", "8x256-flat", "5x128-flat"])
+@pytest.mark.parametrize("rays,samples", [(37, 9), (144, 16)])
+def test_layer1_gradient_by_linearity_vs_autograd_and_the_full_chain(ops, T, kw, rays, samples, monkeypatch):
+    """layer1 has no activation (models.py:62): with NM_BACKWARD_STOP_AT_XYZ0 the delta kernel never applies layers_xyz[0]^T and
+    backward() takes grad(layer1) = W0^T [d_h[1]^T enc | sum d_h[1]] (W0 exported from the handle's packed image).  Every gradient
+    against fp64 autograd at the training tests' tolerance, and layer1's against the full chain's on the same tape.  (The path is
+    taken from n H^2 > 4e9 on: forced here.  Sample counts that the 64-wide networks' fused backward does not serve.)"""
+    spec = O.MLPSpec(**kw)
+    w = _weights(kw)
+    mlp = ops.HipMLP(w, kw, "cuda")
+    from nerfmeshes_amd import _lib
+    assert _lib.load().nm_mlp_backward_stops_at_xyz0(mlp.handle) == 1
+    o, d, t = _rays(rays, samples, rays)
+    grad_out = torch.randn(rays, samples, 4, generator=torch.Generator().manual_seed(1))
+    rad, tape = T.forward_train(mlp, o.cuda(), d.cuda(), t.cuda())
+    full = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
+    monkeypatch.setattr(T, "LINEAR_LAYER1_MIN_WORK", 0)
+    got = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
+    g32 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float32)[1]
+    g64 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float64)[1]
+    assert set(got) == set(g64) == set(full)
+    worst = {k: (_rel(got[k], ref), _rel(full[k], ref), _rel(g32[k], ref)) for k, ref in g64.items()}
+    bad = {k: v for k, v in worst.items() if v[0] > max(2e-4, 20 * v[2])}
+    assert not bad, f"gradient mismatch (by linearity, full chain, torch-fp32) relative to fp64 autograd: {bad}"
+    for k in got:
+        if not k.startswith("layer1."):
+            assert torch.equal(got[k], full[k]), f"{k}: every other gradient comes out of the same kernels on the same deltas"
