@@ -118,8 +118,8 @@ def _train(t):
     if not isinstance(t, dict) or "error" in t:
         return _small(t)
     out = _small(t, "ms_per_iteration", "rays_per_iteration")
-    if isinstance(t.get("roofline"), dict) and "frac_of_executed_work" in t["roofline"]:
-        out["frac_exec"] = t["roofline"]["frac_of_executed_work"]      # `frac` counts the reference's autograd work, this one what is executed
+    if isinstance(t.get("roofline"), dict) and "frac_of_reference_work" in t["roofline"]:
+        out["frac_ref_work"] = t["roofline"]["frac_of_reference_work"]      # `frac` counts the matrix work executed, this one the reference's autograd
     if isinstance(t.get("kernels"), dict):
         out["stages"] = {k: _pick(v, "ms", "frac") for k, v in t["kernels"].items() if isinstance(v, dict) and v.get("ms", 0) >= 0.1}
     if isinstance(t.get("shapes"), dict):
@@ -168,7 +168,7 @@ def compact_line(out, full_path=None):
         line["tiny"] = _small(out["tiny"], "ms_per_view")
         tr = out["tiny"].get("train") if isinstance(out["tiny"], dict) else None
         if isinstance(tr, dict):
-            line["tiny"]["train"] = _pick(tr, "ms_per_iteration_eager", "ms_per_iteration_graph_replay", "frac_graph_replay", "frac_exec",
+            line["tiny"]["train"] = _pick(tr, "ms_per_iteration_eager", "ms_per_iteration_graph_replay", "frac_graph_replay", "frac_ref_work",
                                           "rays_per_s_graph_replay")
     if "train" in out:
         line["train"] = _train(out["train"])

@@ -54,16 +54,21 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
     flops = samples * (fwd + delta + fwd)
     achieved = flops / (ms * 1e-3) / 1e12
     # round 6: layer1's gradient is taken by linearity (no activation follows layer1: train_ops.backward, nm_mlp_backward_ex) -- the
-    # transposed layers_xyz[0] is applied once to a sum over the samples instead of per sample.  `frac` keeps counting what the
-    # reference's autograd does (the definition of every earlier round); `frac_of_executed_work` leaves that layer out
-    executed = samples * (fwd + delta - 2 * Hh * Hh + fwd)
+    # transposed layers_xyz[0] is applied once to a sum over the samples instead of per sample.  `frac` counts the matrix work that is
+    # EXECUTED (that layer left out of the delta term); `frac_of_reference_work` what the reference's autograd does, the basis of
+    # the earlier rounds' figures
+    reference_flops = flops
+    delta -= 2 * Hh * Hh * _linear_layer1_share(Hh, rays, (NUM_COARSE, NUM_COARSE + NUM_FINE))
+    flops = samples * (fwd + delta + fwd)
+    achieved = flops / (ms * 1e-3) / 1e12
     out = {"value": rays / ms * 1e3, "unit": "rays/s", "ms_per_iteration": ms, "rays_per_iteration": rays,
            "workload": "training step: 8x256 coarse+fine, 64+128 samples, perturb + noise, Adam (forward + HIP backward + step)",
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "samples_per_iteration": samples,
-                        "frac_of_executed_work": executed / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                        "flop_basis": "frac: the matrix work of the reference's autograd (forward + delta + weight gradients); "
-                                      "frac_of_executed_work: without the one transposed layer the backward no longer applies per sample",
+                        "frac_of_reference_work": reference_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "flop_basis": "frac: the matrix work executed (forward + delta + weight gradients, the delta chain without "
+                                      "layers_xyz[0]^T: layer1's gradient by linearity); frac_of_reference_work: the reference's autograd, "
+                                      "which applies that layer per sample (the basis of rounds 4 - 5)",
                         "algorithmic_flops_per_sample": {"forward": fwd, "delta": delta, "weight_gradients": fwd},
                         "floor_ms_at_peak": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                         "note": "whole-iteration wall time (taping forward, delta kernel, dW kernels, encodings, compositing, Adam) "
@@ -125,6 +130,15 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
     return out
 
 
+def _linear_layer1_share(hidden, rays, samples_per_net):
+    """Fraction of an iteration's samples whose backward takes layer1's gradient by linearity (the delta chain then leaves
+    layers_xyz[0]^T out): every sample of the 64-wide networks' fused backward, and of the separate kernels the networks whose
+    n x hidden^2 passes train_ops.LINEAR_LAYER1_MIN_WORK."""
+    from nerfmeshes_amd import train_ops
+    taken = [s for s in samples_per_net if hidden == 64 and (rays * s) % 128 == 0 or rays * s * hidden * hidden > train_ops.LINEAR_LAYER1_MIN_WORK]
+    return sum(taken) / float(sum(samples_per_net))
+
+
 def train_flops_per_sample(kw):
     """(forward, delta, weight-gradient) algorithmic FLOP per sample of a view-dependent FlexibleNeRFModel (weights only, as SURVEY
     8(d): /root/reference/src/nerf/models.py:5-58 lists the layers)."""
@@ -180,16 +194,18 @@ def shape_train_probe(dev, name, over, rays, iters=20, replay=True):
 
     samples = rays * (kw["num_coarse"] + (kw["num_coarse"] + kw["num_fine"] if kw["use_fine"] else 0))
     flops = samples * sum(train_flops_per_sample(kw))
+    per_net = (kw["num_coarse"],) + ((kw["num_coarse"] + kw["num_fine"],) if kw["use_fine"] else ())
+    reference_flops = flops
+    flops -= samples * 2 * kw["hidden_size"] ** 2 * _linear_layer1_share(kw["hidden_size"], rays, per_net)   # layer1 by linearity: executed work
     frac = lambda ms: flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS  # noqa: E731
-    executed = flops - samples * 2 * kw["hidden_size"] ** 2      # layer1 by linearity (both backward paths): one transposed layer less per sample
     eager = timed(build())
     out = {"workload": f"{name}: {rays} rays x {samples // rays} samples, perturb + noise, fused Adam", "rays": rays,
            "samples_per_iteration": samples, "ms_per_iteration": eager, "frac": frac(eager),
-           "frac_of_executed_work": frac(eager) * executed / flops,
+           "frac_of_reference_work": frac(eager) * reference_flops / flops,
            "floor_ms_at_peak": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3}
     if replay:
         ms = timed(train_ops.GraphedStep(build(capturable=True)))
-        out.update(ms_graph_replay=ms, frac_graph_replay=frac(ms), frac_graph_replay_of_executed_work=frac(ms) * executed / flops,
+        out.update(ms_graph_replay=ms, frac_graph_replay=frac(ms), frac_graph_replay_of_reference_work=frac(ms) * reference_flops / flops,
                    rays_per_s_graph_replay=rays / ms * 1e3)
     return out
 
@@ -205,7 +221,7 @@ def tiny_train_probe(dev, rays=8192, iters=40):
     r = shape_train_probe(dev, "config 1 training iteration: 4x64", TINY_TRAIN, rays, iters)
     return {"workload": r["workload"], "ms_per_iteration_eager": r["ms_per_iteration"], "frac_eager": r["frac"],
             "ms_per_iteration_graph_replay": r["ms_graph_replay"], "frac_graph_replay": r["frac_graph_replay"],
-            "frac_exec": r["frac_graph_replay_of_executed_work"],      # on the matrix work actually executed (layer1 by linearity)
+            "frac_ref_work": r["frac_graph_replay_of_reference_work"],   # counting the transposed layer the backward no longer applies per sample
             "rays_per_s_graph_replay": r["rays_per_s_graph_replay"], "floor_ms_at_peak": r["floor_ms_at_peak"],
             "note": "launch-bound: one captured hipGraph replaces ~40 launches per iteration (train_ops.GraphedStep)"}
 

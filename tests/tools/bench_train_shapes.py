@@ -126,8 +126,14 @@ def main():
         stages = {k: round(sorted(d.get(k, 0.0) for d in per_iter)[len(per_iter) // 2], 3) for k in per_iter[0]}
         stages["rest"] = round(ms - sum(stages.values()), 3)
         fwd, delta, dw = flops_per_sample(kw, viewdirs)
-        flops = samples * (fwd + delta + dw)
         variant = model.model_coarse.hip().kernel_variant()[0]
+        if variant < 1000 and kw["num_layers"] >= 3:
+            # layer1's gradient by linearity (tuned family: train_ops.backward / the fused backward): the executed delta chain leaves
+            # layers_xyz[0]^T out for the networks whose sample count takes that path -- the FLOP counted here are the executed ones
+            from benchlib.train import _linear_layer1_share
+            per_net = (kw["num_coarse"],) + ((kw["num_coarse"] + kw["num_fine"],) if kw["use_fine"] else ())
+            delta -= 2 * kw["hidden_size"] ** 2 * _linear_layer1_share(kw["hidden_size"], rays, per_net)
+        flops = samples * (fwd + delta + dw)
         out[name] = {"rays": rays, "samples_per_iteration": samples, "ms_per_iteration": round(ms, 3),
                      "rays_per_s": round(rays / ms * 1e3), "kernel_family": "layer-wise" if variant == 2000 else ("generic class %d" % (variant - 1000) if variant >= 1000 else "tuned"),
                      "algorithmic_tflop_per_iteration": round(flops / 1e12, 4),
