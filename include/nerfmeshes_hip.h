@@ -314,6 +314,12 @@ int nm_mlp_backward_stops_at_xyz0(const nm_mlp* mlp);
 int nm_mlp_backward_ex(nm_mlp* mlp, int64_t n, const nm_mlp_tape* tape, const float* d_radiance,
                        const float* d_grad_radiance, const nm_mlp_deltas* deltas, int32_t flags, void* stream);
 int nm_mlp_export_xyz_weight(nm_mlp* mlp, int32_t layer, float* d_out, void* stream);
+/* The same identity gives layers_xyz[0]'s own weight gradient without its activation rows: tape.d_h[0] = layer1(enc) = W1 enc + b1, so
+ *     grad(layers_xyz[0].weight) = d_h[1]^T @ tape.d_h[0] = [d_h[1]^T enc | sum d_h[1]] @ [W1 | b1]^T
+ * -- the (H, dx + 1) matrix of sums the caller already has, times (dx + 1, H) = nm_mlp_export_layer1_transposed: rows 0 .. dx - 1
+ * hold layer1.weight^T, row dx layer1.bias, again out of the packed image.  One of the L hidden x hidden weight-gradient products
+ * over all samples becomes a product over dx + 1 rows. */
+int nm_mlp_export_layer1_transposed(nm_mlp* mlp, float* d_out, void* stream);
 
 /* ABI v6.  The whole back-propagation of a 64-wide network in ONE kernel (nerf_bwd_fused.hip): the delta chain of
  * nm_mlp_backward AND the weight / bias gradients of layer1, layers_xyz[*], fc_feat and layers_dir[0] -- what loss.backward()

@@ -379,6 +379,18 @@ __global__ __launch_bounds__(256) void scatter_tensor(const int32_t* __restrict_
     if (s >= 0 && (s >> 24) == tensor) out[s & 0xffffff] = blob[i];
 }
 
+// [layer1.weight | layer1.bias]^T out of the packed image: out[(j, i)] = W1[i][j] for j < dx, out[(dx, i)] = b1[i]; (dx + 1, H) row-major
+__global__ __launch_bounds__(256) void scatter_layer1_t(const int32_t* __restrict__ index, const float* __restrict__ blob, int64_t count,
+                                                        int H, int dx, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const int32_t s = index[p];
+    if (s < 0) return;
+    const int tensor = s >> 24, e = s & 0xffffff;
+    if (tensor == T_L1W) out[(int64_t)(e % dx) * H + e / dx] = blob[p];
+    else if (tensor == T_L1B) out[(int64_t)dx * H + e] = blob[p];
+}
+
 static bool is_skip(const nm_mlp_desc& d, int i) {   // models.py:37,63
     return i % d.skip_step == 0 && i > 0 && i != d.num_layers - 1;
 }
@@ -763,6 +775,17 @@ int nm_mlp_refresh(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream) {
 }
 
 int64_t nm_mlp_refresh_count(const nm_mlp* m) { return m ? m->refresh_count : -1; }
+
+int nm_mlp_export_layer1_transposed(nm_mlp* m, float* d_out, void* stream_) {
+    NM_REQUIRE(m && d_out, "null argument");
+    NM_REQUIRE(!m->lw, "the layer-wise path keeps no index map of its packed image");
+    const int dx = 6 * m->desc.num_encoding_fn_xyz + (m->desc.include_input_xyz ? 3 : 0);
+    const int64_t n = (int64_t)m->blob_floats;
+    hipLaunchKernelGGL(scatter_layer1_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), m->d_index,
+                       static_cast<const float*>(m->d_blob), n, (int)m->desc.hidden_size, dx, d_out);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int nm_mlp_export_xyz_weight(nm_mlp* m, int32_t layer, float* d_out, void* stream_) {
     NM_REQUIRE(m && d_out, "null argument");

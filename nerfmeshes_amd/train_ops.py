@@ -289,10 +289,13 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
 
     if linear_l1:
         l1_sums = torch.empty(H, dx + 1, **f32)           # [ d_h[1]^T @ encoding | column sums of d_h[1] ]
-        jobs.append((dh[1], enc_x, dx, l1_sums, 0, None))
+        g["layers_xyz.0.bias"] = torch.empty(H, **f32)     # the column sums, from this product (layers_xyz[0]'s own is not run)
+        jobs.append((dh[1], enc_x, dx, l1_sums, 0, g["layers_xyz.0.bias"]))
     else:
         product("layer1", dh[0], enc_x, dx)
     for i in range(L - 1):
+        if linear_l1 and i == 0:
+            continue          # grad(layers_xyz[0].weight) = [d_h[1]^T enc | sum d_h[1]] @ [W1 | b1]^T below: h[0] = layer1(enc) is linear in enc
         delta = dh[1 + i]
         if is_skip(i):                                                                  # cat(x, xyz): models.py:64-65
             gw = torch.empty(H, H + dx, **f32)
@@ -315,6 +318,11 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         check(lib.nm_mlp_export_xyz_weight(mlp.handle, 0, _ptr(w0), _stream()), "nm_mlp_export_xyz_weight")
         both, _ = _weight_grad(mlp, w0, l1_sums, dx + 1, bias=False)
         g["layer1.weight"], g["layer1.bias"] = both[:, :dx].contiguous(), both[:, dx].contiguous()
+        # grad(layers_xyz[0].weight) = d_h[1]^T @ h[0] with h[0] = W1 enc + b1:  l1_sums @ [W1 | b1]^T -- a product over dx + 1 "samples"
+        # instead of one of the L hidden x hidden products over all n
+        w1t = torch.empty(dx + 1, H, **f32)
+        check(lib.nm_mlp_export_layer1_transposed(mlp.handle, _ptr(w1t), _stream()), "nm_mlp_export_layer1_transposed")
+        g["layers_xyz.0.weight"], _ = _weight_grad(mlp, l1_sums.t().contiguous(), w1t, H, bias=False)
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
     if flat:
