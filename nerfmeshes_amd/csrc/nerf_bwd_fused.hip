@@ -79,6 +79,8 @@ struct FusedBwdArgs {
     const float* enc_d;       // (n, 64)
     float* partial;           // (grid, FB_PART)
     int32_t skip_layer;       // i of the one layers_xyz[i] that takes cat(x, xyz), -1: none
+    const float* w1t;         // (dx + 1, 64): layer1.weight^T, then layer1.bias (nm_mlp_export_layer1_transposed; the epilogue's operand)
+    int32_t dx;               // width of the position encoding
 };
 
 // 128 rows of 256 B -> one LDS slot: 32 pieces of 1 KiB, 4 per wave (every wave issues the same count: the waits count them)
@@ -360,8 +362,12 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             const bool next_chain = L >= 3;
             if (next_chain || has_next) stream_to_lds<8>(next_chain ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
             int flying = 4;
-            issue_rows(fa.tape_h + ((int64_t)(L - 2) * args.n + row0) * 64);
-            if (sk == L - 2) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
+            if (L == 2) {
+                issue_rows(fa.enc_x + row0 * 64);          // the last delta contracts with the encoding rows only (see there)
+            } else {
+                issue_rows(fa.tape_h + ((int64_t)(L - 2) * args.n + row0) * 64);
+                if (sk == L - 2) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
+            }
             if constexpr (!(ABL & 4)) if (!dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
             if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_feat, bs_feat, lds, a_off64, slot_ptr(bslot) + b_off64);
             // grad(fc_alpha) = d_last^T @ h[L-1] (row 3; models.py:71), and the column sums of d_last = both heads' bias gradients
@@ -389,8 +395,12 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 // ---- phase B: first chunk of layers_xyz[i-1]^T -- or, behind layers_xyz[1]^T, of the next iteration | rows of the next delta
                 if (i > 1 || has_next) stream_to_lds<8>(i > 1 ? gw + 2 * FB_CHUNK : args.wstream, lds + (par ^ 1) * FB_CHUNK, FB_CHUNK, wave, lane);
                 int flying = 4;
-                issue_rows(fa.tape_h + ((int64_t)(i - 1) * args.n + row0) * 64);
-                if (sk == i - 1) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
+                if (i == 1) {
+                    issue_rows(fa.enc_x + row0 * 64);      // the last delta contracts with the encoding rows only
+                } else {
+                    issue_rows(fa.tape_h + ((int64_t)(i - 1) * args.n + row0) * 64);
+                    if (sk == i - 1) { issue_rows(fa.enc_x + row0 * 64); flying = 8; }
+                }
                 if constexpr (!(ABL & 4)) if (!dw_first) fb_chunk<8, 8, KH>(acc, in, lds + par * FB_CHUNK + lane * 16);
                 if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_xyz[i], bs_xyz[i], lds, a_off64, slot_ptr(bslot) + b_off64);
                 bslot = next_slot(bslot);
@@ -406,18 +416,15 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 fb_apply_mask(in, acc, m);
             }
         }
-        // ================= the last delta: at layers_xyz[0]'s pre-activation.  layer1 has NO activation (models.py:62), so the delta at its
-        // output is LINEAR in this one -- W0^T delta per sample -- and its weight gradient is W0^T applied to a sum over the samples:
-        //     grad(layer1.weight) = W0^T (delta^T @ xyz encoding),      grad(layer1.bias) = W0^T (column sums of delta),
-        // with W0 = layers_xyz[0]'s hidden columns.  The chain stops here: layers_xyz[0]^T is applied ONCE per workgroup, in the
-        // epilogue, to the 64 x 64 product this delta accumulates with the encoding rows -- a chain stage, a delta tile and a barrier
-        // less per iteration (64 of 352 chain MFMAs at 4 layers).
+        // ================= the last delta: at layers_xyz[0]'s pre-activation.  layer1 has NO activation (models.py:62), so (a) the delta
+        // at its output is LINEAR in this one -- W0^T delta per sample -- and (b) the activation rows this delta's own product would
+        // contract with are linear in the encoding -- h[0] = W1 enc + b1.  With S = [delta^T @ enc | column sums of delta] (64 x 64):
+        //     grad(layer1.weight | bias) = W0^T S,           grad(layers_xyz[0].weight) = S [W1 | b1]^T
+        // (W0 = layers_xyz[0]'s hidden columns, W1 = layer1.weight).  The chain stops here and this delta has ONE product, with the
+        // encoding rows; both matrix products with S run once per workgroup, in the epilogue: per iteration a chain stage (64 of
+        // 352 chain MFMAs at 4 layers), a product over the samples (64 of 472), a 32 KB block of rows and two barriers less.
         if constexpr (!(ABL & 8)) fb_write_delta<4>(dbuf, in, wave, g, col);
         fb_wait_barrier<ABL>(0, true);
-        issue_rows(fa.enc_x + row0 * 64);
-        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_xyz[0], bs_xyz[0], lds, a_off64, slot_ptr(bslot) + b_off64);
-        bslot = next_slot(bslot);
-        fb_wait_barrier<ABL>(4);
         int flying = 0;
         if (has_next) {
             fetch_head(it + gridDim.x);
@@ -425,10 +432,7 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
             issue_rows(fa.enc_d + (it + gridDim.x) * (FB_ROWS * 64));
             flying = 8;
         }
-        {
-            float unused = 0.f;
-            if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_l1, unused, lds, a_off64, slot_ptr(bslot) + b_off64);    // delta^T @ xyz encoding
-        }
+        if constexpr (!(ABL & 1)) fb_dw_step<2, ABL, DPF>(acc_l1, bs_xyz[0], lds, a_off64, slot_ptr(bslot) + b_off64);    // delta^T @ xyz encoding
         bslot = next_slot(bslot);
         fb_wait_barrier<ABL>(flying);
     }
@@ -456,19 +460,26 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
     store32(out + FB_P_DIRE, acc_dire);
     store64(out + FB_P_FEAT, acc_feat);
 #pragma unroll
-    for (int i = 0; i < MAXL - 1; ++i)
+    for (int i = 1; i < MAXL - 1; ++i)          // (layers_xyz[0]'s comes out of the 64 x 64 sums below)
         if (i <= L - 2) store64(out + FB_P_XYZ + i * 4096, acc_xyz[i]);
     if (sk >= 0) store64(out + FB_P_SKIP, acc_skip);
-    // layer1 = layers_xyz[0]^T applied to this workgroup's (delta^T @ encoding) -- tile-distributed in acc_l1 -- and, as column 63 (the
-    // encoding is at most 63 wide), to the column sums of that delta: the 64 x 64 product goes through LDS into the chain's B-operand
-    // layout (a "sample" = a column), the transposed weights come from the stream as for any chain stage: 32 MFMAs per wave
+    // S = [delta^T @ enc | column sums of delta] of the last delta -- tile-distributed in acc_l1, the sums in bs_xyz[0] -- goes through
+    // LDS as a 64 x 64 matrix: columns < dx the product, column 63 the sums (the encoding is at most 63 wide), the columns between
+    // zero (they met the rows' unwritten padding).  Then, 32 MFMAs per wave each:
+    //   grad(layer1) = layers_xyz[0]^T S: S in the chain's B-operand layout (a "sample" = a column), the transposed weights from the
+    //     stream as for any chain stage;  column 63 of the result is layer1's bias gradient;
+    //   grad(layers_xyz[0].weight) = S [W1 | b1]^T: S as the A operand, [W1 | b1]^T (fa.w1t: rows 0 .. dx-1 and dx) as B.
     {
         stream_to_lds<8>(args.wstream + (2 * L - 1) * FB_CHUNK, lds, 2 * FB_CHUNK, wave, lane);      // layers_xyz[0]^T, both chunks
         float* mt = reinterpret_cast<float*>(lds + FB_OFF_DBUF);                                     // [k][64]
+        const int dx = fa.dx;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) mt[(4 * (4 * g + r) + qa) * 64 + 4 * col + qb0 + t] = acc_l1[t][r];
+            for (int t = 0; t < 2; ++t) {
+                const int j = 4 * col + qb0 + t;
+                mt[(4 * (4 * g + r) + qa) * 64 + j] = j < dx ? acc_l1[t][r] : 0.0f;
+            }
         fb_wait_barrier<ABL>(0);
         const float colsum = fold(bs_xyz[0]);
         if (bias64 && g == 0) mt[(4 * col + qa) * 64 + 63] = colsum;
@@ -491,6 +502,23 @@ __global__ __launch_bounds__(512, 1) void mlp_backward_dw64_kernel(const MlpBwdA
                 out[FB_P_L1 + row * 64 + 16 * jt + col] = o2[t][r];
                 if (jt == 3 && col == 15) out[FB_P_BIAS + FB_B_L1 + row] = o2[t][r];
             }
+        // grad(layers_xyz[0].weight)[o][i] = sum_j S[o][j] Wx[j][i]:  this wave's column tile jt (i = 16 jt + col), row tiles as above
+        f32x4 o3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int j = 4 * ks + g;                                                      // contraction index of this lane group
+            const int wrow = j < dx ? j : dx;                                              // (column 63 of S pairs with the bias row)
+            const float wv = fa.w1t[wrow * 64 + 16 * jt + col];
+            const float b = (j < dx || j == 63) ? wv : 0.0f;
+            const int r0 = 16 * (upper ? 2 : 0) + col;
+            o3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(mt[r0 * 64 + j], b, o3[0], 0, 0, 0);
+            o3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(mt[(r0 + 16) * 64 + j], b, o3[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[FB_P_XYZ + (16 * ((upper ? 2 : 0) + t) + 4 * g + r) * 64 + 16 * jt + col] = o3[t][r];
     }
     float* ob = out + FB_P_BIAS;
     {
@@ -596,8 +624,8 @@ int nm_mlp_backward_fused_supported(const nm_mlp* m, int64_t n) {
            n % FB_ROWS == 0 && nm_mlp_tapes_encodings(m) && 6 * d.num_encoding_fn_dir + (d.include_input_dir ? 3 : 0) <= 32;
 }
 
-int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* m) {
-    return m ? (int64_t)(m->num_cus > 0 ? m->num_cus : 256) * FB_PART * 4 : 0;
+int64_t nm_mlp_backward_fused_workspace_bytes(const nm_mlp* m) {      // the workgroups' partials, then [layer1.weight | bias]^T (64 x 64)
+    return m ? (int64_t)(m->num_cus > 0 ? m->num_cus : 256) * FB_PART * 4 + 64 * 64 * 4 : 0;
 }
 
 int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const float* d_radiance, const float* d_grad_radiance,
@@ -624,6 +652,11 @@ int nm_mlp_backward_fused(nm_mlp* m, int64_t n, const nm_mlp_tape* tape, const f
     fa.partial = static_cast<float*>(d_workspace);
     fa.skip_layer = fb_skip_layer(m, &one_skip);
     const int cus = m->num_cus > 0 ? m->num_cus : 256;
+    // [W1 | b1]^T out of the packed image -- the operand of the epilogue's product for layers_xyz[0] -- behind the partials
+    float* w1t = fa.partial + (int64_t)cus * FB_PART;
+    if (int rc = nm_mlp_export_layer1_transposed(m, w1t, stream_)) return rc;
+    fa.w1t = w1t;
+    fa.dx = 6 * d.num_encoding_fn_xyz + (d.include_input_xyz ? 3 : 0);
     const int64_t wg_iters = n / FB_ROWS;
     const int grid = (int)(wg_iters < cus ? wg_iters : cus);
     const auto kernel = L <= 4 ? &mlp_backward_dw64_kernel<4> : &mlp_backward_dw64_kernel<FB_MAXL>;

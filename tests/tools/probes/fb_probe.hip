@@ -62,9 +62,11 @@ int main(int argc, char** argv) {
     fa.enc_d = dev_random<float>((size_t)n * 64, 9, -1.f, 1.f);
     CK(hipMalloc(&fa.partial, (size_t)cus * FB_PART * 4));
     fa.skip_layer = sk;
+    fa.w1t = dev_random<float>(64 * 64, 10, -0.1f, 0.1f);
+    fa.dx = L == 4 ? 39 : 63;
     const int64_t iters = n / FB_ROWS;
     const int grid = (int)(iters < cus ? iters : cus);
-    const double mfma_per_wave_iter = 32 + 64 + 64 * (L - 2) /* chain: layers_xyz[0]^T is applied once, in the epilogue */ + 32 + 32 + 64 + 64 * (L - 1) + (sk >= 0 ? 64 : 0) + 64 /* dW */ + 24 /* heads */;
+    const double mfma_per_wave_iter = 32 + 64 + 64 * (L - 2) /* chain: layers_xyz[0]^T is applied once, in the epilogue */ + 32 + 32 + 64 + 64 * (L - 2) + (sk >= 0 ? 64 : 0) + 64 /* dW: the last delta has one product */ + 24 /* heads */;
     const double floor_us = mfma_per_wave_iter * 32 * 2 * (double)((iters + grid - 1) / grid) / 2.4e3;
     printf("L %d  n %lld  grid %d x 512  %d CUs;  %.0f MFMAs per wave and iteration: issue floor at 2.4 GHz %.1f us\n", L, (long long)n, grid, cus, mfma_per_wave_iter, floor_us);
 #define RUN(M, A, what) printf("  %-58s %8.1f us\n", what, L <= 4 ? run<4, A>(a, fa, L, grid, 20) : run<8, A>(a, fa, L, grid, 20));
