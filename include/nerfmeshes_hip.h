@@ -275,6 +275,10 @@ typedef struct nm_mlp_tape {
      * v_stride = 64: an encoding row is 27 floats of its 64 -- so that one block of rows feeds both layers_dir[0]'s and fc_rgb's
      * weight gradients (nm_mlp_backward_fused). */
     int32_t v_stride;
+    /* ABI v6: non-zero = do not write d_h[0] (layer1's output; the plane stays allocated, untouched).  For a backward that takes
+     * layer1's and layers_xyz[0]'s gradients by linearity (nm_mlp_backward_ex + NM_BACKWARD_STOP_AT_XYZ0, nm_mlp_backward_fused):
+     * neither reads it -- a tenth of the tape's bytes.  Tuned-family handles only. */
+    int32_t skip_h0;
 } nm_mlp_tape;
 /* 1 when nm_mlp_forward_train on this handle fills d_enc_xyz / d_enc_dir (when given), 0 when the caller still needs
  * nm_encode_samples_strided. */

@@ -35,7 +35,7 @@ class BundleOut(C.Structure):
 
 
 class MlpTape(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v", "d_enc_xyz", "d_enc_dir")] + [("v_stride", C.c_int32)]
+    _fields_ = [(n, c_void_p) for n in ("d_h", "d_feat", "d_v", "d_mask_h", "d_mask_v", "d_enc_xyz", "d_enc_dir")] + [("v_stride", C.c_int32), ("skip_h0", C.c_int32)]
 
 
 class MlpDeltas(C.Structure):

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, (H <= 128 && !TAPE) ? 4 : 2) void mlp_kern
                 else if (last_density) { tsrc = args.wstream; tbytes = has_next ? N::L1_FIRST : 0; }
                 gemm_stage<N::NT, N::KH, 0, NW, N::LDSBUF, KCH, PIPE, SPREAD, ABL, TAPE>(
                     acc, in, dummy, gw, tsrc, tbytes, lds, par, wave, lane,
-                    tape_row ? tape_row + (int64_t)i * args.n * H : nullptr);
+                    (tape_row && !(i == 0 && args.tape_skip_h0)) ? tape_row + (int64_t)i * args.n * H : nullptr);
                 gw += N::KH * N::STEP;
             }
             if (skip) {  // cat(hidden, xyz_enc): the encoding columns of layers_xyz[i] (models.py:64-65)

@@ -319,6 +319,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     NM_REQUIRE(m->precision == NM_PREC_F32, "training runs in fp32: create the handle with NM_PREC_F32");
     NM_REQUIRE(tape->v_stride >= 0 && (tape->v_stride == 0 || tape->v_stride >= d.hidden_size / 2), "nm_mlp_tape.v_stride is smaller than a row of d_v");
     NM_REQUIRE(!generic || tape->v_stride == 0 || tape->v_stride == d.hidden_size / 2, "only the tuned family writes d_v with a row stride (v_stride)");
+    NM_REQUIRE(!tape->skip_h0 || (!generic && d.num_layers >= 2), "nm_mlp_tape.skip_h0 is a tuned-family option");
     if (m->lw) {             // beyond the fused families: layer by layer (nerf_layerwise.hip); the tape is rows, no masks
         MlpArgs a = m->base;
         a.mode = MODE_RAYS;
@@ -365,6 +366,7 @@ int nm_mlp_forward_train(nm_mlp* m, const float* d_origins, int origins_per_ray,
     if (a.n == 0) return 0;
     a.tape_h = tape->d_h; a.tape_feat = tape->d_feat; a.tape_v = tape->d_v;
     a.tape_v_ld = tape->v_stride > 0 ? tape->v_stride : d.hidden_size / 2;
+    a.tape_skip_h0 = tape->skip_h0 ? 1 : 0;
     a.mask_h = tape->d_mask_h; a.mask_v = tape->d_mask_v;
     a.tiles = (a.n + 15) / 16;
     if (nm_mlp_tapes_encodings(m)) {       // the encoding rows the weight gradients contract with, straight from the registers

@@ -119,6 +119,8 @@ struct MlpArgs {
     float* tape_encx;        // (n, 64) or null: the positional-encoding row of every sample point, reference column order
     float* tape_encd;        // (n, 64) or null: likewise for the view direction (tuned family only: nm_mlp_tape.d_enc_*)
     int32_t tape_v_ld;       // floats per row of tape_v (nm_mlp_tape.v_stride; H/2 when the caller left it 0)
+    int32_t tape_skip_h0;    // tuned taping kernels: do not write tape_h[0] (nm_mlp_tape.skip_h0: layer1's output, which a backward that
+                             // takes layer1's and layers_xyz[0]'s gradients by linearity never reads)
     RayGen gen;              // VIEW: rays generated from the pose (c = t as in RAYS; a, b unused)
     // generic-shape kernels only (mlp_device_g.h): the encodings' run-time description
     const void* g_tab;       // device: GEncArg[2][96] (xyz, dir; two parts of 48): coordinate and frequency band of every encoding argument

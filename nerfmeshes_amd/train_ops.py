@@ -136,6 +136,10 @@ def forward_train(mlp, origins, dirs, t):
             tape["v"] = tape["enc_d"][:, 32:]
     if tape["v"] is None and not flat:
         tape["v"] = torch.empty(n, H // 2, **f32)
+    # layer1's output (h[0]) is read by no backward that takes layer1's and layers_xyz[0]'s gradients by linearity: not written then
+    # (a tenth of the tape's bytes).  Only where that backward is available whatever the sample count: backward() falls back to it
+    tape["h0_taped"] = not (bool(lib.nm_mlp_backward_stops_at_xyz0(mlp.handle)) and
+                            (n * H * H > LINEAR_LAYER1_MIN_WORK or bool(lib.nm_mlp_backward_fused_supported(mlp.handle, n))))
     out = torch.empty(rays, samples, 4, **f32)
     ct = _tape_struct(tape)
     with _stage("taping_forward"):
@@ -148,7 +152,8 @@ def _tape_struct(tape):
     opt = lambda x: None if x is None else _ptr(x)   # noqa: E731
     v = tape["v"]
     return MlpTape(_ptr(tape["h"]), opt(tape["feat"]), opt(v), opt(tape["mask_h"]), opt(tape["mask_v"]),
-                   opt(tape.get("enc_x")), opt(tape.get("enc_d")), 0 if v is None else int(v.stride(0)))
+                   opt(tape.get("enc_x")), opt(tape.get("enc_d")), 0 if v is None else int(v.stride(0)),
+                   0 if tape.get("h0_taped", True) else 1)
 
 
 def encode_samples(mlp, origins, dirs, t):
@@ -252,7 +257,10 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
     # W0^T applied ONCE to sums over the samples -- the tuned delta kernels then stop one transposed layer early (an eighth of the
     # kernel at 8 layers) and d_h[0] is never produced
     # (worth it from ~60 us of saved matrix work on: the path costs five small launches -- n H^2 > 4e9)
-    linear_l1 = bool(lib.nm_mlp_backward_stops_at_xyz0(mlp.handle)) and n * H * H > LINEAR_LAYER1_MIN_WORK
+    linear_l1 = bool(lib.nm_mlp_backward_stops_at_xyz0(mlp.handle)) and (n * H * H > LINEAR_LAYER1_MIN_WORK or not tape.get("h0_taped", True))
+    if not linear_l1 and not tape.get("h0_taped", True):
+        raise _lib.HipLibraryError("this tape was taken without layer1's output (h[0]) for a backward that takes its gradients by linearity, "
+                                   "which has been switched off since (NM_BACKWARD_LINEAR_LAYER1=0 between forward and backward?)")
     with _stage("delta"):
         check(lib.nm_mlp_backward_ex(mlp.handle, n, C.byref(ct), _ptr(radiance), _ptr(grad_radiance), C.byref(cd), 1 if linear_l1 else 0,
                                      _stream()), "nm_mlp_backward_ex")

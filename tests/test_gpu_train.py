@@ -161,7 +161,8 @@ def test_mlp_tape_and_backward_vs_autograd(ops, T, kw, rays, samples):
     ref_enc = O.positional_encoding(pts, kw["num_encoding_fn_xyz"])
     assert _rel(enc_x, ref_enc) < 1e-6
     h0 = torch.nn.functional.linear(ref_enc, w["layer1.weight"], w["layer1.bias"])
-    assert _rel(tape["h"][0], h0) < 1e-5
+    if tape["h0_taped"]:       # (not written where the backward that will run takes layer1's / layers_xyz[0]'s gradients by linearity)
+        assert _rel(tape["h"][0], h0) < 1e-5
     assert float(tape["h"][1:].min()) >= 0.0 and float(tape["feat"].min()) >= 0.0 and float(tape["v"].min()) >= 0.0
 
     got = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
@@ -890,7 +891,7 @@ def test_weight_grad_batch_vs_fp64(out_f, in_f, jobs, n, general, monkeypatch):
 
 
 @pytest.mark.parametrize("kw", SHAPES + FLAT_SHAPES, ids=["4x64", "8x256", "3x128", "4x64-flat", "8x256-flat", "5x128-flat"])
-@pytest.mark.parametrize("rays,samples", [(37, 9), (144, 16)])
+@pytest.mark.parametrize("rays,samples", [(37, 9), (145, 16)])
 def test_layer1_gradient_by_linearity_vs_autograd_and_the_full_chain(ops, T, kw, rays, samples, monkeypatch):
     """layer1 has no activation (models.py:62): with NM_BACKWARD_STOP_AT_XYZ0 the delta kernel never applies layers_xyz[0]^T and
     backward() takes grad(layer1) = W0^T [d_h[1]^T enc | sum d_h[1]] (W0 exported from the handle's packed image) and
@@ -905,9 +906,13 @@ def test_layer1_gradient_by_linearity_vs_autograd_and_the_full_chain(ops, T, kw,
     o, d, t = _rays(rays, samples, rays)
     grad_out = torch.randn(rays, samples, 4, generator=torch.Generator().manual_seed(1))
     rad, tape = T.forward_train(mlp, o.cuda(), d.cuda(), t.cuda())
+    assert tape["h0_taped"]                                       # these sample counts are below the threshold of the path
     full = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
     monkeypatch.setattr(T, "LINEAR_LAYER1_MIN_WORK", 0)
-    got = T.backward(mlp, tape, rad, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
+    rad2, tape2 = T.forward_train(mlp, o.cuda(), d.cuda(), t.cuda())
+    assert not tape2["h0_taped"] and torch.equal(rad, rad2)       # the taping forward leaves layer1's output out, nothing else changes
+    tape2["h"][0].fill_(float("nan"))                             # ... and nobody reads it
+    got = T.backward(mlp, tape2, rad2, grad_out.cuda(), o.cuda(), d.cuda(), t.cuda())
     g32 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float32)[1]
     g64 = _oracle_grads(w, spec, o, d, t, grad_out, torch.float64)[1]
     assert set(got) == set(g64) == set(full)
@@ -916,4 +921,6 @@ def test_layer1_gradient_by_linearity_vs_autograd_and_the_full_chain(ops, T, kw,
     assert not bad, f"gradient mismatch (by linearity, full chain, torch-fp32) relative to fp64 autograd: {bad}"
     for k in got:      # (layers_xyz[0]'s own gradient is taken by the same identity: h[0] = layer1(enc) is linear in the encoding)
         if not k.startswith(("layer1.", "layers_xyz.0.")):
-            assert torch.equal(got[k], full[k]), f"{k}: every other gradient comes out of the same kernels on the same deltas"
+            # every other gradient comes out of the same kernels on the same deltas -- in a batch with one product less, i.e. with
+            # another split of the samples over the workgroups: equal up to the summation grouping
+            assert _rel(got[k], full[k]) < 2e-6, k
