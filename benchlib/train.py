@@ -58,18 +58,21 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
     # EXECUTED (that layer left out of the delta term); `frac_of_reference_work` what the reference's autograd does, the basis of
     # the earlier rounds' figures
     reference_flops = flops
-    delta -= 2 * Hh * Hh * _linear_layer1_share(Hh, rays, (NUM_COARSE, NUM_COARSE + NUM_FINE))
-    flops = samples * (fwd + delta + fwd)
+    share = _linear_layer1_share(Hh, rays, (NUM_COARSE, NUM_COARSE + NUM_FINE))
+    delta -= 2 * Hh * Hh * share              # layers_xyz[0]^T is not applied per sample ...
+    wgrad = fwd - 2 * Hh * Hh * share         # ... and layers_xyz[0]'s own weight gradient is S [W1 | b1]^T, not a product over the samples
+    flops = samples * (fwd + delta + wgrad)
     achieved = flops / (ms * 1e-3) / 1e12
     out = {"value": rays / ms * 1e3, "unit": "rays/s", "ms_per_iteration": ms, "rays_per_iteration": rays,
            "workload": "training step: 8x256 coarse+fine, 64+128 samples, perturb + noise, Adam (forward + HIP backward + step)",
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "samples_per_iteration": samples,
                         "frac_of_reference_work": reference_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                        "flop_basis": "frac: the matrix work executed (forward + delta + weight gradients, the delta chain without "
-                                      "layers_xyz[0]^T: layer1's gradient by linearity); frac_of_reference_work: the reference's autograd, "
-                                      "which applies that layer per sample (the basis of rounds 4 - 5)",
-                        "algorithmic_flops_per_sample": {"forward": fwd, "delta": delta, "weight_gradients": fwd},
+                        "flop_basis": "frac: the matrix work executed (forward + delta + weight gradients; without layers_xyz[0]^T in the "
+                                      "delta chain and without layers_xyz[0]'s per-sample weight-gradient product: both follow from sums "
+                                      "over the samples because layer1 has no activation); frac_of_reference_work: the reference's autograd, "
+                                      "which runs both per sample (the basis of rounds 4 - 5)",
+                        "algorithmic_flops_per_sample": {"forward": fwd, "delta": delta, "weight_gradients": wgrad},
                         "floor_ms_at_peak": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                         "note": "whole-iteration wall time (taping forward, delta kernel, dW kernels, encodings, compositing, Adam) "
                                 "against the fp32 MFMA peak"}}
@@ -83,7 +86,7 @@ def train_probe(dev, dirs, origin, rays=2048, iters=10, cpu_rays=256, cpu_legs=T
     torch.cuda.synchronize()
     ms_prof = (time.perf_counter() - t0) / iters * 1e3
     stages = {k: v / iters for k, v in train_ops.profile_stages(False).items()}
-    work = {"taping_forward": samples * fwd, "delta": samples * delta, "weight_gradients": samples * fwd}
+    work = {"taping_forward": samples * fwd, "delta": samples * delta, "weight_gradients": samples * wgrad}
     kernels = {}
     for name, ms_stage in sorted(stages.items(), key=lambda kv: -kv[1]):
         kernels[name] = {"ms": ms_stage}
@@ -196,7 +199,9 @@ def shape_train_probe(dev, name, over, rays, iters=20, replay=True):
     flops = samples * sum(train_flops_per_sample(kw))
     per_net = (kw["num_coarse"],) + ((kw["num_coarse"] + kw["num_fine"],) if kw["use_fine"] else ())
     reference_flops = flops
-    flops -= samples * 2 * kw["hidden_size"] ** 2 * _linear_layer1_share(kw["hidden_size"], rays, per_net)   # layer1 by linearity: executed work
+    # layer1's and layers_xyz[0]'s gradients by linearity: two hidden x hidden products per sample (a transposed layer of the delta
+    # chain, a weight-gradient product) are not executed for the networks that take the path
+    flops -= samples * 4 * kw["hidden_size"] ** 2 * _linear_layer1_share(kw["hidden_size"], rays, per_net)
     frac = lambda ms: flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS  # noqa: E731
     eager = timed(build())
     out = {"workload": f"{name}: {rays} rays x {samples // rays} samples, perturb + noise, fused Adam", "rays": rays,

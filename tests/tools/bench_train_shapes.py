@@ -132,7 +132,9 @@ def main():
             # layers_xyz[0]^T out for the networks whose sample count takes that path -- the FLOP counted here are the executed ones
             from benchlib.train import _linear_layer1_share
             per_net = (kw["num_coarse"],) + ((kw["num_coarse"] + kw["num_fine"],) if kw["use_fine"] else ())
-            delta -= 2 * kw["hidden_size"] ** 2 * _linear_layer1_share(kw["hidden_size"], rays, per_net)
+            share = _linear_layer1_share(kw["hidden_size"], rays, per_net)
+            delta -= 2 * kw["hidden_size"] ** 2 * share            # layers_xyz[0]^T not applied per sample
+            dw -= 2 * kw["hidden_size"] ** 2 * share               # layers_xyz[0]'s own weight gradient from the sums
         flops = samples * (fwd + delta + dw)
         out[name] = {"rays": rays, "samples_per_iteration": samples, "ms_per_iteration": round(ms, 3),
                      "rays_per_s": round(rays / ms * 1e3), "kernel_family": "layer-wise" if variant == 2000 else ("generic class %d" % (variant - 1000) if variant >= 1000 else "tuned"),
