@@ -330,7 +330,8 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         # instead of one of the L hidden x hidden products over all n
         w1t = torch.empty(dx + 1, H, **f32)
         check(lib.nm_mlp_export_layer1_transposed(mlp.handle, _ptr(w1t), _stream()), "nm_mlp_export_layer1_transposed")
-        g["layers_xyz.0.weight"], _ = _weight_grad(mlp, l1_sums.t().contiguous(), w1t, H, bias=False)
+        sums_t = l1_sums.transpose(0, 1).contiguous()         # (dx + 1, H): a 64 KB copy -- the kernel contracts over ROWS
+        g["layers_xyz.0.weight"], _ = _weight_grad(mlp, sums_t, w1t, H, bias=False)
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
     if flat:
