@@ -324,6 +324,11 @@ int nm_mlp_export_xyz_weight(nm_mlp* mlp, int32_t layer, float* d_out, void* str
  * hold layer1.weight^T, row dx layer1.bias, again out of the packed image.  One of the L hidden x hidden weight-gradient products
  * over all samples becomes a product over dx + 1 rows. */
 int nm_mlp_export_layer1_transposed(nm_mlp* mlp, float* d_out, void* stream);
+/* Both products in one launch, the parameters read out of the packed image: d_sums (H, dx) with row stride ld = d_h[1]^T @ enc,
+ * d_colsum (H) = the column sums of d_h[1]  ->  d_l1w (H, dx), d_l1b (H) = grad(layer1), d_x0w (H, H) = grad(layers_xyz[0].weight).
+ * What nerfmeshes_amd/train_ops.py: backward calls behind the weight-gradient batch. */
+int nm_mlp_linear_layer1_finish(nm_mlp* mlp, const float* d_sums, int32_t ld, const float* d_colsum, float* d_l1w, float* d_l1b,
+                                float* d_x0w, void* stream);
 
 /* ABI v6.  The whole back-propagation of a 64-wide network in ONE kernel (nerf_bwd_fused.hip): the delta chain of
  * nm_mlp_backward AND the weight / bias gradients of layer1, layers_xyz[*], fc_feat and layers_dir[0] -- what loss.backward()

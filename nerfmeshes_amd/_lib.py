@@ -119,6 +119,7 @@ SIGNATURES = {
     "nm_mlp_backward_ex": (C.c_int, [c_void_p, C.c_int64, C.POINTER(MlpTape), c_void_p, c_void_p, C.POINTER(MlpDeltas), C.c_int32, c_void_p]),
     "nm_mlp_export_xyz_weight": (C.c_int, [c_void_p, C.c_int32, c_void_p, c_void_p]),
     "nm_mlp_export_layer1_transposed": (C.c_int, [c_void_p, c_void_p, c_void_p]),
+    "nm_mlp_linear_layer1_finish": (C.c_int, [c_void_p, c_void_p, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nm_mlp_backward": (C.c_int, [c_void_p, C.c_int64, C.POINTER(MlpTape), c_void_p, c_void_p, C.POINTER(MlpDeltas),
                                   c_void_p]),
     "nm_encode_samples": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_int64, C.c_int32, c_void_p,

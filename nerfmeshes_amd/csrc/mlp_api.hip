@@ -686,6 +686,17 @@ int nm_mlp_create_ex(const nm_mlp_desc* desc, const nm_mlp_weights* w, int devic
     hipDeviceProp_t prop;
     NM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     m->num_cus = prop.multiProcessorCount;
+    // behind everything the kernels stream: PLAIN copies of the three tensors nm_mlp_linear_layer1_finish multiplies with, filled by
+    // the same gather -- layers_xyz[0].weight (H, H) row-major, layer1.weight TRANSPOSED (dx, H), layer1.bias (H)
+    if (!index.empty() && desc->num_layers >= 2) {
+        const int Hh = desc->hidden_size, dxx = 6 * desc->num_encoding_fn_xyz + (desc->include_input_xyz ? 3 : 0);
+        while (index.size() % 64) index.push_back(-1);
+        m->plain_off = index.size();
+        for (int e = 0; e < Hh * Hh; ++e) index.push_back((T_XYZ0 << 24) | e);
+        for (int j = 0; j < dxx; ++j)
+            for (int i = 0; i < Hh; ++i) index.push_back((T_L1W << 24) | (i * dxx + j));
+        for (int i = 0; i < Hh; ++i) index.push_back((T_L1B << 24) | i);
+    }
     m->blob_floats = index.size();
     m->blob_bytes = index.size() * 4;
     NM_HIP_CHECK(hipMalloc(&m->d_blob, m->blob_bytes));
@@ -775,6 +786,52 @@ int nm_mlp_refresh(nm_mlp* m, const nm_mlp_weights* d_weights, void* stream) {
 }
 
 int64_t nm_mlp_refresh_count(const nm_mlp* m) { return m ? m->refresh_count : -1; }
+
+// Both products of the linearity identities in one launch: with S = [sums (H, dx) | colsum (H)]
+//     l1w[i][j] = sum_k W0[k][i] sums[k][j],   l1b[i] = sum_k W0[k][i] colsum[k],   x0w[o][i] = sum_j sums[o][j] W1[i][j] + colsum[o] b1[i]
+// one thread per output element, fixed summation order; W0, W1^T, b1 are the plain copies behind the packed image (coalesced or
+// broadcast reads, everything L2-resident).  8.4 M multiply-adds at 8x256: launch-sized work -- it replaces two exports, three
+// copies and two weight-gradient launches with their reductions (about 90 us of launches in an eager iteration).
+__global__ __launch_bounds__(256) void linear_layer1_finish_kernel(const float* __restrict__ w0, const float* __restrict__ w1t,
+                                                                   const float* __restrict__ b1, const float* __restrict__ sums, int ld,
+                                                                   const float* __restrict__ colsum, int H, int dx, float* __restrict__ l1w,
+                                                                   float* __restrict__ l1b, float* __restrict__ x0w) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int n_x0 = H * H;
+    if (t < n_x0) {                       // x0w: thread (o, i), i fastest: sums[o][j] is a broadcast, w1t[j][i] coalesced
+        const int o = t / H, i = t - o * H;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < dx; ++j) s = fmaf(sums[(int64_t)o * ld + j], w1t[j * H + i], s);
+        x0w[t] = fmaf(colsum[o], b1[i], s);
+    } else if (t < n_x0 + (dx + 1) * H) { // l1: thread (j, i), i fastest: w0[k][i] coalesced, sums[k][j] a broadcast
+        const int e = t - n_x0, j = e / H, i = e - j * H;
+        float s = 0.0f;
+        if (j < dx) {
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) s = fmaf(w0[k * H + i], sums[(int64_t)k * ld + j], s);
+            l1w[i * dx + j] = s;
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) s = fmaf(w0[k * H + i], colsum[k], s);
+            l1b[i] = s;
+        }
+    }
+}
+
+int nm_mlp_linear_layer1_finish(nm_mlp* m, const float* d_sums, int32_t ld, const float* d_colsum, float* d_l1w, float* d_l1b,
+                                float* d_x0w, void* stream_) {
+    NM_REQUIRE(m && d_sums && d_colsum && d_l1w && d_l1b && d_x0w, "null argument");
+    NM_REQUIRE(m->plain_off, "this handle keeps no plain copy of layer1 / layers_xyz[0] (layer-wise path, or a one-layer network)");
+    const int H = m->desc.hidden_size, dx = 6 * m->desc.num_encoding_fn_xyz + (m->desc.include_input_xyz ? 3 : 0);
+    NM_REQUIRE(ld >= dx, "row stride of the sums is smaller than the encoding");
+    const float* w0 = static_cast<const float*>(m->d_blob) + m->plain_off;
+    const int threads = H * H + (dx + 1) * H;
+    hipLaunchKernelGGL(linear_layer1_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       w0, w0 + (size_t)H * H, w0 + (size_t)H * H + (size_t)dx * H, d_sums, (int)ld, d_colsum, H, dx, d_l1w, d_l1b, d_x0w);
+    NM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int nm_mlp_export_layer1_transposed(nm_mlp* m, float* d_out, void* stream_) {
     NM_REQUIRE(m && d_out, "null argument");

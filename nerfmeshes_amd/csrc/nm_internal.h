@@ -215,4 +215,7 @@ struct nm_mlp {
     // of a verification pass over the caller's live tensors (device, 2 x 8 bytes); how many gathers ran since create
     unsigned long long* d_check;
     int64_t refresh_count;
+    // float offset, in the packed image, of the plain copies nm_mlp_linear_layer1_finish reads: layers_xyz[0].weight (H, H),
+    // layer1.weight^T (dx, H), layer1.bias (H); 0: none (layer-wise path, one-layer networks)
+    size_t plain_off;
 };

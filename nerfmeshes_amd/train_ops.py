@@ -296,7 +296,7 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
         g[name + ".weight"] = out
 
     if linear_l1:
-        l1_sums = torch.empty(H, dx + 1, **f32)           # [ d_h[1]^T @ encoding | column sums of d_h[1] ]
+        l1_sums = torch.empty(H, dx, **f32)               # d_h[1]^T @ encoding; the column sums of d_h[1] = layers_xyz[0]'s bias gradient
         g["layers_xyz.0.bias"] = torch.empty(H, **f32)     # the column sums, from this product (layers_xyz[0]'s own is not run)
         jobs.append((dh[1], enc_x, dx, l1_sums, 0, g["layers_xyz.0.bias"]))
     else:
@@ -319,19 +319,12 @@ def backward(mlp, tape, radiance, grad_radiance, origins, dirs, t):
             product("layers_dir.0", dv, enc_d, dd, out=gw, col0=H, bias=False)
     _weight_grad_batch(mlp, jobs)
     if linear_l1:
-        # grad(layer1) = W0^T @ [ d_h[1]^T enc | sum d_h[1] ]: the same weight-gradient kernel over H "samples" (rows of W0 as it
-        # sits in the handle's packed image -- what the forward of this step used)
-        l1_sums[:, dx].copy_(g["layers_xyz.0.bias"])
-        w0 = torch.empty(H, H, **f32)
-        check(lib.nm_mlp_export_xyz_weight(mlp.handle, 0, _ptr(w0), _stream()), "nm_mlp_export_xyz_weight")
-        both, _ = _weight_grad(mlp, w0, l1_sums, dx + 1, bias=False)
-        g["layer1.weight"], g["layer1.bias"] = both[:, :dx].contiguous(), both[:, dx].contiguous()
-        # grad(layers_xyz[0].weight) = d_h[1]^T @ h[0] with h[0] = W1 enc + b1:  l1_sums @ [W1 | b1]^T -- a product over dx + 1 "samples"
-        # instead of one of the L hidden x hidden products over all n
-        w1t = torch.empty(dx + 1, H, **f32)
-        check(lib.nm_mlp_export_layer1_transposed(mlp.handle, _ptr(w1t), _stream()), "nm_mlp_export_layer1_transposed")
-        sums_t = l1_sums.transpose(0, 1).contiguous()         # (dx + 1, H): a 64 KB copy -- the kernel contracts over ROWS
-        g["layers_xyz.0.weight"], _ = _weight_grad(mlp, sums_t, w1t, H, bias=False)
+        # with S = [ d_h[1]^T enc | sum d_h[1] ]:  grad(layer1) = W0^T S  and  grad(layers_xyz[0].weight) = d_h[1]^T @ h[0] = S [W1 | b1]^T
+        # (h[0] = W1 enc + b1): one small kernel that reads W0, W1, b1 out of the handle's packed image -- what the forward of this
+        # step used -- instead of a transposed layer of the delta chain and a hidden x hidden product, both over all n samples
+        g["layer1.weight"], g["layer1.bias"], g["layers_xyz.0.weight"] = torch.empty(H, dx, **f32), torch.empty(H, **f32), torch.empty(H, H, **f32)
+        check(lib.nm_mlp_linear_layer1_finish(mlp.handle, _ptr(l1_sums), dx, _ptr(g["layers_xyz.0.bias"]), _ptr(g["layer1.weight"]),
+                                              _ptr(g["layer1.bias"]), _ptr(g["layers_xyz.0.weight"]), _stream()), "nm_mlp_linear_layer1_finish")
     # the 1-row / 3-row heads share dlast (n,4): one product per operand, rows picked afterwards (an MFMA tile would
     # waste 12 of its 16 rows; the product is HBM-bound on reading h / v once)
     if flat:
