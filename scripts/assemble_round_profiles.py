@@ -99,6 +99,12 @@ for f in sorted(os.listdir(G)):
 ab = {"separate_kernels": _load(os.path.join(G, f"tiny_train_separate_{tag}.json")), "fused_backward": _load(os.path.join(G, f"tiny_train_fused_{tag}.json"))}
 if counters or ab["fused_backward"]:
     wc, busy, gui = counters.get("SQ_WAVE_CYCLES"), counters.get("SQ_VALU_MFMA_BUSY_CYCLES"), counters.get("GRBM_GUI_ACTIVE")
+    kernel_us = None
+    trace = os.path.join(G, f"trace_{tag}", "trace1.txt")
+    if os.path.exists(trace):
+        for line in open(trace):
+            if "mlp_backward_dw64_kernel" in line and " avg " in line:
+                kernel_us = float(line.split(" avg ")[1].split()[0])
     json.dump({
         "what": "nm::mlp_backward_dw64_kernel<4> (the 64-wide networks' whole backward: delta chain + every weight gradient, nerf_bwd_fused.hip) "
                 "on a REAL tape of config 1's size (4x64, 8192 rays x 32 samples; tests/tools/fused_bwd_one.py): rocprofv3 --pmc passes, one "
@@ -106,16 +112,19 @@ if counters or ab["fused_backward"]:
                 "(tests/tools/bench_tiny_train.py, NM_FUSED_BACKWARD=0/1: bench.py's tiny.train and train.shapes probes)",
         "counters_per_launch": counters,
         "matrix_pipe_busy_over_wave_resident_time": (busy / (wc * 4 / 2)) if wc and busy else None,
-        "clock_GHz_during_the_kernel": (gui / 8 / 265e-6 / 1e9) if gui else None,
+        "kernel_us_in_config1_iteration": kernel_us,
+        "clock_GHz_during_the_kernel": (gui / 8 / (kernel_us * 1e-6) / 1e9) if gui and kernel_us else None,
         "hbm_bytes_fetched_per_launch": counters.get("FETCH_SIZE", 0) * 1024 * 2 or None,     # FETCH_SIZE counts 64-byte halves on gfx950 (guide, HBM section)
-        "reading": "fetched = the tape once (2 KB per sample: 537 MB) -- no delta row is ever written or re-read; the matrix pipe is busy 0.68 of "
-                   "the wave-resident time at 2.3 GHz (not clock-bound, unlike the 128-wide weight gradients); executed MFMA work is 1.13 x the "
-                   "algorithmic FLOP (encoding products padded to 64 columns): 0.68 x 0.96 x 0.88 = 0.57 of the fp32 MFMA peak, the measured "
-                   "0.52 - 0.55.  2.2 VALU instructions per MFMA (mask application, delta-tile stores, bias sums, operand addressing) on two "
-                   "lock-stepped waves per SIMD; a quarter of the wave time waits (barriers, DMA); 38 % of the LDS-active cycles are 2-way "
-                   "conflicts of the 8-byte row-block reads, which the operand-read ablations of the probe show not to matter",
-        "algorithmic": {"samples": 262144, "flop_delta_plus_weight_gradients": 262144 * (36864 + 48896), "tape_bytes_read_once": 262144 * 2048,
-                        "mfma_issue_floor_us_at_2.4GHz": 157.0},
+        "reading": "fetched = the tape once WITHOUT layer1's output (1.75 KB per sample: 459 MB) -- no delta row is ever written or re-read; "
+                   "matrix pipe busy over wave-resident time, clock and instruction mix: the fields above (the clock is GRBM_GUI_ACTIVE per XCD "
+                   "over the kernel's duration in a traced iteration); executed MFMA work is about 1.1 x the algorithmic FLOP (encoding "
+                   "products padded to 64 columns); two lock-stepped waves per SIMD cannot overlap the VALU work (mask application, "
+                   "delta-tile stores, bias sums, operand addressing) with the matrix pipe; a quarter of the wave time waits (barriers, "
+                   "DMA); the LDS bank conflicts are the 2-way ones of the 8-byte row-block reads, which the operand-read ablations of the "
+                   "probe show not to matter",
+        "algorithmic": {"samples": 262144, "flop_delta_plus_weight_gradients_executed": 262144 * (36864 - 8192 + 48896 - 8192),
+                        "flop_delta_plus_weight_gradients_of_the_reference": 262144 * (36864 + 48896), "tape_bytes_read_once": 262144 * 1792,
+                        "mfma_issue_floor_us_at_2.4GHz": 134.8},
         "iteration_ab_same_box": ab,
         "probe": f"profiles/{tag}_raw/fused_backward_probe.txt", "kernel_traces": f"profiles/{tag}_raw/iteration_kernels_*.txt",
     }, open(os.path.join(P, f"{tag}_pmc_fused_backward.json"), "w"), indent=1)
